@@ -1,0 +1,359 @@
+"""Pure-Python big-int reference for the commit/open hot path of arkworks poly-commit.
+
+TEST INFRASTRUCTURE ONLY (see oracle/README.md).  Nothing in the product path imports this.
+
+This is the *second opinion* behind the C++ oracle (oracle/oracle.cpp): every primitive is
+re-derived here with Python arbitrary-precision integers, independently of both the C++
+oracle (64-bit limbs) and the HIP code (32-bit limbs).  It also generates the golden
+fixtures under tests/golden/ (tools/gen_golden.py).
+
+Reference anchors (relative to /root/reference):
+  * MSM semantics            poly-commit/src/kzg10/mod.rs:175-178 (msm_bigint: min(len) pairs)
+  * KZG10::commit / open     poly-commit/src/kzg10/mod.rs:157-210, 217-310, 452-470
+  * IPA halving rounds       poly-commit/src/ipa_pc/mod.rs:54-72, 664-711
+  * reed_solomon / NTT       poly-commit/src/linear_codes/utils.rs:112-127, pinned by
+                             test_reed_solomon :303-331 (natural order, arkworks omega)
+  * Ligero dimensions        poly-commit/src/linear_codes/ligero.rs:118-128,
+                             poly-commit/src/linear_codes/utils.rs:156-184
+The field/curve arithmetic itself lives in crates.io ark-ff/ark-ec/ark-poly 0.5 (not in
+/root/reference); it is restated from the published definitions of the curves.
+"""
+import math
+
+# ----------------------------------------------------------------------------------------
+# Fields.  name -> (modulus, multiplicative generator used by arkworks, two-adicity)
+# ----------------------------------------------------------------------------------------
+FIELDS = {
+    "bls12_381_fq": dict(
+        p=0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+        gen=2, limbs64=6),
+    "bls12_381_fr": dict(
+        p=0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+        gen=7, limbs64=4),
+    "bn254_fq": dict(
+        p=21888242871839275222246405745257275088696311157297823662689037894645226208583,
+        gen=3, limbs64=4),
+    "bn254_fr": dict(
+        p=21888242871839275222246405745257275088548364400416034343698204186575808495617,
+        gen=5, limbs64=4),
+    # ark-pallas naming: Fq = base field of Pallas, Fr = scalar field of Pallas.
+    "pallas_fq": dict(
+        p=0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+        gen=5, limbs64=4),
+    "pallas_fr": dict(
+        p=0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,
+        gen=5, limbs64=4),
+}
+
+
+def two_adicity(p):
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s += 1
+        t //= 2
+    return s
+
+
+def two_adic_root(field):
+    """arkworks FftField::TWO_ADIC_ROOT_OF_UNITY = GENERATOR^((p-1)/2^s)."""
+    f = FIELDS[field]
+    p = f["p"]
+    s = two_adicity(p)
+    return pow(f["gen"], (p - 1) >> s, p)
+
+
+def root_of_unity(field, log_n):
+    """omega of the radix-2 domain of size 2^log_n (ark-poly Radix2EvaluationDomain::new):
+    TWO_ADIC_ROOT_OF_UNITY ^ (2^(s - log_n))."""
+    p = FIELDS[field]["p"]
+    s = two_adicity(p)
+    assert log_n <= s
+    return pow(two_adic_root(field), 1 << (s - log_n), p)
+
+
+# ----------------------------------------------------------------------------------------
+# Curves (all short Weierstrass, a = 0):  y^2 = x^3 + b over Fq, scalar field Fr.
+# ----------------------------------------------------------------------------------------
+CURVES = {
+    "bls12_381": dict(
+        fq="bls12_381_fq", fr="bls12_381_fr", b=4,
+        gx=0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+        gy=0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1),
+    "bn254": dict(fq="bn254_fq", fr="bn254_fr", b=3, gx=1, gy=2),
+    "pallas": dict(
+        fq="pallas_fq", fr="pallas_fr", b=5,
+        gx=FIELDS["pallas_fq"]["p"] - 1, gy=2),
+}
+
+INF = None  # point at infinity
+
+
+def curve_params(curve):
+    c = CURVES[curve]
+    return FIELDS[c["fq"]]["p"], FIELDS[c["fr"]]["p"], c["b"]
+
+
+def on_curve(curve, P):
+    if P is INF:
+        return True
+    p, _, b = curve_params(curve)
+    x, y = P
+    return (y * y - x * x * x - b) % p == 0
+
+
+def ec_neg(curve, P):
+    if P is INF:
+        return INF
+    p = curve_params(curve)[0]
+    return (P[0], (-P[1]) % p)
+
+
+def ec_add(curve, P, Q):
+    p = curve_params(curve)[0]
+    if P is INF:
+        return Q
+    if Q is INF:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % p == 0:
+            return INF
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    y3 = (lam * (x1 - x3) - y1) % p
+    return (x3, y3)
+
+
+def ec_mul(curve, k, P):
+    R = INF
+    Q = P
+    while k:
+        if k & 1:
+            R = ec_add(curve, R, Q)
+        Q = ec_add(curve, Q, Q)
+        k >>= 1
+    return R
+
+
+def generator(curve):
+    c = CURVES[curve]
+    return (c["gx"], c["gy"])
+
+
+def msm(curve, bases, scalars):
+    """Sum k_i * P_i over min(len) pairs (ark-ec msm_bigint truncation semantics)."""
+    acc = INF
+    for P, k in zip(bases, scalars):
+        acc = ec_add(curve, acc, ec_mul(curve, k, P))
+    return acc
+
+
+def gen_bases(curve, n):
+    """Synthetic SRS stand-in P_i = (i+1)*G."""
+    G = generator(curve)
+    out, cur = [], G
+    for _ in range(n):
+        out.append(cur)
+        cur = ec_add(curve, cur, G)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# Deterministic scalar generator (SplitMix64, rejection sampled) -- SURVEY.md section 8d.
+# ----------------------------------------------------------------------------------------
+M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & M64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+
+def gen_scalars(field, seed, n):
+    """n field elements uniform in [0,p): four u64 limbs (LE), top limb masked to the
+    modulus bit length, rejection sampled."""
+    p = FIELDS[field]["p"]
+    nl = FIELDS[field]["limbs64"]
+    bits = p.bit_length()
+    top_mask = (1 << (bits - 64 * (nl - 1))) - 1
+    rng = SplitMix64(seed)
+    out = []
+    while len(out) < n:
+        limbs = [rng.next() for _ in range(nl)]
+        limbs[-1] &= top_mask
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < p:
+            out.append(v)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# NTT / Reed-Solomon
+# ----------------------------------------------------------------------------------------
+def ntt_naive(field, coeffs, log_n):
+    """out[j] = sum_i coeffs[i] * omega^(i*j), natural order (O(n*m))."""
+    p = FIELDS[field]["p"]
+    n = 1 << log_n
+    w = root_of_unity(field, log_n)
+    out = []
+    for j in range(n):
+        wj = pow(w, j, p)
+        acc = 0
+        for c in reversed(coeffs):
+            acc = (acc * wj + c) % p
+        out.append(acc)
+    return out
+
+
+def ntt(field, coeffs, log_n):
+    """Iterative radix-2 DIT, natural in / natural out."""
+    p = FIELDS[field]["p"]
+    n = 1 << log_n
+    a = list(coeffs) + [0] * (n - len(coeffs))
+    # bit reversal
+    j = 0
+    for i in range(1, n):
+        bit = n >> 1
+        while j & bit:
+            j ^= bit
+            bit >>= 1
+        j |= bit
+        if i < j:
+            a[i], a[j] = a[j], a[i]
+    length = 2
+    while length <= n:
+        wl = root_of_unity(field, length.bit_length() - 1)
+        for i in range(0, n, length):
+            w = 1
+            for k in range(length // 2):
+                u = a[i + k]
+                v = a[i + k + length // 2] * w % p
+                a[i + k] = (u + v) % p
+                a[i + k + length // 2] = (u - v) % p
+                w = w * wl % p
+        length <<= 1
+    return a
+
+
+def reed_solomon(field, msg, rho_inv):
+    """linear_codes/utils.rs:112-127: domain = next_pow2(len*rho_inv); fft(msg)."""
+    m = len(msg)
+    size = 1
+    while size < m * rho_inv:
+        size <<= 1
+    return ntt(field, msg, size.bit_length() - 1)
+
+
+# ----------------------------------------------------------------------------------------
+# Ligero shape (linear_codes/utils.rs:156-184, ligero.rs:118-128)
+# ----------------------------------------------------------------------------------------
+def ceil_div(a, b):
+    return (a + b - 1) // b
+
+
+def ark_log2(x):
+    """ark_std::log2 = ceil(log2 x), 0 for x <= 1."""
+    if x <= 1:
+        return 0
+    return (x - 1).bit_length()
+
+
+def calculate_t(field_bits, sec_param, distance, codeword_len):
+    residual = codeword_len / 2.0 ** field_bits
+    rhs = math.log2(2.0 ** (-sec_param) - residual)
+    nom = rhs - 1.0
+    denom = math.log2(1.0 - 0.5 * distance[0] / distance[1])
+    t = math.ceil(nom / denom)
+    return t if t < codeword_len else codeword_len
+
+
+def ligero_dimensions(field, poly_len, rho_inv=4, sec_param=128):
+    bits = FIELDS[field]["p"].bit_length()
+    t = calculate_t(bits, sec_param, (rho_inv - 1, rho_inv), poly_len)
+    n = 1 << ark_log2(math.ceil(math.sqrt(ceil_div(2 * poly_len, t))))
+    m = ceil_div(poly_len, n)
+    return n, m, t
+
+
+# ----------------------------------------------------------------------------------------
+# KZG10 commit / open (hiding off), restating kzg10/mod.rs
+# ----------------------------------------------------------------------------------------
+def skip_leading_zeros(coeffs):
+    lz = 0
+    while lz < len(coeffs) and coeffs[lz] == 0:
+        lz += 1
+    return lz, coeffs[lz:]
+
+
+def kzg_commit(curve, powers_of_g, coeffs):
+    lz, plain = skip_leading_zeros(coeffs)
+    return msm(curve, powers_of_g[lz:], plain)
+
+
+def witness_polynomial(field, coeffs, z):
+    """Quotient of p(x) by (x - z) (kzg10/mod.rs:217-240); synthetic division."""
+    p = FIELDS[field]["p"]
+    n = len(coeffs)
+    if n <= 1:
+        return []
+    q = [0] * (n - 1)
+    acc = 0
+    for i in range(n - 1, 0, -1):
+        acc = (coeffs[i] + z * acc) % p
+        q[i - 1] = acc
+    return q
+
+
+def kzg_open(curve, powers_of_g, coeffs, z):
+    fr = CURVES[curve]["fr"]
+    return kzg_commit(curve, powers_of_g, witness_polynomial(fr, coeffs, z))
+
+
+def poly_eval(field, coeffs, z):
+    p = FIELDS[field]["p"]
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * z + c) % p
+    return acc
+
+
+# ----------------------------------------------------------------------------------------
+# IPA halving rounds with an externally supplied challenge list (ipa_pc/mod.rs:664-711).
+# ----------------------------------------------------------------------------------------
+def ipa_rounds(curve, comm_key, coeffs, z_point, h_prime, challenges):
+    """Returns (l_vec, r_vec, final_key, final_coeff)."""
+    fr = FIELDS[CURVES[curve]["fr"]]["p"]
+    n = len(coeffs)
+    assert n == len(comm_key) and n & (n - 1) == 0
+    zs = [pow(z_point, i, fr) for i in range(n)]
+    key = list(comm_key)
+    cs = list(coeffs)
+    l_vec, r_vec = [], []
+    rnd = 0
+    while n > 1:
+        h = n // 2
+        ip_l = sum(a * b for a, b in zip(cs[h:n], zs[:h])) % fr
+        ip_r = sum(a * b for a, b in zip(cs[:h], zs[h:n])) % fr
+        l = ec_add(curve, msm(curve, key[:h], cs[h:n]), ec_mul(curve, ip_l, h_prime))
+        r = ec_add(curve, msm(curve, key[h:n], cs[:h]), ec_mul(curve, ip_r, h_prime))
+        l_vec.append(l)
+        r_vec.append(r)
+        u = challenges[rnd]
+        rnd += 1
+        ui = pow(u, -1, fr)
+        for i in range(h):
+            cs[i] = (cs[i] + ui * cs[h + i]) % fr
+            zs[i] = (zs[i] + u * zs[h + i]) % fr
+            key[i] = ec_add(curve, key[i], ec_mul(curve, u, key[h + i]))
+        n = h
+    return l_vec, r_vec, key[0], cs[0]
