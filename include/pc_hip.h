@@ -1,0 +1,93 @@
+/* pc_hip.h -- C ABI of the MI355X (gfx950) backend for the commit/open hot path of
+ * arkworks-rs/poly-commit.
+ *
+ * Each entry point replaces one call the reference makes into its (external) arithmetic
+ * crates; a Rust shim crate binds these with `extern "C"`.  Citations
+ * are relative to the reference checkout.
+ *
+ * Conventions (identical to arkworks' in-memory representations, so buffers cross the FFI
+ * without conversion):
+ *   - field element: little-endian limbs, Montgomery form, 32 bytes (Fr of all three curves,
+ *     Fq of BN254 / Pallas) or 48 bytes (Fq of BLS12-381)       [ark-ff Fp<MontBackend>]
+ *   - "bigint" scalar: canonical residue, 32 bytes LE               [F::into_bigint()]
+ *   - affine point: x || y (Montgomery).  With stride == 2*sizeof(Fq) the point at infinity
+ *     is encoded as (0,0); with a larger stride (Rust `Affine{x,y,infinity:bool}`, 104 / 72
+ *     bytes) the byte at offset 2*sizeof(Fq) is the infinity flag.
+ * All functions return PC_OK (0) or a negative pc_status; they never abort or throw across
+ * the boundary.  A pc_ctx is bound to one GPU; calls on one ctx are serialised by an
+ * internal mutex (the reference is called from arbitrary rayon threads, e.g.
+ * poly-commit/src/hyrax/mod.rs:233-242).
+ */
+#ifndef PC_HIP_H
+#define PC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pc_ctx pc_ctx;
+typedef struct pc_srs pc_srs;
+
+typedef enum { PC_CURVE_BLS12_381 = 0, PC_CURVE_BN254 = 1, PC_CURVE_PALLAS = 2 } pc_curve;
+typedef enum { PC_SCALARS_CANONICAL = 0, PC_SCALARS_MONTGOMERY = 1 } pc_scalar_form;
+typedef enum { PC_MEM_HOST = 0, PC_MEM_DEVICE = 1 } pc_mem;
+
+typedef enum {
+  PC_OK = 0,
+  PC_ERR_INVALID_ARG = -1,
+  PC_ERR_OOM = -2,
+  PC_ERR_HIP = -3,
+  PC_ERR_NO_DEVICE = -4,
+  PC_ERR_TOO_LARGE = -5,
+  PC_ERR_UNSUPPORTED = -6
+} pc_status;
+
+/* Library / device lifetime. */
+int pc_hip_device_count(void);
+int pc_hip_init(int device_id, pc_ctx** out);
+void pc_hip_shutdown(pc_ctx* ctx);
+const char* pc_hip_strerror(int status);
+/* Last HIP error string recorded on this ctx (for Error::InvalidParameters(String)). */
+const char* pc_hip_last_error(const pc_ctx* ctx);
+
+/* SRS residency.  Replaces nothing in the reference -- it is the hook MarlinKZG10::trim
+ * (poly-commit/src/marlin/marlin_pc/mod.rs:80-169, powers copied at :96) and
+ * InnerProductArgPC::trim (ipa_pc/mod.rs:359-401) call once per committer key so that
+ * `powers_of_g` / `comm_key` stay in HBM across commit/open calls.
+ * n_max_scalars bounds the MSM length later issued against this SRS (0 = n). */
+int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, size_t stride_bytes,
+                      pc_mem where, pc_srs** out);
+void pc_hip_srs_free(pc_srs* srs);
+size_t pc_hip_srs_len(const pc_srs* srs);
+/* Device pointer of the packed (x||y) resident bases, for callers that build on it. */
+void* pc_hip_srs_device_ptr(const pc_srs* srs);
+
+/* Variable-base MSM:  out = sum_{i<n} scalars[i] * bases[base_offset + i].
+ * Replaces <E::G1 as VariableBaseMSM>::msm_bigint(&powers_of_g[lz..], &coeffs) at
+ * poly-commit/src/kzg10/mod.rs:175-178 and :255-258, and ipa_pc/mod.rs:64.
+ * form = PC_SCALARS_MONTGOMERY accepts the polynomial's coefficient slice as it lies in
+ * memory and fuses convert_to_bigints (kzg10/mod.rs:463-470) into the digit kernel.
+ * out_xy: 2*sizeof(Fq) bytes on the host, affine, Montgomery; *out_is_infinity set if the
+ * sum is the identity (out_xy is then all zero). */
+int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars,
+               pc_scalar_form form, pc_mem where, size_t n, void* out_xy, int* out_is_infinity);
+
+/* Batched MSM over one SRS (MarlinKZG10::commit's sequential loop over polynomials,
+ * marlin_pc/mod.rs:192-237): n_polys independent scalar vectors, out_xy holds n_polys points. */
+int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs, const size_t* base_offsets,
+                     const void* const* scalars, const size_t* n, size_t n_polys,
+                     pc_scalar_form form, pc_mem where, void* out_xy, int* out_is_infinity);
+
+/* Tuning (optional): window bits c (0 = auto), level-0 chunk length T (0 = auto).  Applies
+ * to SRS objects uploaded afterwards. */
+int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
+
+/* Kernel-only timing of the last MSM issued on this ctx, in milliseconds, by phase
+ * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py. */
+int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PC_HIP_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of include/pc_hip.h.  No fallbacks: if the HIP library is missing or no
+GPU is present, construction fails loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CURVES = {"bls12_381": 0, "bn254": 1, "pallas": 2}
+FQ_BYTES = {"bls12_381": 48, "bn254": 32, "pallas": 32}
+PC_MEM_HOST, PC_MEM_DEVICE = 0, 1
+PC_SCALARS_CANONICAL, PC_SCALARS_MONTGOMERY = 0, 1
+
+_lib = None
+
+
+class PcHipError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__(f"pc_hip status {status}: {msg}")
+        self.status = status
+
+
+def library_path():
+    return os.path.join(HERE, "libpc_hip.so")
+
+
+def load_library():
+    """Load libpc_hip.so (built by poly-commit_amd/build.py).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise PcHipError(-100, f"{path} not built: run python -m poly_commit_amd.build "
+                               "(or __graft_entry__.build())")
+    lib = C.CDLL(path)
+    vp, sz, ip = C.c_void_p, C.c_size_t, C.c_int
+    lib.pc_hip_device_count.restype = ip
+    lib.pc_hip_init.argtypes = [ip, C.POINTER(vp)]
+    lib.pc_hip_shutdown.argtypes = [vp]
+    lib.pc_hip_shutdown.restype = None
+    lib.pc_hip_strerror.argtypes = [ip]
+    lib.pc_hip_strerror.restype = C.c_char_p
+    lib.pc_hip_last_error.argtypes = [vp]
+    lib.pc_hip_last_error.restype = C.c_char_p
+    lib.pc_hip_srs_upload.argtypes = [vp, ip, vp, sz, sz, ip, C.POINTER(vp)]
+    lib.pc_hip_srs_free.argtypes = [vp]
+    lib.pc_hip_srs_free.restype = None
+    lib.pc_hip_srs_len.argtypes = [vp]
+    lib.pc_hip_srs_len.restype = sz
+    lib.pc_hip_srs_device_ptr.argtypes = [vp]
+    lib.pc_hip_srs_device_ptr.restype = vp
+    lib.pc_hip_msm.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip)]
+    lib.pc_hip_msm_batch.argtypes = [vp, vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), sz, ip, ip, vp,
+                                     C.POINTER(ip)]
+    lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
+    lib.pc_hip_set_timing.argtypes = [vp, ip]
+    lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def _ptr(x):
+    """host numpy array -> (void*, PC_MEM_HOST); torch cuda tensor / int -> (void*, PC_MEM_DEVICE)."""
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return C.c_void_p(x.ctypes.data), PC_MEM_HOST
+    if isinstance(x, int):
+        return C.c_void_p(x), PC_MEM_DEVICE
+    if hasattr(x, "data_ptr"):   # torch tensor
+        assert x.is_contiguous()
+        return C.c_void_p(x.data_ptr()), (PC_MEM_DEVICE if x.is_cuda else PC_MEM_HOST)
+    raise TypeError(type(x))
+
+
+class Context:
+    """One GPU (pc_ctx)."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.pc_hip_init(device_id, C.byref(h))
+        if rc != 0:
+            raise PcHipError(rc, self.lib.pc_hip_strerror(rc).decode())
+        self.h = h
+        self.device_id = device_id
+
+    def check(self, rc):
+        if rc != 0:
+            raise PcHipError(rc, self.lib.pc_hip_strerror(rc).decode() + " / " +
+                             self.lib.pc_hip_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.pc_hip_shutdown(self.h)
+            self.h = None
+
+    def set_msm_tuning(self, window_bits=0, chunk=0):
+        self.check(self.lib.pc_hip_set_msm_tuning(self.h, window_bits, chunk))
+
+    def set_timing(self, on=True):
+        self.check(self.lib.pc_hip_set_timing(self.h, 1 if on else 0))
+
+    def last_msm_phases_ms(self):
+        out = (C.c_float * 8)()
+        self.check(self.lib.pc_hip_last_msm_phases_ms(self.h, out))
+        return list(out)
+
+    def upload_srs(self, curve, bases, n=None, stride_bytes=0):
+        return Srs(self, curve, bases, n, stride_bytes)
+
+
+class Srs:
+    """Resident bases (pc_srs): powers_of_g of a KZG committer key, or an IPA comm_key."""
+
+    def __init__(self, ctx, curve, bases, n=None, stride_bytes=0):
+        self.ctx, self.curve = ctx, curve
+        p, where = _ptr(bases)
+        if n is None:
+            n = bases.shape[0]
+        h = C.c_void_p()
+        ctx.check(ctx.lib.pc_hip_srs_upload(ctx.h, CURVES[curve], p, n, stride_bytes, where, C.byref(h)))
+        self.h, self.n = h, n
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.pc_hip_srs_free(self.h)
+            self.h = None
+
+    def msm(self, scalars, n=None, base_offset=0, montgomery=False):
+        """sum scalars[i] * bases[base_offset + i]; returns (xy uint64 array, is_infinity)."""
+        p, where = _ptr(scalars)
+        if n is None:
+            n = scalars.shape[0]
+        out = np.zeros(2 * FQ_BYTES[self.curve] // 8, dtype=np.uint64)
+        inf = C.c_int(0)
+        self.ctx.check(self.ctx.lib.pc_hip_msm(self.ctx.h, self.h, base_offset, p,
+                                               PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
+                                               where, n, C.c_void_p(out.ctypes.data), C.byref(inf)))
+        return out, bool(inf.value)

@@ -1,0 +1,109 @@
+// Short-Weierstrass a = 0 group arithmetic for the MSM buckets.
+//
+// Bases are affine (x, y) in Montgomery form -- the in-memory form of arkworks'
+// short_weierstrass::Affine without the `infinity` flag; infinity is encoded as (0, 0),
+// which is never on y^2 = x^3 + b with b != 0.  Buckets use XYZZ (extended Jacobian)
+// coordinates: x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2; infinity <=> ZZ == 0.  Mixed addition
+// costs 8M + 2S (madd-2008-s), full addition 12M + 2S (add-2008-s), doubling 6M + 4S... see
+// the Explicit-Formulas Database, "XYZZ coordinates for short Weierstrass curves".
+//
+// Results are handed back as affine points, which are canonical: any correct schedule is
+// bit-identical to ark-ec's msm_bigint followed by into_affine
+// (poly-commit/src/kzg10/mod.rs:175-178, :209).
+#pragma once
+#include "fp32.hpp"
+
+namespace pc {
+
+template <class C>
+struct AffD {
+  typedef Fd<typename C::FqP> Fq;
+  Fq x, y;
+  static PC_HD AffD infinity() { AffD a; a.x = Fq::zero(); a.y = Fq::zero(); return a; }
+  PC_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  static PC_HD AffD load(const uint32_t* p) { AffD a; a.x = Fq::load(p); a.y = Fq::load(p + Fq::N); return a; }
+  PC_HD void store(uint32_t* p) const { x.store(p); y.store(p + Fq::N); }
+  PC_HD AffD neg_if(bool s) const { AffD a; a.x = x; a.y = s ? y.neg() : y; return a; }
+};
+
+template <class C>
+struct XyzzD {
+  typedef Fd<typename C::FqP> Fq;
+  static constexpr int WORDS = 4 * Fq::N;
+  Fq X, Y, ZZ, ZZZ;
+
+  static PC_HD XyzzD infinity() { XyzzD r; r.X = Fq::zero(); r.Y = Fq::zero(); r.ZZ = Fq::zero(); r.ZZZ = Fq::zero(); return r; }
+  PC_HD bool is_inf() const { return ZZ.is_zero(); }
+  static PC_HD XyzzD from_affine(const AffD<C>& a) {
+    XyzzD r;
+    if (a.is_inf()) return infinity();
+    r.X = a.x; r.Y = a.y; r.ZZ = Fq::one(); r.ZZZ = Fq::one(); return r;
+  }
+  static PC_HD XyzzD load(const uint32_t* p) {
+    XyzzD r; r.X = Fq::load(p); r.Y = Fq::load(p + Fq::N); r.ZZ = Fq::load(p + 2 * Fq::N); r.ZZZ = Fq::load(p + 3 * Fq::N); return r;
+  }
+  PC_HD void store(uint32_t* p) const { X.store(p); Y.store(p + Fq::N); ZZ.store(p + 2 * Fq::N); ZZZ.store(p + 3 * Fq::N); }
+
+  // 2 * (affine point), mdbl-2008-s-1 with a = 0.
+  static PC_HD XyzzD dbl_affine(const AffD<C>& a) {
+    if (a.is_inf() || a.y.is_zero()) return infinity();
+    XyzzD r;
+    Fq U = a.y.dbl(), V = U.sqr(), W = U.mul(V), S = a.x.mul(V);
+    Fq xx = a.x.sqr(), M = xx.dbl().add(xx);
+    r.X = M.sqr().sub(S.dbl());
+    r.Y = M.mul(S.sub(r.X)).sub(W.mul(a.y));
+    r.ZZ = V; r.ZZZ = W;
+    return r;
+  }
+  // dbl-2008-s-1 with a = 0.
+  PC_HD XyzzD dbl() const {
+    if (is_inf() || Y.is_zero()) return infinity();
+    XyzzD r;
+    Fq U = Y.dbl(), V = U.sqr(), W = U.mul(V), S = X.mul(V);
+    Fq xx = X.sqr(), M = xx.dbl().add(xx);
+    r.X = M.sqr().sub(S.dbl());
+    r.Y = M.mul(S.sub(r.X)).sub(W.mul(Y));
+    r.ZZ = V.mul(ZZ); r.ZZZ = W.mul(ZZZ);
+    return r;
+  }
+  // this += affine (madd-2008-s), all special cases handled.
+  PC_HD void add_affine(const AffD<C>& a) {
+    if (a.is_inf()) return;
+    if (is_inf()) { X = a.x; Y = a.y; ZZ = Fq::one(); ZZZ = Fq::one(); return; }
+    Fq U2 = a.x.mul(ZZ), S2 = a.y.mul(ZZZ);
+    Fq Pp = U2.sub(X), R = S2.sub(Y);
+    if (Pp.is_zero()) {
+      if (R.is_zero()) *this = dbl_affine(a); else *this = infinity();
+      return;
+    }
+    Fq PP = Pp.sqr(), PPP = Pp.mul(PP), Q = X.mul(PP);
+    Fq X3 = R.sqr().sub(PPP).sub(Q.dbl());
+    Y = R.mul(Q.sub(X3)).sub(Y.mul(PPP));
+    X = X3;
+    ZZ = ZZ.mul(PP); ZZZ = ZZZ.mul(PPP);
+  }
+  // this += o (add-2008-s), all special cases handled.
+  PC_HD void add(const XyzzD& o) {
+    if (o.is_inf()) return;
+    if (is_inf()) { *this = o; return; }
+    Fq U1 = X.mul(o.ZZ), U2 = o.X.mul(ZZ), S1 = Y.mul(o.ZZZ), S2 = o.Y.mul(ZZZ);
+    Fq Pp = U2.sub(U1), R = S2.sub(S1);
+    if (Pp.is_zero()) {
+      if (R.is_zero()) *this = dbl(); else *this = infinity();
+      return;
+    }
+    Fq PP = Pp.sqr(), PPP = Pp.mul(PP), Q = U1.mul(PP);
+    Fq X3 = R.sqr().sub(PPP).sub(Q.dbl());
+    Y = R.mul(Q.sub(X3)).sub(S1.mul(PPP));
+    X = X3;
+    ZZ = ZZ.mul(o.ZZ).mul(PP); ZZZ = ZZZ.mul(o.ZZZ).mul(PPP);
+  }
+  PC_HD AffD<C> to_affine() const {
+    if (is_inf()) return AffD<C>::infinity();
+    // x = X / ZZ, y = Y / ZZZ ; one inversion of ZZ*ZZZ
+    Fq t = ZZ.mul(ZZZ).inv();
+    AffD<C> a; a.x = X.mul(t.mul(ZZZ)); a.y = Y.mul(t.mul(ZZ)); return a;
+  }
+};
+
+}  // namespace pc

@@ -1,0 +1,78 @@
+// HIP execution backend for the orchestration templates (msm.hpp, ...): one stream, every
+// kernel body launched through a single generic __global__ wrapper, scans through hipCUB.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdexcept>
+#include <string>
+
+namespace pc {
+
+struct HipError : std::runtime_error {
+  hipError_t code;
+  HipError(hipError_t c, const char* what) : std::runtime_error(std::string(what) + ": " + hipGetErrorString(c)), code(c) {}
+};
+#define PC_HIP_CHECK(expr)                                        \
+  do {                                                            \
+    hipError_t _e = (expr);                                       \
+    if (_e != hipSuccess) throw ::pc::HipError(_e, #expr);        \
+  } while (0)
+
+template <class Body>
+__global__ void __launch_bounds__(256) k_run(Body body, uint32_t lanes) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < lanes) body(i);
+}
+
+struct HipBackend {
+  hipStream_t stream = nullptr;
+  void* scan_tmp = nullptr;
+  size_t scan_tmp_bytes = 0;
+  // optional phase timing
+  static constexpr int MAX_EV = 16;
+  hipEvent_t ev[MAX_EV];
+  int n_ev = 0;
+  bool timing = false;
+
+  void init() {
+    PC_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (int i = 0; i < MAX_EV; i++) PC_HIP_CHECK(hipEventCreate(&ev[i]));
+  }
+  void destroy() {
+    if (scan_tmp) (void)hipFree(scan_tmp);
+    for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  void mark() { if (timing && n_ev < MAX_EV) PC_HIP_CHECK(hipEventRecord(ev[n_ev++], stream)); }
+
+  void* alloc(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 4)); return p; }
+  void free(void* p) { if (p) (void)hipFree(p); }
+  void memset(void* p, int v, size_t bytes) { PC_HIP_CHECK(hipMemsetAsync(p, v, bytes, stream)); }
+  void copy_d2d(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
+  void copy_h2d(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream)); }
+  void copy_d2h(void* d, const void* s, size_t bytes) {
+    PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream));
+    PC_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void sync() { PC_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+  void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
+    size_t need = 0;
+    PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, stream));
+    if (need > scan_tmp_bytes) {
+      if (scan_tmp) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(scan_tmp); }
+      PC_HIP_CHECK(hipMalloc(&scan_tmp, need)); scan_tmp_bytes = need;
+    }
+    PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, need, in, out, (int)n, stream));
+  }
+
+  template <class Body>
+  void launch(const Body& body, size_t lanes, int block = 256) {
+    if (lanes == 0) return;
+    dim3 grid((unsigned)((lanes + block - 1) / block));
+    hipLaunchKernelGGL(k_run<Body>, grid, dim3(block), 0, stream, body, (uint32_t)lanes);
+    PC_HIP_CHECK(hipGetLastError());
+  }
+};
+
+}  // namespace pc

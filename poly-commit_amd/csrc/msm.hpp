@@ -1,0 +1,451 @@
+// Variable-base MSM for gfx950: sum_i k_i * P_i over a resident SRS.
+//
+// Replaces <E::G1 as VariableBaseMSM>::msm_bigint at its call sites in the reference
+// (poly-commit/src/kzg10/mod.rs:175-178, :255-258; ipa_pc/mod.rs:64).  The result is
+// returned as an affine point, which is canonical, so it is bit-identical to ark-ec's
+// result after into_affine() whatever the internal schedule.
+//
+// Pipeline (all on one HIP stream, no host round trip until the final download):
+//   1. digits+histogram  one thread per scalar: (optional Montgomery->canonical), signed
+//                        radix-2^c digits, one histogram atomic per non-zero digit
+//   2. exclusive scan    bucket offsets (CSR row pointers)
+//   3. scatter           digits recomputed (cheaper than storing W*n keys), entry =
+//                        base index | sign<<31 written at an atomically claimed slot
+//   4. accumulate        the flat, bucket-sorted entry array is cut into equal chunks of T
+//                        entries, one chunk per lane: every lane executes exactly T mixed
+//                        additions (no load imbalance whatever the scalar distribution).
+//                        Runs that lie wholly inside a chunk are written to their bucket;
+//                        the (at most two) runs cut by a chunk edge go to a partial list.
+//   5. seg-reduce        the partial list (sorted by bucket by construction) is reduced
+//                        level by level with the same chunk rule until every bucket is whole
+//   6. bucket reduce     sum_j (j+1) B_j per window by grouped running sums, recursively:
+//                        Red(X) = sum(Tw) + K * Red(S);  plain sums ride along as a fan-in-K
+//                        tree; leaves one point per (window, level)
+//   7. host tail         <= W*levels points are downloaded and folded with Horner
+//                        (255 dependent doublings: one CPU core beats one GPU lane 40x here)
+//
+// The kernel bodies are functors templated on nothing but the curve; the orchestration is a
+// template over a Backend that provides launch/alloc/scan.  The product instantiates it
+// with HipBackend only (hip_backend.hpp); tests/emu instantiates the same code with a
+// single-threaded CPU stepping backend to validate the indexing logic without a GPU.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "ec.hpp"
+
+namespace pc {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+PC_D uint32_t atomic_inc_u32(uint32_t* p) { return atomicAdd(p, 1u); }
+#else
+inline uint32_t atomic_inc_u32(uint32_t* p) { uint32_t o = *p; *p = o + 1; return o; }
+#endif
+
+static constexpr uint32_t KEY_INVALID = 0xffffffffu;
+
+struct MsmGeom {
+  uint32_t n;          // pairs in this call
+  uint32_t c;          // window bits
+  uint32_t W;          // number of windows (digits per scalar)
+  uint32_t nb_win;     // buckets per window = 2^(c-1)
+  uint32_t NB;         // total buckets = W * nb_win
+  uint32_t base_off;   // offset of this call's first base inside the resident SRS
+  uint32_t from_mont;  // scalars arrive as Montgomery residues
+  uint32_t T;          // level-0 chunk length
+  uint32_t T2;         // level>=1 chunk length
+};
+
+PC_HD uint32_t msm_num_windows(uint32_t bits, uint32_t c) { return bits / c + 1; }
+
+// Signed radix-2^c recoding: digit in [-(2^(c-1)-1), 2^(c-1)].
+// Returns key+1 (0 for a zero digit) and the sign.
+template <class FrP>
+struct ScalarDigits {
+  uint32_t s[FrP::N];
+  PC_HD void load(const uint32_t* p, bool from_mont) {
+    Fd<FrP> f = Fd<FrP>::load(p);
+    if (from_mont) f = f.from_mont();
+    PC_UNROLL for (int i = 0; i < FrP::N; i++) s[i] = f.l[i];
+  }
+  PC_HD uint32_t bits_at(uint32_t off, uint32_t c) const {
+    uint32_t w = off >> 5, b = off & 31;
+    if (w >= (uint32_t)FrP::N) return 0;
+    uint64_t v = s[w];
+    if (w + 1 < (uint32_t)FrP::N) v |= (uint64_t)s[w + 1] << 32;
+    return (uint32_t)(v >> b) & ((1u << c) - 1u);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// 1. digits + histogram
+// ---------------------------------------------------------------------------------------
+template <class C>
+struct DigitsHistBody {
+  typedef typename C::FrP FrP;
+  MsmGeom g;
+  const uint32_t* scalars;   // n x FrP::N
+  uint32_t* hist;            // NB counters (zeroed)
+  PC_HD void operator()(uint32_t i) const {
+    ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (g.c - 1);
+    for (uint32_t w = 0; w < g.W; w++) {
+      uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
+      carry = raw > half;
+      uint32_t mag = carry ? (2 * half - raw) : raw;
+      if (mag) atomic_inc_u32(hist + (size_t)w * g.nb_win + (mag - 1));
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// 3. scatter
+// ---------------------------------------------------------------------------------------
+template <class C>
+struct ScatterBody {
+  typedef typename C::FrP FrP;
+  MsmGeom g;
+  const uint32_t* scalars;
+  uint32_t* cursor;          // NB, initialised to the bucket offsets
+  uint32_t* entries;         // M = offsets[NB] slots
+  PC_HD void operator()(uint32_t i) const {
+    ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (g.c - 1);
+    for (uint32_t w = 0; w < g.W; w++) {
+      uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
+      carry = raw > half;
+      uint32_t mag = carry ? (2 * half - raw) : raw;
+      if (mag) {
+        uint32_t pos = atomic_inc_u32(cursor + (size_t)w * g.nb_win + (mag - 1));
+        entries[pos] = (g.base_off + i) | (carry << 31);
+      }
+    }
+  }
+};
+
+// first index k in [0, n] with a[k] > v, minus one: a[k] <= v < a[k+1]
+PC_HD uint32_t find_bucket(const uint32_t* offs, uint32_t nb, uint32_t v) {
+  uint32_t lo = 0, hi = nb;   // invariant: offs[lo] <= v, answer in [lo, hi)
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offs[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// Slot range [lo, hi] that the partials of bucket `key` occupy at reduction level `level`
+// (level 1 = output of the accumulate kernel).  See the header comment, step 5.
+PC_HD void partial_slot_range(const uint32_t* offs, uint32_t key, uint32_t T, uint32_t T2, uint32_t level,
+                              uint32_t& lo, uint32_t& hi) {
+  lo = 2 * (offs[key] / T);
+  hi = 2 * ((offs[key + 1] - 1) / T);
+  for (uint32_t l = 2; l <= level; l++) { lo = 2 * (lo / T2); hi = 2 * (hi / T2); }
+}
+
+// ---------------------------------------------------------------------------------------
+// 4. accumulate: one chunk of T sorted entries per lane
+// ---------------------------------------------------------------------------------------
+template <class C>
+struct AccumulateBody {
+  typedef XyzzD<C> Pt;
+  static constexpr int AW = 2 * Fd<typename C::FqP>::N;   // words per affine base
+  MsmGeom g;
+  const uint32_t* bases;     // resident SRS, AW words per point
+  const uint32_t* entries;
+  const uint32_t* offsets;   // NB + 1
+  uint32_t* buckets;         // NB x Pt::WORDS (zeroed = infinity)
+  uint32_t* pkeys;           // 2 slots per lane
+  uint32_t* ppts;            // 2 x Pt::WORDS per lane
+  PC_HD void flush(const Pt& acc, uint32_t k, uint32_t s, uint32_t e, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
+    bool complete = offsets[k] >= s && offsets[k + 1] <= e;
+    if (complete) { acc.store(buckets + (size_t)k * Pt::WORDS); return; }
+    uint32_t slot = first ? 2 * t : 2 * t + 1;
+    acc.store(ppts + (size_t)slot * Pt::WORDS);
+    if (first) k0 = k; else k1 = k;
+  }
+  PC_HD void operator()(uint32_t t) const {
+    const uint32_t M = offsets[g.NB];
+    const uint64_t s64 = (uint64_t)t * g.T;
+    uint32_t k0 = KEY_INVALID, k1 = KEY_INVALID;
+    if (s64 < M) {
+      const uint32_t s = (uint32_t)s64;
+      const uint32_t e = (M - s > g.T) ? s + g.T : M;
+      uint32_t k = find_bucket(offsets, g.NB, s);
+      uint32_t boundary = offsets[k + 1];
+      Pt acc = Pt::infinity();
+      bool first = true;
+      uint32_t val = entries[s];
+      AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * AW);
+      for (uint32_t p = s; p < e; p++) {
+        // prefetch the next entry's base while this one is being added
+        uint32_t nval = val; AffD<C> npt = pt;
+        if (p + 1 < e) { nval = entries[p + 1]; npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * AW); }
+        if (p == boundary) {
+          flush(acc, k, s, e, t, first, k0, k1);
+          first = false; acc = Pt::infinity();
+          do { k++; } while (offsets[k + 1] <= p);
+          boundary = offsets[k + 1];
+        }
+        acc.add_affine(pt.neg_if(val >> 31));
+        val = nval; pt = npt;
+      }
+      flush(acc, k, s, e, t, first, k0, k1);
+    }
+    pkeys[2 * t] = k0; pkeys[2 * t + 1] = k1;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// 5. segmented reduction of the partial list, level >= 1 -> level + 1
+// ---------------------------------------------------------------------------------------
+template <class C>
+struct SegReduceBody {
+  typedef XyzzD<C> Pt;
+  MsmGeom g;
+  uint32_t level;            // level of the INPUT slots (>= 1)
+  uint32_t n_in;             // input slots
+  const uint32_t* in_keys; const uint32_t* in_pts;
+  const uint32_t* offsets;
+  uint32_t* buckets;
+  uint32_t* out_keys; uint32_t* out_pts;   // 2 slots per lane
+  PC_HD void flush(const Pt& acc, uint32_t key, uint32_t cs, uint32_t ce, uint32_t u, bool first, uint32_t& k0, uint32_t& k1) const {
+    uint32_t lo, hi; partial_slot_range(offsets, key, g.T, g.T2, level, lo, hi);
+    if (lo >= cs && hi < ce) { acc.store(buckets + (size_t)key * Pt::WORDS); return; }
+    uint32_t slot = first ? 2 * u : 2 * u + 1;
+    acc.store(out_pts + (size_t)slot * Pt::WORDS);
+    if (first) k0 = key; else k1 = key;
+  }
+  PC_HD void operator()(uint32_t u) const {
+    const uint32_t cs = u * g.T2;
+    const uint32_t ce = (n_in - cs > g.T2) ? cs + g.T2 : n_in;
+    uint32_t k0 = KEY_INVALID, k1 = KEY_INVALID;
+    uint32_t cur = KEY_INVALID; bool first = true;
+    Pt acc = Pt::infinity();
+    for (uint32_t p = cs; p < ce; p++) {
+      uint32_t key = in_keys[p];
+      if (key == KEY_INVALID) continue;
+      if (key != cur) {
+        if (cur != KEY_INVALID) { flush(acc, cur, cs, ce, u, first, k0, k1); first = false; }
+        cur = key; acc = Pt::infinity();
+      }
+      acc.add(Pt::load(in_pts + (size_t)p * Pt::WORDS));
+    }
+    if (cur != KEY_INVALID) flush(acc, cur, cs, ce, u, first, k0, k1);
+    out_keys[2 * u] = k0; out_keys[2 * u + 1] = k1;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// 6. bucket reduction level:  X (wb x m) -> S (wb x m/K), Tw (wb x m/K);  plain fan-in-K sums
+//    of the older Tw arrays ride along (which = 1 + j).
+// ---------------------------------------------------------------------------------------
+template <class C>
+struct BucketReduceBody {
+  typedef XyzzD<C> Pt;
+  uint32_t m_in;             // elements per window at this level
+  uint32_t K;                // group size (power of two, <= m_in)
+  uint32_t weight_off;       // 1 at level 0 (weights j+1), 0 afterwards (weights j)
+  uint32_t n_groups_total;   // windows * m_in / K
+  const uint32_t* x;         // input array (windows * m_in points)
+  uint32_t* s_out;           // windows * m_in/K
+  uint32_t* tw_out;          // windows * m_in/K
+  PC_HD void operator()(uint32_t gidx) const {
+    const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;   // windows are contiguous, m_in % K == 0
+    Pt run = Pt::infinity(), acc = Pt::infinity();
+    for (uint32_t j = K; j-- > 0;) {
+      run.add(Pt::load(base + (size_t)j * Pt::WORDS));
+      if (j + weight_off > 0) acc.add(run);
+    }
+    run.store(s_out + (size_t)gidx * Pt::WORDS);
+    acc.store(tw_out + (size_t)gidx * Pt::WORDS);
+  }
+};
+
+template <class C>
+struct PlainSumBody {
+  typedef XyzzD<C> Pt;
+  uint32_t K;
+  const uint32_t* x; uint32_t* out;
+  PC_HD void operator()(uint32_t gidx) const {
+    const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;
+    Pt acc = Pt::infinity();
+    for (uint32_t j = 0; j < K; j++) acc.add(Pt::load(base + (size_t)j * Pt::WORDS));
+    acc.store(out + (size_t)gidx * Pt::WORDS);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Orchestration
+// ---------------------------------------------------------------------------------------
+struct MsmConfig {
+  uint32_t c = 0;            // 0 = choose from n
+  uint32_t T = 0;            // 0 = choose from n*W
+  uint32_t T2 = 16;
+  uint32_t K0 = 8;           // bucket-reduce group size
+  uint32_t target_lanes = 1u << 18;
+};
+
+PC_HD uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+inline uint32_t msm_choose_c(size_t n) {
+  // window width: balances n*W mixed adds against ~2*W*2^(c-1) full adds of the reduction
+  if (n < 32) return 3;
+  uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
+  uint32_t c = lg > 4 ? lg - 4 : 2;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  return c;
+}
+
+template <class C, class Backend>
+class MsmPlan {
+ public:
+  typedef XyzzD<C> Pt;
+  typedef typename C::FrP FrP;
+  static constexpr int AW = 2 * Fd<typename C::FqP>::N;
+
+  MsmPlan(Backend& be, size_t n_max, const MsmConfig& cfg) : be_(be), cfg_(cfg), n_max_(n_max) {
+    if (cfg_.T2 < 4) cfg_.T2 = 4;       // each level must shrink the list: 2*ceil(s/T2) < s
+    if (cfg_.K0 < 2) cfg_.K0 = 2;
+    uint32_t c = cfg.c ? cfg.c : msm_choose_c(n_max);
+    setup_geometry(c, n_max);
+    const size_t Mmax = (size_t)n_max * g_.W;
+    hist_ = (uint32_t*)be_.alloc(((size_t)g_.NB + 1) * 4);
+    offsets_ = (uint32_t*)be_.alloc(((size_t)g_.NB + 1) * 4);
+    cursor_ = (uint32_t*)be_.alloc(((size_t)g_.NB + 1) * 4);
+    entries_ = (uint32_t*)be_.alloc((Mmax ? Mmax : 1) * 4);
+    buckets_ = (uint32_t*)be_.alloc((size_t)g_.NB * Pt::WORDS * 4);
+    scalars_ = (uint32_t*)be_.alloc((n_max ? n_max : 1) * (size_t)FrP::N * 4);
+    // partial levels
+    size_t lanes0 = ceil_div_u32(Mmax ? Mmax : 1, min_T_);
+    size_t slots = 2 * lanes0;
+    for (int i = 0; i < 2; i++) {
+      pk_[i] = (uint32_t*)be_.alloc(slots * 4);
+      pp_[i] = (uint32_t*)be_.alloc(slots * (size_t)Pt::WORDS * 4);
+      slots = 2 * (size_t)ceil_div_u32(slots, cfg_.T2);
+    }
+    // bucket-reduce levels
+    uint32_t m = g_.nb_win; n_levels_ = 0; size_t total = 0;
+    while (m > 1) {
+      uint32_t K = cfg_.K0 < m ? cfg_.K0 : m;
+      lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
+      total += (size_t)(n_levels_ + 2) * g_.W * m;             // S + Tw + older plain arrays
+      n_levels_++;
+    }
+    red_ = (uint32_t*)be_.alloc((total ? total : 1) * (size_t)Pt::WORDS * 4);
+    result_host_.resize((size_t)g_.W * (n_levels_ ? n_levels_ : 1) * Pt::WORDS);
+  }
+  ~MsmPlan() {
+    void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_};
+    for (void* p : ps) be_.free(p);
+  }
+
+  const MsmGeom& geom() const { return g_; }
+  uint32_t* scalar_staging() { return scalars_; }
+
+  // bases_dev: resident SRS; scalars_dev: n x FrP::N words on the device.
+  // Writes the affine result (AW words, Montgomery; (0,0) = infinity) to out_host.
+  void run(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont,
+           uint32_t* out_host) {
+    MsmGeom g = g_;
+    g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
+    const size_t Mmax = n * g.W;
+    if (n == 0) { for (int i = 0; i < AW; i++) out_host[i] = 0; return; }
+    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / cfg_.target_lanes);
+    if (T < min_T_) T = min_T_;
+    if (T > 4096) T = 4096;
+    g.T = T; g.T2 = cfg_.T2;
+
+    be_.memset(hist_, 0, ((size_t)g.NB + 1) * 4);
+    be_.memset(buckets_, 0, (size_t)g.NB * Pt::WORDS * 4);
+    { DigitsHistBody<C> b{g, scalars_dev, hist_}; be_.launch(b, n); }
+    be_.exclusive_scan_u32(hist_, offsets_, (size_t)g.NB + 1);
+    be_.copy_d2d(cursor_, offsets_, ((size_t)g.NB + 1) * 4);
+    { ScatterBody<C> b{g, scalars_dev, cursor_, entries_}; be_.launch(b, n); }
+
+    size_t lanes = ceil_div_u32(Mmax, T);
+    { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.launch(b, lanes); }
+    size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
+    for (;;) {
+      size_t lanes2 = ceil_div_u32(slots, g.T2);
+      SegReduceBody<C> b{g, level, (uint32_t)slots, pk_[cur], pp_[cur], offsets_, buckets_, pk_[cur ^ 1], pp_[cur ^ 1]};
+      be_.launch(b, lanes2);
+      if (lanes2 == 1) break;
+      slots = 2 * lanes2; level++; cur ^= 1;
+    }
+
+    // bucket reduction
+    // layout of red_: per level l: [S_l][Tw_l = P_l][P_{l-1} reduced]...[P_0 reduced], each W * lvl_m_[l] points
+    const uint32_t* x = buckets_;
+    uint32_t* lvl_base = red_;
+    uint32_t* prev_base = nullptr;
+    for (uint32_t l = 0; l < n_levels_; l++) {
+      const uint32_t K = lvl_K_[l], m_out = lvl_m_[l];
+      const size_t cnt = (size_t)g.W * m_out;           // groups at this level
+      const size_t stride = cnt * Pt::WORDS;
+      uint32_t* s_out = lvl_base; uint32_t* tw_out = lvl_base + stride;
+      { BucketReduceBody<C> b{m_out * K, K, l == 0 ? 1u : 0u, (uint32_t)cnt, x, s_out, tw_out}; be_.launch(b, cnt); }
+      for (uint32_t j = 0; j < l; j++) {
+        // older plain array j sits at prev_base + (1 + (l-1-j)) * prev_stride ... see index helpers
+        const size_t prev_stride = (size_t)g.W * lvl_m_[l - 1] * Pt::WORDS;
+        const uint32_t* pin = prev_base + (size_t)(1 + (l - 1 - j)) * prev_stride;
+        uint32_t* pout = lvl_base + (size_t)(1 + (l - j)) * stride;
+        PlainSumBody<C> b{K, pin, pout}; be_.launch(b, cnt);
+      }
+      x = s_out; prev_base = lvl_base; lvl_base += (size_t)(l + 2) * stride;
+    }
+    // download: the last level holds W points per array: [S][P_{L-1}][P_{L-2}]...[P_0]
+    host_tail(prev_base, out_host);
+  }
+
+ private:
+  void setup_geometry(uint32_t c, size_t n_max) {
+    g_.c = c; g_.W = msm_num_windows(FrP::BITS, c); g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
+    g_.n = (uint32_t)n_max; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2;
+    min_T_ = cfg_.T ? cfg_.T : 16;
+  }
+
+  // Horner over (level, window) on the host.  P_j[w] has weight 2^(c*w + k_0 + ... + k_{j-1}).
+  void host_tail(const uint32_t* last_level_dev, uint32_t* out_host) {
+    const uint32_t L = n_levels_, W = g_.W;
+    Pt total = Pt::infinity();
+    if (L == 0) {   // c == 1: one bucket per window, weight 1
+      be_.copy_d2h(result_host_.data(), buckets_, (size_t)W * Pt::WORDS * 4);
+      for (uint32_t w = W; w-- > 0;) {
+        for (uint32_t d = 0; d < g_.c; d++) total = total.dbl();
+        total.add(Pt::load(&result_host_[(size_t)w * Pt::WORDS]));
+      }
+    } else {
+      // arrays 1..L of the last level (array 0 is S, weight 0 -> unused)
+      be_.copy_d2h(result_host_.data(), last_level_dev + (size_t)W * Pt::WORDS, (size_t)W * L * Pt::WORDS * 4);
+      // array index a (0-based after skipping S) holds P_{L-1-a}
+      for (uint32_t w = W; w-- > 0;) {
+        Pt win = Pt::infinity();
+        for (uint32_t j = L; j-- > 0;) {
+          // win = win * 2^{k_j} + P_j
+          uint32_t kj = 0; while ((1u << kj) < lvl_K_[j]) kj++;
+          for (uint32_t d = 0; d < kj; d++) win = win.dbl();
+          win.add(Pt::load(&result_host_[((size_t)(L - 1 - j) * W + w) * Pt::WORDS]));
+        }
+        for (uint32_t d = 0; d < g_.c; d++) total = total.dbl();
+        total.add(win);
+      }
+    }
+    AffD<C> a = total.to_affine();
+    a.store(out_host);
+  }
+
+  Backend& be_;
+  MsmConfig cfg_;
+  size_t n_max_;
+  MsmGeom g_;
+  uint32_t min_T_;
+  uint32_t *hist_, *offsets_, *cursor_, *entries_, *buckets_, *scalars_, *red_;
+  uint32_t* pk_[2]; uint32_t* pp_[2];
+  uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32];
+  std::vector<uint32_t> result_host_;
+};
+
+}  // namespace pc

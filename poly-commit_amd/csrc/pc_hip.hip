@@ -1,0 +1,233 @@
+// C ABI of the gfx950 backend (include/pc_hip.h).  Thin glue: context/SRS lifetime, buffer
+// staging, error translation.  The work is in msm.hpp / ntt.hpp.
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../include/pc_hip.h"
+#include "hip_backend.hpp"
+#include "msm.hpp"
+
+namespace {
+
+struct MsmRunner {
+  virtual ~MsmRunner() {}
+  virtual void run(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont,
+                   uint32_t* out_host) = 0;
+  virtual int affine_words() const = 0;
+};
+
+template <class C>
+struct MsmRunnerT : MsmRunner {
+  pc::HipBackend& be;
+  pc::MsmPlan<C, pc::HipBackend> plan;
+  MsmRunnerT(pc::HipBackend& b, size_t n, const pc::MsmConfig& cfg) : be(b), plan(b, n, cfg) {}
+  void run(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont,
+           uint32_t* out_host) override {
+    const uint32_t* sdev = (const uint32_t*)scalars;
+    be.n_ev = 0; be.mark();
+    if (where == PC_MEM_HOST && n) {
+      be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
+      sdev = plan.scalar_staging();
+    }
+    plan.run(bases, base_off, sdev, n, from_mont, out_host);
+  }
+  int affine_words() const override { return pc::MsmPlan<C, pc::HipBackend>::AW; }
+};
+
+}  // namespace
+
+struct pc_ctx {
+  int device = 0;
+  pc::HipBackend be;
+  std::mutex mu;
+  std::string last_error;
+  pc::MsmConfig msm_cfg;
+  float phases[8] = {0};
+};
+
+struct pc_srs {
+  pc_ctx* ctx = nullptr;
+  pc_curve curve = PC_CURVE_BLS12_381;
+  size_t n = 0;
+  uint32_t* bases = nullptr;     // packed x||y
+  int aw = 0;                    // words per affine point
+  MsmRunner* runner = nullptr;
+};
+
+static int fq_bytes(pc_curve c) { return c == PC_CURVE_BLS12_381 ? 48 : 32; }
+
+template <class Fn>
+static int guarded(pc_ctx* ctx, Fn fn) {
+  try {
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return PC_ERR_HIP; }
+    return fn();
+  } catch (const pc::HipError& e) {
+    ctx->last_error = e.what();
+    return e.code == hipErrorOutOfMemory ? PC_ERR_OOM : PC_ERR_HIP;
+  } catch (const std::bad_alloc&) {
+    ctx->last_error = "host allocation failed"; return PC_ERR_OOM;
+  } catch (const std::exception& e) {
+    ctx->last_error = e.what(); return PC_ERR_HIP;
+  }
+}
+
+extern "C" {
+
+int pc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pc_hip_init(int device_id, pc_ctx** out) {
+  if (!out) return PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = pc_hip_device_count();
+  if (n <= 0) return PC_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return PC_ERR_INVALID_ARG;
+  pc_ctx* ctx = new (std::nothrow) pc_ctx();
+  if (!ctx) return PC_ERR_OOM;
+  ctx->device = device_id;
+  int rc = guarded(ctx, [&]() { ctx->be.init(); return (int)PC_OK; });
+  if (rc != PC_OK) { delete ctx; return rc; }
+  *out = ctx;
+  return PC_OK;
+}
+
+void pc_hip_shutdown(pc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  ctx->be.destroy();
+  delete ctx;
+}
+
+const char* pc_hip_strerror(int status) {
+  switch (status) {
+    case PC_OK: return "ok";
+    case PC_ERR_INVALID_ARG: return "invalid argument";
+    case PC_ERR_OOM: return "out of memory";
+    case PC_ERR_HIP: return "HIP runtime error";
+    case PC_ERR_NO_DEVICE: return "no HIP device";
+    case PC_ERR_TOO_LARGE: return "problem too large for this build";
+    case PC_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+const char* pc_hip_last_error(const pc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk) {
+  if (!ctx || window_bits == 1 || window_bits > 24) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->msm_cfg.c = window_bits; ctx->msm_cfg.T = chunk;
+  return PC_OK;
+}
+
+int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, size_t stride_bytes, pc_mem where,
+                      pc_srs** out) {
+  if (!ctx || !out || (!bases && n) || (int)curve < 0 || (int)curve > 2) return PC_ERR_INVALID_ARG;
+  const size_t pb = 2 * (size_t)fq_bytes(curve);
+  if (stride_bytes == 0) stride_bytes = pb;
+  if (stride_bytes < pb) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 31)) return PC_ERR_TOO_LARGE;
+  if (where == PC_MEM_DEVICE && stride_bytes != pb) return PC_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *out = nullptr;
+  pc_srs* srs = new (std::nothrow) pc_srs();
+  if (!srs) return PC_ERR_OOM;
+  srs->ctx = ctx; srs->curve = curve; srs->n = n; srs->aw = (int)(pb / 4);
+  int rc = guarded(ctx, [&]() {
+    srs->bases = (uint32_t*)ctx->be.alloc((n ? n : 1) * pb);
+    if (n) {
+      if (where == PC_MEM_DEVICE) {
+        ctx->be.copy_d2d(srs->bases, bases, n * pb);
+      } else if (stride_bytes == pb) {
+        ctx->be.copy_h2d(srs->bases, bases, n * pb);
+      } else {
+        // Rust Affine{x, y, infinity}: repack, mapping the flag to the (0,0) encoding
+        std::vector<uint8_t> packed(n * pb);
+        const uint8_t* src = (const uint8_t*)bases;
+        for (size_t i = 0; i < n; i++) {
+          const uint8_t* p = src + i * stride_bytes;
+          if (p[pb]) memset(&packed[i * pb], 0, pb); else memcpy(&packed[i * pb], p, pb);
+        }
+        ctx->be.copy_h2d(srs->bases, packed.data(), n * pb);
+        ctx->be.sync();
+      }
+      ctx->be.sync();
+    }
+    switch (curve) {
+      case PC_CURVE_BLS12_381: srs->runner = new MsmRunnerT<pc_curve_bls12_381>(ctx->be, n, ctx->msm_cfg); break;
+      case PC_CURVE_BN254: srs->runner = new MsmRunnerT<pc_curve_bn254>(ctx->be, n, ctx->msm_cfg); break;
+      default: srs->runner = new MsmRunnerT<pc_curve_pallas>(ctx->be, n, ctx->msm_cfg); break;
+    }
+    return (int)PC_OK;
+  });
+  if (rc != PC_OK) { pc_hip_srs_free(srs); return rc; }
+  *out = srs;
+  return PC_OK;
+}
+
+void pc_hip_srs_free(pc_srs* srs) {
+  if (!srs) return;
+  if (srs->ctx) (void)hipSetDevice(srs->ctx->device);
+  delete srs->runner;
+  if (srs->bases) (void)hipFree(srs->bases);
+  delete srs;
+}
+size_t pc_hip_srs_len(const pc_srs* srs) { return srs ? srs->n : 0; }
+void* pc_hip_srs_device_ptr(const pc_srs* srs) { return srs ? srs->bases : nullptr; }
+
+static int msm_one(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form,
+                   pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
+  if (base_offset > srs->n) return PC_ERR_INVALID_ARG;
+  // msm_bigint semantics: min(bases.len(), scalars.len()) pairs
+  size_t avail = srs->n - base_offset;
+  if (n > avail) n = avail;
+  if (n && !scalars) return PC_ERR_INVALID_ARG;
+  uint32_t* out = (uint32_t*)out_xy;
+  srs->runner->run(srs->bases, (uint32_t)base_offset, scalars, where, n, form == PC_SCALARS_MONTGOMERY, out);
+  if (out_is_infinity) {
+    uint32_t acc = 0;
+    for (int i = 0; i < srs->aw; i++) acc |= out[i];
+    *out_is_infinity = acc == 0;
+  }
+  // phase times
+  pc::HipBackend& be = ctx->be;
+  for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
+  if (be.timing) for (int i = 0; i + 1 < be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], be.ev[i], be.ev[i + 1]);
+  return PC_OK;
+}
+
+int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form,
+               pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
+  if (!ctx || !srs || !out_xy || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() { return msm_one(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity); });
+}
+
+int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs, const size_t* base_offsets, const void* const* scalars,
+                     const size_t* n, size_t n_polys, pc_scalar_form form, pc_mem where, void* out_xy,
+                     int* out_is_infinity) {
+  if (!ctx || !srs || !out_xy || srs->ctx != ctx || (n_polys && (!scalars || !n))) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    for (size_t k = 0; k < n_polys; k++) {
+      int rc = msm_one(ctx, srs, base_offsets ? base_offsets[k] : 0, scalars[k], form, where, n[k],
+                       (uint8_t*)out_xy + k * (size_t)srs->aw * 4, out_is_infinity ? out_is_infinity + k : nullptr);
+      if (rc != PC_OK) return rc;
+    }
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_set_timing(pc_ctx* ctx, int on) { if (!ctx) return PC_ERR_INVALID_ARG; ctx->be.timing = on != 0; return PC_OK; }
+
+int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]) {
+  if (!ctx || !out) return PC_ERR_INVALID_ARG;
+  for (int i = 0; i < 8; i++) out[i] = ctx->phases[i];
+  return PC_OK;
+}
+
+}  // extern "C"

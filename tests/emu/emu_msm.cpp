@@ -1,0 +1,79 @@
+// TEST-ONLY single-threaded stepping backend for the MSM orchestration in
+// poly-commit_amd/csrc/msm.hpp.  It runs every kernel body as a plain loop over the lane
+// index so that the indexing logic (chunking, partial lists, reduction levels, host tail)
+// can be validated against the oracle on a machine without a GPU.  It is NOT part of the
+// product library (libpc_hip.so is built from csrc/ only and instantiates HipBackend only).
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../poly-commit_amd/csrc/msm.hpp"
+
+struct CpuStepBackend {
+  void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
+  void free(void* p) { ::free(p); }
+  void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
+  void copy_d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
+  void copy_d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
+  void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
+    uint32_t acc = 0;
+    for (size_t i = 0; i < n; i++) { uint32_t v = in[i]; out[i] = acc; acc += v; }
+  }
+  template <class B> void launch(const B& body, size_t lanes) {
+    for (size_t i = 0; i < lanes; i++) body((uint32_t)i);
+  }
+};
+
+template <class C>
+static void run(const uint32_t* bases, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int T, int T2, int K0,
+                int from_mont, uint32_t* out) {
+  CpuStepBackend be;
+  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) cfg.K0 = K0;
+  pc::MsmPlan<C, CpuStepBackend> plan(be, n, cfg);
+  plan.run(bases, base_off, scalars, n, from_mont != 0, out);
+}
+
+extern "C" void emu_msm(int curve, const uint32_t* bases, const uint32_t* scalars, size_t n, uint32_t base_off, int c,
+                        int T, int T2, int K0, int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: run<pc_curve_bls12_381>(bases, scalars, n, base_off, c, T, T2, K0, from_mont, out); break;
+    case 1: run<pc_curve_bn254>(bases, scalars, n, base_off, c, T, T2, K0, from_mont, out); break;
+    case 2: run<pc_curve_pallas>(bases, scalars, n, base_off, c, T, T2, K0, from_mont, out); break;
+  }
+}
+
+// field / curve unit hooks (32-bit limb code vs the 64-bit limb oracle)
+template <class P> static void fop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  typedef pc::Fd<P> F; F x = F::load(a), y = F::load(b), r;
+  switch (op) {
+    case 0: r = x.mul(y); break; case 1: r = x.add(y); break; case 2: r = x.sub(y); break;
+    case 3: r = x.inv(); break; case 4: r = x.neg(); break; case 5: r = x.from_mont(); break;
+    default: r = x.to_mont(); break;
+  }
+  r.store(out);
+}
+extern "C" void emu_fop(int curve, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  switch (curve * 2 + which) {
+    case 0: fop<pc_bls12_381_fq>(op, a, b, out); break; case 1: fop<pc_bls12_381_fr>(op, a, b, out); break;
+    case 2: fop<pc_bn254_fq>(op, a, b, out); break;     case 3: fop<pc_bn254_fr>(op, a, b, out); break;
+    case 4: fop<pc_pallas_fq>(op, a, b, out); break;    case 5: fop<pc_pallas_fr>(op, a, b, out); break;
+  }
+}
+template <class C> static void ecop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  typedef pc::XyzzD<C> Pt; typedef pc::AffD<C> A;
+  A pa = A::load(a), pb = A::load(b);
+  Pt r = Pt::from_affine(pa);
+  switch (op) {
+    case 0: r.add_affine(pb); break;
+    case 1: { Pt q = Pt::from_affine(pb); q = q.dbl(); q.add_affine(pb.neg_if(true)); r.add(q); } break;  // via full add, non-trivial ZZ
+    case 2: r = r.dbl(); break;
+    case 3: r = Pt::dbl_affine(pa); break;
+  }
+  r.to_affine().store(out);
+}
+extern "C" void emu_ecop(int curve, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  switch (curve) {
+    case 0: ecop<pc_curve_bls12_381>(op, a, b, out); break;
+    case 1: ecop<pc_curve_bn254>(op, a, b, out); break;
+    case 2: ecop<pc_curve_pallas>(op, a, b, out); break;
+  }
+}

@@ -1,0 +1,127 @@
+"""GPU parity: pc_hip_msm (HIP Pippenger) == CPU oracle, bit for bit, through the C ABI.
+
+Mirrors the reference's cross-implementation pattern (streaming_kzg/tests.rs:40-84: two MSM
+implementations must return equal commitments) and the MSM-linearity check of
+kzg10/mod.rs:520-544 (add_commitments_test)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["bls12_381", "bn254", "pallas"]
+
+
+def _check(srs, curve, bases, scalars, **kw):
+    got, inf = srs.msm(scalars, **kw)
+    off = kw.get("base_offset", 0)
+    want = O.msm_pippenger(curve, bases[off:], scalars, 8, 1)
+    assert (got == want).all(), (curve, len(scalars), kw)
+    assert inf == (not want.any())
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_small_sizes(ctx, curve):
+    nmax = 4200
+    bases = O.gen_bases(curve, nmax)
+    srs = ctx.upload_srs(curve, bases)
+    for n in (0, 1, 2, 31, 32, 33, 257, 4097):
+        scalars = O.gen_scalars(curve, 0x5EED0001 + n, max(n, 1))[:n]
+        _check(srs, curve, bases, scalars)
+    srs.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_edge_scalars(ctx, curve):
+    n = 1500
+    r = R.FIELDS[R.CURVES[curve]["fr"]]["p"]
+    bases = O.gen_bases(curve, n)
+    bases[7] = 0            # a point at infinity among the bases
+    bases[100] = bases[99]  # repeated base
+    srs = ctx.upload_srs(curve, bases)
+    rnd = O.gen_scalars(curve, 99, n)
+    cases = {
+        "zeros": np.zeros((n, 4), dtype=np.uint64),
+        "ones": O.ints_to_limbs([1] * n, 4),
+        "r-1": O.ints_to_limbs([r - 1] * n, 4),
+        "same": np.repeat(rnd[:1], n, axis=0),
+        "half-zero": np.where((np.arange(n) % 2 == 0)[:, None], rnd, 0).astype(np.uint64),
+        "low-hamming": O.ints_to_limbs([1 << (i % 254) for i in range(n)], 4),
+        "window-carry": O.ints_to_limbs([(1 << 254) - 1 - (i << 60) for i in range(n)], 4) if curve != "bn254" else
+                        O.ints_to_limbs([(1 << 253) - 1 - (i << 60) for i in range(n)], 4),
+    }
+    for name, sc in cases.items():
+        sc = np.ascontiguousarray(sc)
+        got, inf = srs.msm(sc)
+        want = O.msm_pippenger(curve, bases, sc, 8, 1)
+        assert (got == want).all(), (curve, name)
+    # P + (-P): scalars (1, r-1) on the repeated base pair cancel
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    sc[99] = O.ints_to_limbs([1], 4)[0]
+    sc[100] = O.ints_to_limbs([r - 1], 4)[0]
+    got, inf = srs.msm(sc)
+    assert inf and not got.any()
+    srs.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_offset_truncation_montgomery(ctx, curve):
+    n = 3000
+    bases = O.gen_bases(curve, n)
+    srs = ctx.upload_srs(curve, bases)
+    scalars = O.gen_scalars(curve, 5, n)
+    # KZG10::commit passes powers_of_g[num_leading_zeros..] (kzg10/mod.rs:175-178)
+    _check(srs, curve, bases, scalars[:1000], base_offset=1234)
+    # msm_bigint uses min(len) pairs: more scalars than bases left
+    got, _ = srs.msm(scalars, base_offset=2000)
+    want = O.msm_pippenger(curve, bases[2000:], scalars[:1000], 8, 1)
+    assert (got == want).all()
+    # Montgomery-form scalars (the polynomial's coefficient slice as it lies in memory)
+    mont = O.f_to_mont(curve, 1, scalars)
+    got, _ = srs.msm(mont, montgomery=True)
+    want = O.msm_pippenger(curve, bases, scalars, 8, 1)
+    assert (got == want).all()
+    srs.free()
+
+
+@pytest.mark.parametrize("c,T", [(4, 1), (7, 3), (10, 16), (13, 64), (16, 0)])
+def test_msm_tunings(ctx, c, T):
+    curve = "bls12_381"
+    n = 5000
+    bases = O.gen_bases(curve, n)
+    scalars = O.gen_scalars(curve, 1234, n)
+    ctx.set_msm_tuning(c, T)
+    try:
+        srs = ctx.upload_srs(curve, bases)
+        _check(srs, curve, bases, scalars)
+        srs.free()
+    finally:
+        ctx.set_msm_tuning(0, 0)
+
+
+def test_msm_linearity(ctx):
+    """commit(f*p) == f*commit(p): add_commitments_test, kzg10/mod.rs:520-544."""
+    curve = "bls12_381"
+    n = 2048
+    fr = R.FIELDS["bls12_381_fr"]["p"]
+    bases = O.gen_bases(curve, n)
+    srs = ctx.upload_srs(curve, bases)
+    s = O.limbs_to_ints(O.gen_scalars(curve, 77, n))
+    f = 0x1234567
+    c1, _ = srs.msm(O.ints_to_limbs(s, 4))
+    c2, _ = srs.msm(O.ints_to_limbs([f * x % fr for x in s], 4))
+    p1 = O.array_to_points(curve, c1)[0]
+    assert R.ec_mul(curve, f, p1) == O.array_to_points(curve, c2)[0]
+    srs.free()
+
+
+def test_msm_2_16_bls(ctx):
+    curve = "bls12_381"
+    n = (1 << 16) + 1
+    bases = O.gen_bases(curve, n)
+    scalars = O.gen_scalars(curve, 0x5EED0001, n)
+    srs = ctx.upload_srs(curve, bases)
+    _check(srs, curve, bases, scalars)
+    srs.free()

@@ -1,0 +1,112 @@
+// gfx950 instruction-rate and field-arithmetic micro-benchmarks (design input for the
+// Montgomery multiplier; not part of the product library).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#include "../poly-commit_amd/csrc/ec.hpp"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_rate(uint32_t* out, uint32_t seed, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = seed * 2654435761u + t, b = a ^ 0x9e3779b9u;
+  uint64_t acc[8];
+  uint32_t x[8];
+  for (int i = 0; i < 8; i++) { acc[i] = a + i; x[i] = b + i * 7; }
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (OP == 0) acc[i] = (uint64_t)x[i] * (uint32_t)acc[i] + acc[i];                 // v_mad_u64_u32
+      if (OP == 1) x[i] = x[i] * (uint32_t)acc[i] + 1;                                   // v_mul_lo_u32 (+add)
+      if (OP == 2) x[i] = __umulhi(x[i], (uint32_t)acc[i]) + x[i];                       // v_mul_hi_u32
+      if (OP == 3) { uint64_t s = acc[i] + ((uint64_t)x[i] << 32 | x[i]); acc[i] = s; } // 64-bit add (add_co + addc)
+      if (OP == 4) x[i] = __umul24(x[i], (uint32_t)acc[i]) + x[i];       // v_mad_u32_u24
+      if (OP == 5) x[i] = x[i] + (uint32_t)acc[i];                                       // v_add_u32
+      if (OP == 6) { double d = __longlong_as_double(acc[i] | 0x3ff0000000000000ull); d = __builtin_fma(d, 1.0000001, 0.5); acc[i] = __double_as_longlong(d); }  // v_fma_f64
+    }
+  }
+  uint32_t r = 0;
+  for (int i = 0; i < 8; i++) r ^= (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32) ^ x[i];
+  out[t] = r;
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_fmul(uint32_t* out, int iters) {
+  typedef pc::Fd<P> F;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  F x = F::one(), y = F::one();
+  x.l[0] += t; y.l[1] ^= t * 77;
+  for (int it = 0; it < iters; it++) { x = x.mul(y); y = y.mul(x); }
+  uint32_t r = 0; for (int i = 0; i < P::N; i++) r ^= x.l[i] ^ y.l[i];
+  out[t] = r;
+}
+template <class P>
+__global__ void __launch_bounds__(256) k_fadd(uint32_t* out, int iters) {
+  typedef pc::Fd<P> F;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  F x = F::one(), y = F::one();
+  x.l[0] += t; y.l[1] ^= t * 77;
+  for (int it = 0; it < iters; it++) { x = x.add(y); y = y.sub(x); }
+  uint32_t r = 0; for (int i = 0; i < P::N; i++) r ^= x.l[i] ^ y.l[i];
+  out[t] = r;
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_madd(uint32_t* out, const uint32_t* pts, int npts, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  pc::XyzzD<C> acc = pc::XyzzD<C>::infinity();
+  constexpr int AW = 2 * C::FqP::N;
+  for (int it = 0; it < iters; it++) {
+    pc::AffD<C> p = pc::AffD<C>::load(pts + (size_t)((t * 31 + it) % npts) * AW);
+    acc.add_affine(p);
+  }
+  uint32_t r = 0; for (int i = 0; i < C::FqP::N; i++) r ^= acc.X.l[i] ^ acc.ZZ.l[i];
+  out[t] = r;
+}
+
+template <class K>
+static float timeit(K launch) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  launch();
+  hipDeviceSynchronize();
+  hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
+  float ms = 0; hipEventElapsedTime(&ms, a, b); return ms;
+}
+
+int main() {
+  int ndev = 0; CHECK(hipGetDeviceCount(&ndev));
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  printf("device %s CUs=%d clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+  const int blocks = 256 * 8, threads = 256;
+  const size_t lanes = (size_t)blocks * threads;
+  uint32_t* out; CHECK(hipMalloc(&out, lanes * 4));
+  const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32(+add)", "v_mul_hi_u32(+add)", "add64 (add_co+addc)", "v_mad_u32_u24", "v_add_u32", "v_fma_f64"};
+  const int iters = 2048;
+#define RATE(OP) { float ms = timeit([&]() { hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(threads), 0, 0, out, 1u, iters); }); \
+    printf("%-22s %8.3f ms  %8.2f Gops/s (lane-ops)\n", names[OP], ms, (double)lanes * iters * 8 / ms * 1e-6); }
+  RATE(0) RATE(1) RATE(2) RATE(3) RATE(4) RATE(5) RATE(6)
+  {
+    const int it = 256;
+    float ms = timeit([&]() { hipLaunchKernelGGL(k_fmul<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
+    printf("fmul bls12_381_fq (12 limbs) %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
+    ms = timeit([&]() { hipLaunchKernelGGL(k_fmul<pc_bn254_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
+    printf("fmul bn254_fq (8 limbs)      %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
+    ms = timeit([&]() { hipLaunchKernelGGL(k_fadd<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it * 8); });
+    printf("fadd+fsub bls12_381_fq       %8.3f ms  %8.2f G addsub/s\n", ms, (double)lanes * it * 8 * 2 / ms * 1e-6);
+  }
+  {
+    // a few points on the curve: (i+1)G is not needed for timing; use the generator only plus doubles
+    typedef pc_curve_bls12_381 C;
+    constexpr int AW = 24;
+    std::vector<uint32_t> h(AW * 64);
+    pc::AffD<C> g; for (int i = 0; i < 12; i++) { g.x.l[i] = C::GX[i]; g.y.l[i] = C::GY[i]; }
+    pc::XyzzD<C> acc = pc::XyzzD<C>::from_affine(g);
+    for (int i = 0; i < 64; i++) { pc::AffD<C> a = acc.to_affine(); a.store(&h[i * AW]); acc.add_affine(g); }
+    uint32_t* dp; CHECK(hipMalloc(&dp, h.size() * 4)); CHECK(hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    const int it = 64;
+    float ms = timeit([&]() { hipLaunchKernelGGL(k_madd<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    printf("XYZZ madd bls12_381          %8.3f ms  %8.2f M madd/s\n", ms, (double)lanes * it / ms * 1e-3);
+  }
+  return 0;
+}
