@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- KZG commit+open hot path on MI355X (BASELINE.json configs[1]).
+
+One step = one MarlinKZG10<Bls12_381> commit + one single-point open of one dense
+polynomial of degree 2^20 per GPU, hiding off (the shape bench-templates times,
+bench-templates/src/lib.rs:69-84,106-138):
+    commit : MSM of d+1 pairs over the resident SRS           (kzg10/mod.rs:175-178)
+    open   : witness polynomial p/(x-z) on the device          (kzg10/mod.rs:217-240)
+             MSM of d pairs                                    (kzg10/mod.rs:255-258)
+SRS, coefficients and the evaluation point's quotient stay in HBM; only the two 96-byte
+affine results come back to the host.  value = G1 (base, scalar) pairs per second, whole job.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ONE polynomial of degree
+N*2^20 whose SRS and coefficients are sharded in contiguous chunks (weak scaling: fixed pairs
+per GPU); each rank runs the full Pippenger on its chunk and the partial commitments /
+opening proofs are combined with an all_gather + EC adds (RCCL has no EC reduce op); the
+division carry crosses ranks as one Fr element.  See poly-commit_amd/sharded.py.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+PAIR_BYTES = {"bls12_381": 128, "bn254": 96, "pallas": 96}   # affine base + 32-byte scalar
+HBM_PEAK_GBPS = 8000.0                                        # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(curve, log_d, budget_s=15.0):
+    """CPU restatement of ark-ec's Pippenger (oracle/, 'port'), timed on this box's cores on a
+    bounded sample: the largest power-of-two MSM that fits the time budget."""
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    n0 = 1 << 14
+    b = O.gen_bases(curve, n0)
+    s = O.gen_scalars(curve, 1, n0)
+    t = time.time()
+    O.msm_pippenger(curve, b, s, cores, 1)
+    rate = n0 / max(time.time() - t, 1e-6)
+    lg = 14
+    while lg < log_d and (1 << (lg + 1)) / rate < budget_s:
+        lg += 1
+    n = 1 << lg
+    b = O.gen_bases(curve, n)
+    s = O.gen_scalars(curve, 2, n)
+    best = None
+    for mode in (1, 0):   # chunk-parallel and window-parallel schedules; keep the faster
+        t = time.time()
+        O.msm_pippenger(curve, b, s, cores, mode)
+        dt = time.time() - t
+        best = dt if best is None else min(best, dt)
+        if dt > budget_s:
+            break
+    return {"value": n / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs, restated ark-ec signed-digit Pippenger "
+                      f"(oracle/oracle.cpp), best of chunk-/window-parallel, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-degree", type=int, default=20)
+    ap.add_argument("--curve", default="bls12_381")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import oracle_lib as O          # synthetic inputs + cpu_baseline leg only (never the measured path)
+    import poly_commit_amd as pc
+    from poly_commit_amd import sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    curve = args.curve
+    d = 1 << args.log_degree
+    n = d + 1 if world == 1 else d          # coefficients held by this rank
+    ctx = pc.Context(local_rank)
+    if args.window_bits or args.chunk:
+        ctx.set_msm_tuning(args.window_bits, args.chunk)
+    ctx.set_timing(True)
+
+    # ---- synthetic inputs: bases (i+1)G, coefficients SplitMix64(seed) -------
+    eng = sharded.HipEngine(ctx, curve)
+    job = sharded.ShardedKzg(eng, curve, rank, world, dist)
+    bases = O.gen_bases(curve, n + 1)       # +1: the open of shard r > 0 reaches one base back
+    job.load_srs_chunk(bases)
+    coeffs_h = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0001 + rank, n))
+    coeffs = torch.from_numpy(coeffs_h.view(np.int64)).cuda()
+    z_mont = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x2EE7, 1))[0]
+    job.set_point(z_mont)
+    torch.cuda.synchronize()
+
+    def step():
+        c = job.commit(coeffs, n)
+        w = job.open(coeffs, n)
+        return c, w
+
+    acc_ms, ph_sum, n_msm = [], np.zeros(8), 0
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for ph in job.last_phases:          # two MSMs per step
+            ph_sum += np.array(ph); n_msm += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    pairs_per_step = world * (2 * n - 1) if world == 1 else world * (2 * n) - 1
+    value = pairs_per_step * args.steps / dt
+    ph = ph_sum / max(n_msm, 1)
+    # dominant kernel = bucket accumulation (phase index 3); algorithmic bytes = pairs * B/pair
+    acc_ms = float(ph[3])
+    pairs_per_launch = (2 * n - 1) / 2.0
+    achieved = pairs_per_launch * PAIR_BYTES[curve] / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+
+    if rank == 0:
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MSM G1-scalar-pairs/sec inside KZG commit+open (MarlinKZG10<Bls12_381> shape, hiding off)",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer)", "data": "synthetic",
+            "config": {"workload": f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{args.log_degree} per GPU, "
+                                   f"SRS resident, hiding off (BASELINE configs[1])",
+                       "curve": curve, "log_degree": args.log_degree, "pairs_per_step": pairs_per_step,
+                       "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients sharded in {world} contiguous chunks, "
+                                                                 f"all_gather of partial points"},
+            "commit_open_per_s": args.steps / dt if world == 1 else None,
+            "msm_phase_ms": {k: float(v) for k, v in zip(
+                ["digits_hist", "scan", "scatter", "accumulate", "seg_reduce", "bucket_reduce"], ph[:6])},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_run<AccumulateBody> (bucket accumulation), avg of hipEvent-timed launches",
+                         "algorithmic_bytes_per_launch": pairs_per_launch * PAIR_BYTES[curve]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(curve, args.log_degree)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

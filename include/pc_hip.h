@@ -87,6 +87,40 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
  * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py. */
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
 
+
+/* Enable/disable hipEvent phase timing on this ctx (off by default). */
+int pc_hip_set_timing(pc_ctx* ctx, int on);
+
+/* Batched forward NTT == reed_solomon(row, rho_inv) for every row of the coefficient matrix:
+ * GeneralEvaluationDomain::<F>::new(m * rho_inv).fft(msg), poly-commit/src/linear_codes/
+ * utils.rs:112-127, called per row from LinearEncode::compute_matrices,
+ * linear_codes/mod.rs:131-135.  `field_of` selects the SCALAR field of that curve.
+ * in: rows x in_cols elements (row-major, Montgomery), in_cols <= 2^log_n; each row is
+ * zero-padded to 2^log_n and transformed; out: rows x 2^log_n, natural order,
+ * out[r][j] = sum_i in[r][i] * omega^(i j) with arkworks' omega (pinned by
+ * test_reed_solomon, utils.rs:303-331). */
+int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem where_in, size_t rows,
+                     size_t in_cols, unsigned log_n, void* out, pc_mem where_out);
+/* Kernel-only milliseconds of the last pc_hip_ntt_batch: [pass A, pass B]. */
+int pc_hip_last_ntt_phases_ms(const pc_ctx* ctx, float out[2]);
+
+/* Witness polynomial q = p / (x - z): KZG10::compute_witness_polynomial,
+ * poly-commit/src/kzg10/mod.rs:217-240.  coeffs: n Fr (Montgomery); z: one Fr (Montgomery,
+ * host); out: n-1 Fr.  Keeps the quotient in HBM between commit and open. */
+int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n,
+                        const void* z_host, void* out, pc_mem where_out);
+/* The same recurrence exposed with a carry, for a polynomial sharded over several GPUs:
+ *   acc = carry_in (or 0);  for i = n-1 .. 0:  acc = coeffs[i] + z*acc;  out[i] = acc.
+ * out has n elements; on the shard that holds coefficient 0, out[0] = p(z) and out[1..n) is
+ * the witness polynomial.  carry_in_host may be NULL. */
+int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n,
+                         const void* z_host, const void* carry_in_host, void* out, pc_mem where_out);
+
+/* Host-side sum of `count` affine points (x||y Montgomery, (0,0) = infinity): the handful of
+ * point additions the reference also performs on the host (e.g. `commitment +=
+ * &random_commitment`, kzg10/mod.rs:206) and the fold of per-GPU partial results. */
+int pc_hip_points_sum(pc_curve curve, const void* points_xy, size_t count, void* out_xy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,11 @@ def load_library():
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
     lib.pc_hip_set_timing.argtypes = [vp, ip]
     lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
+    lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
+    lib.pc_hip_poly_div_scan.argtypes = [vp, ip, vp, ip, sz, vp, vp, vp, ip]
+    lib.pc_hip_points_sum.argtypes = [ip, vp, sz, vp]
     _lib = lib
     return lib
 
@@ -106,6 +111,55 @@ class Context:
         self.check(self.lib.pc_hip_last_msm_phases_ms(self.h, out))
         return list(out)
 
+    def ntt_batch(self, curve, mat, log_n, out=None, rows=None, in_cols=None):
+        """rows x in_cols Fr (Montgomery) -> rows x 2^log_n, natural order.  numpy in -> numpy out;
+        torch cuda tensors (or raw device pointers with rows/in_cols) stay on the device."""
+        pin, win = _ptr(mat)
+        if rows is None:
+            rows, in_cols = mat.shape[0], mat.shape[1]
+        if out is None:
+            assert win == PC_MEM_HOST
+            out = np.zeros((rows, 1 << log_n, 4), dtype=np.uint64)
+        pout, wout = _ptr(out)
+        self.check(self.lib.pc_hip_ntt_batch(self.h, CURVES[curve], pin, win, rows, in_cols, log_n, pout, wout))
+        return out
+
+    def last_ntt_phases_ms(self):
+        out = (C.c_float * 2)()
+        self.check(self.lib.pc_hip_last_ntt_phases_ms(self.h, out))
+        return list(out)
+
+    def witness_poly(self, curve, coeffs, z, out=None, n=None):
+        """q = p / (x - z); coeffs n x 4 uint64 (Montgomery), z 4 x uint64 host array."""
+        pin, win = _ptr(coeffs)
+        if n is None:
+            n = coeffs.shape[0]
+        if out is None:
+            assert win == PC_MEM_HOST
+            out = np.zeros((max(n - 1, 1), 4), dtype=np.uint64)
+        pout, wout = _ptr(out)
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        self.check(self.lib.pc_hip_witness_poly(self.h, CURVES[curve], pin, win, n, C.c_void_p(z.ctypes.data), pout, wout))
+        return out[: max(n - 1, 0)] if isinstance(out, np.ndarray) else out
+
+    def div_scan(self, curve, coeffs, z, carry_in=None, out=None, n=None):
+        """acc = carry_in; for i = n-1..0: acc = coeffs[i] + z*acc; out[i] = acc  (n outputs)."""
+        pin, win = _ptr(coeffs)
+        if n is None:
+            n = coeffs.shape[0]
+        if out is None:
+            assert win == PC_MEM_HOST
+            out = np.zeros((n, 4), dtype=np.uint64)
+        pout, wout = _ptr(out)
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        cin = None
+        if carry_in is not None:
+            carry_in = np.ascontiguousarray(carry_in, dtype=np.uint64)
+            cin = C.c_void_p(carry_in.ctypes.data)
+        self.check(self.lib.pc_hip_poly_div_scan(self.h, CURVES[curve], pin, win, n, C.c_void_p(z.ctypes.data), cin,
+                                                 pout, wout))
+        return out
+
     def upload_srs(self, curve, bases, n=None, stride_bytes=0):
         return Srs(self, curve, bases, n, stride_bytes)
 
@@ -138,3 +192,14 @@ class Srs:
                                                PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
                                                where, n, C.c_void_p(out.ctypes.data), C.byref(inf)))
         return out, bool(inf.value)
+
+
+def points_sum(curve, points):
+    """Host-side sum of affine points (k x 2*Fq uint64 array) -> one affine point."""
+    lib = load_library()
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    out = np.zeros(2 * FQ_BYTES[curve] // 8, dtype=np.uint64)
+    rc = lib.pc_hip_points_sum(CURVES[curve], C.c_void_p(points.ctypes.data), points.shape[0], C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise PcHipError(rc, lib.pc_hip_strerror(rc).decode())
+    return out

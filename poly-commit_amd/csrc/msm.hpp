@@ -263,16 +263,34 @@ struct BucketReduceBody {
   }
 };
 
+// One launch per level: lanes [0, cnt) do the weighted running sums of this level; lanes
+// [cnt*(1+a), cnt*(2+a)) fold older plain array a (fan-in K).  Serial depth per level =
+// one launch instead of (1 + l).
 template <class C>
-struct PlainSumBody {
+struct BucketLevelBody {
   typedef XyzzD<C> Pt;
-  uint32_t K;
-  const uint32_t* x; uint32_t* out;
-  PC_HD void operator()(uint32_t gidx) const {
-    const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;
-    Pt acc = Pt::infinity();
-    for (uint32_t j = 0; j < K; j++) acc.add(Pt::load(base + (size_t)j * Pt::WORDS));
-    acc.store(out + (size_t)gidx * Pt::WORDS);
+  uint32_t K, weight_off, cnt, n_old;
+  const uint32_t* x;           // weighted input, cnt * K points
+  const uint32_t* old_in;      // n_old arrays of cnt * K points each (previous level's arrays 1..n_old)
+  uint32_t* out;               // this level's region: [S][Tw][old 0 reduced]...[old n_old-1 reduced], cnt points each
+  PC_HD void operator()(uint32_t lane) const {
+    const uint32_t a = lane / cnt, gidx = lane % cnt;
+    const size_t stride = (size_t)cnt * Pt::WORDS;
+    if (a == 0) {
+      const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;
+      Pt run = Pt::infinity(), acc = Pt::infinity();
+      for (uint32_t j = K; j-- > 0;) {
+        run.add(Pt::load(base + (size_t)j * Pt::WORDS));
+        if (j + weight_off > 0) acc.add(run);
+      }
+      run.store(out + (size_t)gidx * Pt::WORDS);
+      acc.store(out + stride + (size_t)gidx * Pt::WORDS);
+    } else {
+      const uint32_t* base = old_in + (size_t)(a - 1) * cnt * K * Pt::WORDS + (size_t)gidx * K * Pt::WORDS;
+      Pt acc = Pt::infinity();
+      for (uint32_t j = 0; j < K; j++) acc.add(Pt::load(base + (size_t)j * Pt::WORDS));
+      acc.store(out + (size_t)(1 + a) * stride + (size_t)gidx * Pt::WORDS);
+    }
   }
 };
 
@@ -282,8 +300,9 @@ struct PlainSumBody {
 struct MsmConfig {
   uint32_t c = 0;            // 0 = choose from n
   uint32_t T = 0;            // 0 = choose from n*W
-  uint32_t T2 = 16;
-  uint32_t K0 = 8;           // bucket-reduce group size
+  uint32_t T2 = 32;
+  uint32_t K0 = 4;           // bucket-reduce group size, level 0 (wide: keep the chain short)
+  uint32_t K1 = 8;           // group size of the later, latency-bound levels
   uint32_t target_lanes = 1u << 18;
 };
 
@@ -309,6 +328,7 @@ class MsmPlan {
   MsmPlan(Backend& be, size_t n_max, const MsmConfig& cfg) : be_(be), cfg_(cfg), n_max_(n_max) {
     if (cfg_.T2 < 4) cfg_.T2 = 4;       // each level must shrink the list: 2*ceil(s/T2) < s
     if (cfg_.K0 < 2) cfg_.K0 = 2;
+    if (cfg_.K1 < 2) cfg_.K1 = 2;
     uint32_t c = cfg.c ? cfg.c : msm_choose_c(n_max);
     setup_geometry(c, n_max);
     const size_t Mmax = (size_t)n_max * g_.W;
@@ -329,7 +349,7 @@ class MsmPlan {
     // bucket-reduce levels
     uint32_t m = g_.nb_win; n_levels_ = 0; size_t total = 0;
     while (m > 1) {
-      uint32_t K = cfg_.K0 < m ? cfg_.K0 : m;
+      uint32_t K = n_levels_ == 0 ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
       lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
       total += (size_t)(n_levels_ + 2) * g_.W * m;             // S + Tw + older plain arrays
       n_levels_++;
@@ -361,12 +381,16 @@ class MsmPlan {
     be_.memset(hist_, 0, ((size_t)g.NB + 1) * 4);
     be_.memset(buckets_, 0, (size_t)g.NB * Pt::WORDS * 4);
     { DigitsHistBody<C> b{g, scalars_dev, hist_}; be_.launch(b, n); }
+    be_.mark();   // 1: digits + histogram
     be_.exclusive_scan_u32(hist_, offsets_, (size_t)g.NB + 1);
     be_.copy_d2d(cursor_, offsets_, ((size_t)g.NB + 1) * 4);
+    be_.mark();   // 2: scan
     { ScatterBody<C> b{g, scalars_dev, cursor_, entries_}; be_.launch(b, n); }
+    be_.mark();   // 3: scatter
 
     size_t lanes = ceil_div_u32(Mmax, T);
     { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.launch(b, lanes); }
+    be_.mark();   // 4: accumulate
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
       size_t lanes2 = ceil_div_u32(slots, g.T2);
@@ -376,6 +400,7 @@ class MsmPlan {
       slots = 2 * lanes2; level++; cur ^= 1;
     }
 
+    be_.mark();   // 5: segmented reduction of partials
     // bucket reduction
     // layout of red_: per level l: [S_l][Tw_l = P_l][P_{l-1} reduced]...[P_0 reduced], each W * lvl_m_[l] points
     const uint32_t* x = buckets_;
@@ -385,17 +410,13 @@ class MsmPlan {
       const uint32_t K = lvl_K_[l], m_out = lvl_m_[l];
       const size_t cnt = (size_t)g.W * m_out;           // groups at this level
       const size_t stride = cnt * Pt::WORDS;
-      uint32_t* s_out = lvl_base; uint32_t* tw_out = lvl_base + stride;
-      { BucketReduceBody<C> b{m_out * K, K, l == 0 ? 1u : 0u, (uint32_t)cnt, x, s_out, tw_out}; be_.launch(b, cnt); }
-      for (uint32_t j = 0; j < l; j++) {
-        // older plain array j sits at prev_base + (1 + (l-1-j)) * prev_stride ... see index helpers
-        const size_t prev_stride = (size_t)g.W * lvl_m_[l - 1] * Pt::WORDS;
-        const uint32_t* pin = prev_base + (size_t)(1 + (l - 1 - j)) * prev_stride;
-        uint32_t* pout = lvl_base + (size_t)(1 + (l - j)) * stride;
-        PlainSumBody<C> b{K, pin, pout}; be_.launch(b, cnt);
-      }
-      x = s_out; prev_base = lvl_base; lvl_base += (size_t)(l + 2) * stride;
+      // previous level's arrays 1..l ([Tw_{l-1}][P_{l-2}]...[P_0]) are contiguous after its S array
+      const uint32_t* old_in = l ? prev_base + (size_t)g.W * lvl_m_[l - 1] * Pt::WORDS : nullptr;
+      BucketLevelBody<C> b{K, l == 0 ? 1u : 0u, (uint32_t)cnt, l, x, old_in, lvl_base};
+      be_.launch(b, cnt * (1 + l));
+      x = lvl_base; prev_base = lvl_base; lvl_base += (size_t)(l + 2) * stride;
     }
+    be_.mark();   // 6: bucket reduction
     // download: the last level holds W points per array: [S][P_{L-1}][P_{L-2}]...[P_0]
     host_tail(prev_base, out_host);
   }

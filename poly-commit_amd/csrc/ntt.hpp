@@ -1,0 +1,189 @@
+// Batched forward radix-2 NTT over the scalar field: the Reed-Solomon encoder under Ligero.
+//
+// Replaces GeneralEvaluationDomain::<F>::new(m * rho_inv).fft(msg) at
+// poly-commit/src/linear_codes/utils.rs:119-126 (called per matrix row from
+// linear_codes/mod.rs:131-135).  Semantics pinned by test_reed_solomon (utils.rs:303-331):
+//   out[j] = sum_i in[i] * omega^(i*j),  natural order in and out,
+//   omega = TWO_ADIC_ROOT_OF_UNITY^(2^(s - log_n))   (arkworks' FftField constants).
+// Each row is zero-padded from in_cols to N = 2^log_n (the padding is never read).
+//
+// Four-step decomposition N = N1 * N2, two kernels, both staging a tile in LDS (limb-major /
+// SoA so that consecutive lanes hit consecutive banks):
+//   pass A  tile = C adjacent columns i2 of the N1 x N2 view; N1-point NTT down each column
+//           (bit-reversed on the way into LDS, DIT butterflies), then * omega_N^(i2*j1)
+//   pass B  tile = R adjacent rows j1; N2-point NTT along each row; transposed store
+//           X[j1 + N1*j2] (R*32 B contiguous runs)
+// Twiddles come from one table W[j] = omega_N^j, j < N (<= 4 MiB at 2^17: L2 resident).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "fp32.hpp"
+#include "hip_backend.hpp"
+
+namespace pc {
+
+static constexpr int NTT_THREADS = 256;
+static constexpr uint32_t NTT_TILE_MAX = 2048;   // elements per LDS tile (64 KiB of 32-byte elements)
+
+template <class FrP>
+struct PowTable { uint32_t w[32][FrP::N]; };   // w[k] = omega_N^(2^k)
+
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_twiddles(uint32_t* W, uint32_t n, PowTable<FrP> pt) {
+  typedef Fd<FrP> F;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  F acc = F::one();
+  for (uint32_t k = 0; (j >> k) != 0; k++)
+    if ((j >> k) & 1) acc = acc.mul(F::load(pt.w[k]));
+  acc.store(W + (size_t)j * FrP::N);
+}
+
+PC_HD uint32_t bitrev(uint32_t v, uint32_t bits) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (v & 1); v >>= 1; }
+  return r;
+}
+
+template <class FrP>
+struct LdsTile {
+  typedef Fd<FrP> F;
+  uint32_t* base; uint32_t stride;   // word stride between limbs (= padded tile elements)
+  __device__ __forceinline__ F get(uint32_t pos) const {
+    F r;
+#pragma unroll
+    for (int k = 0; k < FrP::N; k++) r.l[k] = base[k * stride + pos];
+    return r;
+  }
+  __device__ __forceinline__ void put(uint32_t pos, const F& v) const {
+#pragma unroll
+    for (int k = 0; k < FrP::N; k++) base[k * stride + pos] = v.l[k];
+  }
+};
+
+// DIT butterfly stages over `lines` independent length-2^lg sequences laid out in LDS at
+// pos = line * (len + 1) + p (bit-reversed input, natural output).
+template <class FrP>
+__device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t lines, uint32_t lg, const uint32_t* W,
+                                               uint32_t log_n_total) {
+  typedef Fd<FrP> F;
+  const uint32_t len = 1u << lg, halfs = len >> 1;
+  for (uint32_t s = 1; s <= lg; s++) {
+    const uint32_t h = 1u << (s - 1);
+    const uint32_t tw_shift = log_n_total - s;       // omega_{2^s}^j = W[j << (log_n - s)]
+    for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
+      uint32_t line = b / halfs, k = b % halfs;
+      uint32_t g = k / h, j = k % h;
+      uint32_t p0 = line * (len + 1) + g * 2 * h + j, p1 = p0 + h;
+      F u = t.get(p0), v = t.get(p1);
+      if (j) v = v.mul(F::load(W + ((size_t)j << tw_shift) * FrP::N));
+      t.put(p0, u.add(v)); t.put(p1, u.sub(v));
+    }
+    __syncthreads();
+  }
+}
+
+template <class FrP>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, uint32_t in_cols, uint32_t* tmp, const uint32_t* W,
+                                                           uint32_t log_n, uint32_t lg1, uint32_t C) {
+  typedef Fd<FrP> F;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
+  const uint32_t tiles = N2 / C;
+  const uint32_t row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  LdsTile<FrP> t{smem, C * (N1 + 1)};
+  const uint32_t* rin = in + (size_t)row * in_cols * FrP::N;
+  for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
+    uint32_t c = idx % C, i1 = idx / C;
+    uint32_t i = i1 * N2 + tile * C + c;
+    F v = (i < in_cols) ? F::load(rin + (size_t)i * FrP::N) : F::zero();
+    t.put(c * (N1 + 1) + bitrev(i1, lg1), v);
+  }
+  __syncthreads();
+  lds_ntt_stages<FrP>(t, C, lg1, W, log_n);
+  uint32_t* rout = tmp + (size_t)row * N * FrP::N;
+  for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
+    uint32_t c = idx % C, j1 = idx / C;
+    uint32_t i2 = tile * C + c;
+    F v = t.get(c * (N1 + 1) + j1);
+    uint32_t e = i2 * j1;                       // < N
+    if (e) v = v.mul(F::load(W + (size_t)e * FrP::N));
+    v.store(rout + ((size_t)j1 * N2 + i2) * FrP::N);
+  }
+}
+
+template <class FrP>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const uint32_t* tmp, uint32_t* out, const uint32_t* W, uint32_t log_n,
+                                                           uint32_t lg1, uint32_t R) {
+  typedef Fd<FrP> F;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
+  const uint32_t tiles = N1 / R;
+  const uint32_t row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  LdsTile<FrP> t{smem, R * (N2 + 1)};
+  const uint32_t* rin = tmp + ((size_t)row * N + (size_t)tile * R * N2) * FrP::N;
+  for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
+    uint32_t r = idx / N2, i2 = idx % N2;
+    t.put(r * (N2 + 1) + bitrev(i2, lg2), F::load(rin + (size_t)idx * FrP::N));
+  }
+  __syncthreads();
+  lds_ntt_stages<FrP>(t, R, lg2, W, log_n);
+  uint32_t* rout = out + (size_t)row * N * FrP::N;
+  for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
+    uint32_t r = idx % R, j2 = idx / R;
+    F v = t.get(r * (N2 + 1) + j2);
+    v.store(rout + ((size_t)(tile * R + r) + (size_t)N1 * j2) * FrP::N);
+  }
+}
+
+template <class FrP>
+class NttPlan {
+ public:
+  typedef Fd<FrP> F;
+  NttPlan(HipBackend& be, unsigned log_n) : be_(be), log_n_(log_n) {
+    const uint32_t N = 1u << log_n;
+    lg1_ = (log_n + 1) / 2;
+    W_ = (uint32_t*)be_.alloc((size_t)N * FrP::N * 4);
+    PowTable<FrP> pt;
+    F w = F::load(FrP::ROOT);
+    for (unsigned i = log_n; i < (unsigned)FrP::TWO_ADICITY; i++) w = w.sqr();   // omega_N
+    for (unsigned k = 0; k < 32; k++) { w.store(pt.w[k]); w = w.sqr(); }
+    hipLaunchKernelGGL(k_ntt_twiddles<FrP>, dim3((N + 255) / 256), dim3(256), 0, be_.stream, W_, N, pt);
+    PC_HIP_CHECK(hipGetLastError());
+    be_.sync();
+  }
+  ~NttPlan() { be_.free(W_); be_.free(tmp_); }
+  unsigned log_n() const { return log_n_; }
+
+  // in: rows x in_cols, out: rows x 2^log_n, device pointers, Montgomery form.
+  void run(const uint32_t* in, size_t rows, size_t in_cols, uint32_t* out) {
+    if (rows == 0) return;
+    const uint32_t N = 1u << log_n_, lg2 = log_n_ - lg1_, N1 = 1u << lg1_, N2 = 1u << lg2;
+    size_t need = rows * (size_t)N * FrP::N * 4;
+    if (need > tmp_bytes_) { be_.sync(); be_.free(tmp_); tmp_ = (uint32_t*)be_.alloc(need); tmp_bytes_ = need; }
+    uint32_t C = 8; while (C > N2) C >>= 1; while (C > 1 && C * N1 > NTT_TILE_MAX) C >>= 1;
+    uint32_t R = 8; while (R > N1) R >>= 1; while (R > 1 && R * N2 > NTT_TILE_MAX) R >>= 1;
+    size_t lds_a = (size_t)C * (N1 + 1) * FrP::N * 4, lds_b = (size_t)R * (N2 + 1) * FrP::N * 4;
+    if (lds_a > 160 * 1024 || lds_b > 160 * 1024) throw std::runtime_error("NTT size exceeds the LDS tile");
+    if (lds_a > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_a<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    if (lds_b > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_b<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    be_.mark();
+    hipLaunchKernelGGL(k_ntt_pass_a<FrP>, dim3((unsigned)(rows * (N2 / C))), dim3(NTT_THREADS), lds_a, be_.stream, in,
+                       (uint32_t)in_cols, tmp_, W_, log_n_, lg1_, C);
+    PC_HIP_CHECK(hipGetLastError());
+    be_.mark();
+    hipLaunchKernelGGL(k_ntt_pass_b<FrP>, dim3((unsigned)(rows * (N1 / R))), dim3(NTT_THREADS), lds_b, be_.stream, tmp_, out, W_,
+                       log_n_, lg1_, R);
+    PC_HIP_CHECK(hipGetLastError());
+    be_.mark();
+  }
+
+ private:
+  HipBackend& be_;
+  unsigned log_n_, lg1_;
+  uint32_t* W_ = nullptr;
+  uint32_t* tmp_ = nullptr;
+  size_t tmp_bytes_ = 0;
+};
+
+}  // namespace pc

@@ -7,6 +7,10 @@
 #include "../../include/pc_hip.h"
 #include "hip_backend.hpp"
 #include "msm.hpp"
+#include "ntt.hpp"
+#include "poly.hpp"
+#include <map>
+#include <memory>
 
 namespace {
 
@@ -37,7 +41,20 @@ struct MsmRunnerT : MsmRunner {
 
 }  // namespace
 
+struct NttRunner {
+  virtual ~NttRunner() {}
+  virtual void run(const uint32_t* in, size_t rows, size_t in_cols, uint32_t* out) = 0;
+};
+template <class FrP>
+struct NttRunnerT : NttRunner {
+  pc::NttPlan<FrP> plan;
+  NttRunnerT(pc::HipBackend& be, unsigned log_n) : plan(be, log_n) {}
+  void run(const uint32_t* in, size_t rows, size_t in_cols, uint32_t* out) override { plan.run(in, rows, in_cols, out); }
+};
+
 struct pc_ctx {
+  std::map<std::pair<int, unsigned>, std::unique_ptr<NttRunner>> ntt_plans;
+  float ntt_phases[2] = {0, 0};
   int device = 0;
   pc::HipBackend be;
   std::mutex mu;
@@ -99,6 +116,7 @@ int pc_hip_init(int device_id, pc_ctx** out) {
 void pc_hip_shutdown(pc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  ctx->ntt_plans.clear();
   ctx->be.destroy();
   delete ctx;
 }
@@ -228,6 +246,118 @@ int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]) {
   if (!ctx || !out) return PC_ERR_INVALID_ARG;
   for (int i = 0; i < 8; i++) out[i] = ctx->phases[i];
   return PC_OK;
+}
+
+
+// Stage a host buffer on the device (or pass a device pointer through).
+struct Staged {
+  pc::HipBackend& be; void* dev = nullptr; bool owned = false;
+  Staged(pc::HipBackend& b, const void* p, pc_mem where, size_t bytes, bool copy_in) : be(b) {
+    if (where == PC_MEM_DEVICE) { dev = const_cast<void*>(p); return; }
+    dev = be.alloc(bytes); owned = true;
+    if (copy_in && bytes) be.copy_h2d(dev, p, bytes);
+  }
+  ~Staged() { if (owned) be.free(dev); }
+};
+
+int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem where_in, size_t rows, size_t in_cols,
+                     unsigned log_n, void* out, pc_mem where_out) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || (rows && (!in || !out))) return PC_ERR_INVALID_ARG;
+  const unsigned max_lg = field_of == PC_CURVE_BN254 ? 28 : 32;
+  if (log_n > max_lg || log_n > 27) return PC_ERR_TOO_LARGE;
+  if (in_cols > ((size_t)1 << log_n)) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (rows == 0) return (int)PC_OK;
+    auto key = std::make_pair((int)field_of, log_n);
+    auto it = ctx->ntt_plans.find(key);
+    if (it == ctx->ntt_plans.end()) {
+      std::unique_ptr<NttRunner> r;
+      switch (field_of) {
+        case PC_CURVE_BLS12_381: r.reset(new NttRunnerT<pc_bls12_381_fr>(ctx->be, log_n)); break;
+        case PC_CURVE_BN254: r.reset(new NttRunnerT<pc_bn254_fr>(ctx->be, log_n)); break;
+        default: r.reset(new NttRunnerT<pc_pallas_fr>(ctx->be, log_n)); break;
+      }
+      it = ctx->ntt_plans.emplace(key, std::move(r)).first;
+    }
+    const size_t N = (size_t)1 << log_n;
+    Staged sin(ctx->be, in, where_in, rows * in_cols * 32, true);
+    Staged sout(ctx->be, out, where_out, rows * N * 32, false);
+    ctx->be.n_ev = 0;
+    it->second->run((const uint32_t*)sin.dev, rows, in_cols, (uint32_t*)sout.dev);
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, rows * N * 32); else ctx->be.sync();
+    ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
+    if (ctx->be.timing && ctx->be.n_ev >= 3) {
+      (void)hipEventElapsedTime(&ctx->ntt_phases[0], ctx->be.ev[0], ctx->be.ev[1]);
+      (void)hipEventElapsedTime(&ctx->ntt_phases[1], ctx->be.ev[1], ctx->be.ev[2]);
+    }
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_last_ntt_phases_ms(const pc_ctx* ctx, float out[2]) {
+  if (!ctx || !out) return PC_ERR_INVALID_ARG;
+  out[0] = ctx->ntt_phases[0]; out[1] = ctx->ntt_phases[1];
+  return PC_OK;
+}
+
+int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,
+                         const void* carry_in_host, void* out, pc_mem where_out) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && (!coeffs || !out))) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (n == 0) return (int)PC_OK;
+    Staged sin(ctx->be, coeffs, where_in, n * 32, true);
+    Staged sout(ctx->be, out, where_out, n * 32, false);
+    const uint32_t* z = (const uint32_t*)z_host; const uint32_t* cin = (const uint32_t*)carry_in_host;
+    switch (field_of) {
+      case PC_CURVE_BLS12_381: pc::div_scan<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev); break;
+      case PC_CURVE_BN254: pc::div_scan<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev); break;
+      default: pc::div_scan<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev); break;
+    }
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n * 32);
+    return (int)PC_OK;
+  });
+}
+
+extern "C++" {
+template <class C>
+static void points_sum_t(const uint32_t* pts, size_t count, uint32_t* out) {
+  constexpr int AW = 2 * C::FqP::N;
+  pc::XyzzD<C> acc = pc::XyzzD<C>::infinity();
+  for (size_t i = 0; i < count; i++) acc.add_affine(pc::AffD<C>::load(pts + i * AW));
+  acc.to_affine().store(out);
+}
+}  // extern "C++"
+int pc_hip_points_sum(pc_curve curve, const void* points_xy, size_t count, void* out_xy) {
+  if ((int)curve < 0 || (int)curve > 2 || !out_xy || (count && !points_xy)) return PC_ERR_INVALID_ARG;
+  switch (curve) {
+    case PC_CURVE_BLS12_381: points_sum_t<pc_curve_bls12_381>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
+    case PC_CURVE_BN254: points_sum_t<pc_curve_bn254>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
+    default: points_sum_t<pc_curve_pallas>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
+  }
+  return PC_OK;
+}
+
+int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,
+                        void* out, pc_mem where_out) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && !coeffs) || (n > 1 && !out)) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (n <= 1) return (int)PC_OK;
+    Staged sin(ctx->be, coeffs, where_in, n * 32, true);
+    Staged sout(ctx->be, out, where_out, (n - 1) * 32, false);
+    const uint32_t* z = (const uint32_t*)z_host;
+    switch (field_of) {
+      case PC_CURVE_BLS12_381: pc::witness_polynomial<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
+      case PC_CURVE_BN254: pc::witness_polynomial<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
+      default: pc::witness_polynomial<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
+    }
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, (n - 1) * 32);
+    return (int)PC_OK;
+  });
 }
 
 }  // extern "C"

@@ -1,0 +1,99 @@
+// Scalar-field polynomial kernels on the open path.
+//
+// witness polynomial: quotient of p(x) by (x - z) -- KZG10::compute_witness_polynomial,
+// poly-commit/src/kzg10/mod.rs:217-240 (ark-poly's `&p / &divisor`).  It is the linear
+// recurrence acc = p[i] + z*acc, q[i-1] = acc (i = n-1 .. 1), evaluated as a chunked scan of
+// affine maps: each lane folds a chunk of G elements (up-sweep, carry-in 0), the per-chunk
+// results are folded again with factor z^G, ... and the carries are pushed back down.
+#pragma once
+#include <vector>
+#include "fp32.hpp"
+
+namespace pc {
+
+// out[u] = Horner(x[u*G .. min(count,(u+1)*G)), high index first, factor f, carry-in 0)
+template <class FrP>
+struct ScanUpBody {
+  typedef Fd<FrP> F;
+  const uint32_t* x; uint32_t count; uint32_t G; F f; uint32_t* out;
+  PC_HD void operator()(uint32_t u) const {
+    uint32_t s = u * G, e = (count - s > G) ? s + G : count;
+    F acc = F::zero();
+    for (uint32_t j = e; j-- > s;) acc = F::load(x + (size_t)j * FrP::N).add(f.mul(acc));
+    acc.store(out + (size_t)u * FrP::N);
+  }
+};
+
+// group u: acc = carry_in[u] (or 0); for j high..low: [pre] out[j] = acc; acc = x[j] + f*acc; [post] out[j] = acc
+template <class FrP>
+struct ScanDownBody {
+  typedef Fd<FrP> F;
+  const uint32_t* x; uint32_t count; uint32_t G; F f;
+  const uint32_t* carry_in;   // one per group, may be null
+  uint32_t* out;              // one per element
+  uint32_t post;              // 0: store the carry INTO element j; 1: store the value AFTER element j
+  PC_HD void operator()(uint32_t u) const {
+    uint32_t s = u * G, e = (count - s > G) ? s + G : count;
+    F acc = carry_in ? F::load(carry_in + (size_t)u * FrP::N) : F::zero();
+    for (uint32_t j = e; j-- > s;) {
+      if (!post) acc.store(out + (size_t)j * FrP::N);
+      acc = F::load(x + (size_t)j * FrP::N).add(f.mul(acc));
+      if (post) acc.store(out + (size_t)j * FrP::N);
+    }
+  }
+};
+
+// Chunked scan of the division recurrence over x[0..count):
+//   acc = carry_in (or 0);  for j = count-1 .. 0:  acc = x[j] + z*acc;  out[j] = acc.
+// carry_in_host: one Montgomery Fr on the host, or null.  x / out are device pointers.
+template <class FrP, class Backend>
+void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* z_host, const uint32_t* carry_in_host,
+              uint32_t* out, uint32_t G = 64) {
+  typedef Fd<FrP> F;
+  if (count_in == 0) return;
+  uint32_t count0 = (uint32_t)count_in;
+  F z = F::load(z_host);
+  std::vector<uint32_t> counts; std::vector<F> factors;
+  counts.push_back(count0); factors.push_back(z);
+  do {
+    F f = factors.back(), fg = F::one();
+    for (uint32_t i = 0; i < G; i++) fg = fg.mul(f);      // f^G
+    counts.push_back((counts.back() + G - 1) / G); factors.push_back(fg);
+  } while (counts.back() > 1);
+  const size_t L = counts.size() - 1;                       // number of up-sweeps
+  size_t total = 0; for (size_t k = 1; k <= L; k++) total += counts[k];
+  uint32_t* buf = (uint32_t*)be.alloc((2 * total + 2) * (size_t)FrP::N * 4);
+  std::vector<uint32_t*> B(L + 1), Cc(L + 1);
+  uint32_t* cur = buf;
+  for (size_t k = 1; k <= L; k++) { B[k] = cur; cur += (size_t)counts[k] * FrP::N; }
+  for (size_t k = 1; k <= L; k++) { Cc[k] = cur; cur += (size_t)counts[k] * FrP::N; }
+  uint32_t* top_carry = nullptr;
+  if (carry_in_host) { top_carry = cur; be.copy_h2d(top_carry, carry_in_host, (size_t)FrP::N * 4); }
+  B[0] = const_cast<uint32_t*>(x0);
+  for (size_t k = 0; k < L; k++) {
+    ScanUpBody<FrP> b{B[k], counts[k], G, factors[k], B[k + 1]};
+    be.launch(b, counts[k + 1]);
+  }
+  // down-sweep: level L has a single element, whose carry-in is the caller's
+  for (size_t k = L; k-- > 0;) {
+    const uint32_t* cin = (k + 1 == L) ? top_carry : Cc[k + 1];
+    if (k > 0) {
+      ScanDownBody<FrP> b{B[k], counts[k], G, factors[k], cin, Cc[k], 0};
+      be.launch(b, counts[k + 1]);
+    } else {
+      ScanDownBody<FrP> b{B[0], counts[0], G, factors[0], cin, out, 1};
+      be.launch(b, counts[1]);
+    }
+  }
+  be.sync();
+  be.free(buf);
+}
+
+// q (n-1 elements) = p (n elements) / (x - z): q[i-1] = value after element i, i = n-1 .. 1.
+template <class FrP, class Backend>
+void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t G = 64) {
+  if (n <= 1) return;
+  div_scan<FrP>(be, p + FrP::N, n - 1, z_host, nullptr, q, G);
+}
+
+}  // namespace pc

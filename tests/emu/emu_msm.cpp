@@ -7,13 +7,17 @@
 #include <string.h>
 #include <vector>
 #include "../../poly-commit_amd/csrc/msm.hpp"
+#include "../../poly-commit_amd/csrc/poly.hpp"
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
   void free(void* p) { ::free(p); }
   void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
+  void mark() {}
+  void sync() {}
   void copy_d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
   void copy_d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
+  void copy_h2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
   void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
     uint32_t acc = 0;
     for (size_t i = 0; i < n; i++) { uint32_t v = in[i]; out[i] = acc; acc += v; }
@@ -27,7 +31,7 @@ template <class C>
 static void run(const uint32_t* bases, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int T, int T2, int K0,
                 int from_mont, uint32_t* out) {
   CpuStepBackend be;
-  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) cfg.K0 = K0;
+  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; }
   pc::MsmPlan<C, CpuStepBackend> plan(be, n, cfg);
   plan.run(bases, base_off, scalars, n, from_mont != 0, out);
 }
@@ -75,5 +79,23 @@ extern "C" void emu_ecop(int curve, int op, const uint32_t* a, const uint32_t* b
     case 0: ecop<pc_curve_bls12_381>(op, a, b, out); break;
     case 1: ecop<pc_curve_bn254>(op, a, b, out); break;
     case 2: ecop<pc_curve_pallas>(op, a, b, out); break;
+  }
+}
+
+extern "C" void emu_witness(int curve, const uint32_t* p, size_t n, const uint32_t* z, uint32_t* q, uint32_t G) {
+  CpuStepBackend be;
+  switch (curve) {
+    case 0: pc::witness_polynomial<pc_bls12_381_fr>(be, p, n, z, q, G); break;
+    case 1: pc::witness_polynomial<pc_bn254_fr>(be, p, n, z, q, G); break;
+    case 2: pc::witness_polynomial<pc_pallas_fr>(be, p, n, z, q, G); break;
+  }
+}
+
+extern "C" void emu_div_scan(int curve, const uint32_t* x, size_t n, const uint32_t* z, const uint32_t* carry, uint32_t* out, uint32_t G) {
+  CpuStepBackend be;
+  switch (curve) {
+    case 0: pc::div_scan<pc_bls12_381_fr>(be, x, n, z, carry, out, G); break;
+    case 1: pc::div_scan<pc_bn254_fr>(be, x, n, z, carry, out, G); break;
+    case 2: pc::div_scan<pc_pallas_fr>(be, x, n, z, carry, out, G); break;
   }
 }
