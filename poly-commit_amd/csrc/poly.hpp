@@ -16,10 +16,12 @@ template <class FrP>
 struct ScanUpBody {
   typedef Fd<FrP> F;
   const uint32_t* x; uint32_t count; uint32_t G; F f; uint32_t* out;
+  const uint32_t* extra;      // optional virtual element x[count - 1] (the caller's carry-in), else null
+  PC_HD F elem(uint32_t j) const { return (extra && j + 1 == count) ? F::load(extra) : F::load(x + (size_t)j * FrP::N); }
   PC_HD void operator()(uint32_t u) const {
     uint32_t s = u * G, e = (count - s > G) ? s + G : count;
     F acc = F::zero();
-    for (uint32_t j = e; j-- > s;) acc = F::load(x + (size_t)j * FrP::N).add(f.mul(acc));
+    for (uint32_t j = e; j-- > s;) acc = elem(j).add(f.mul(acc));
     acc.store(out + (size_t)u * FrP::N);
   }
 };
@@ -32,13 +34,15 @@ struct ScanDownBody {
   const uint32_t* carry_in;   // one per group, may be null
   uint32_t* out;              // one per element
   uint32_t post;              // 0: store the carry INTO element j; 1: store the value AFTER element j
+  const uint32_t* extra;      // optional virtual top element (see ScanUpBody); never stored
   PC_HD void operator()(uint32_t u) const {
     uint32_t s = u * G, e = (count - s > G) ? s + G : count;
     F acc = carry_in ? F::load(carry_in + (size_t)u * FrP::N) : F::zero();
     for (uint32_t j = e; j-- > s;) {
-      if (!post) acc.store(out + (size_t)j * FrP::N);
-      acc = F::load(x + (size_t)j * FrP::N).add(f.mul(acc));
-      if (post) acc.store(out + (size_t)j * FrP::N);
+      const bool virt = extra && j + 1 == count;
+      if (!post && !virt) acc.store(out + (size_t)j * FrP::N);
+      acc = (virt ? F::load(extra) : F::load(x + (size_t)j * FrP::N)).add(f.mul(acc));
+      if (post && !virt) acc.store(out + (size_t)j * FrP::N);
     }
   }
 };
@@ -51,7 +55,8 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
               uint32_t* out, uint32_t G = 64) {
   typedef Fd<FrP> F;
   if (count_in == 0) return;
-  uint32_t count0 = (uint32_t)count_in;
+  // A carry-in c is the same as one more (virtual) coefficient on top: acc = c + z*0 = c.
+  uint32_t count0 = (uint32_t)count_in + (carry_in_host ? 1 : 0);
   F z = F::load(z_host);
   std::vector<uint32_t> counts; std::vector<F> factors;
   counts.push_back(count0); factors.push_back(z);
@@ -67,21 +72,21 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
   uint32_t* cur = buf;
   for (size_t k = 1; k <= L; k++) { B[k] = cur; cur += (size_t)counts[k] * FrP::N; }
   for (size_t k = 1; k <= L; k++) { Cc[k] = cur; cur += (size_t)counts[k] * FrP::N; }
-  uint32_t* top_carry = nullptr;
-  if (carry_in_host) { top_carry = cur; be.copy_h2d(top_carry, carry_in_host, (size_t)FrP::N * 4); }
+  uint32_t* extra = nullptr;
+  if (carry_in_host) { extra = cur; be.copy_h2d(extra, carry_in_host, (size_t)FrP::N * 4); }
   B[0] = const_cast<uint32_t*>(x0);
   for (size_t k = 0; k < L; k++) {
-    ScanUpBody<FrP> b{B[k], counts[k], G, factors[k], B[k + 1]};
+    ScanUpBody<FrP> b{B[k], counts[k], G, factors[k], B[k + 1], k == 0 ? extra : nullptr};
     be.launch(b, counts[k + 1]);
   }
-  // down-sweep: level L has a single element, whose carry-in is the caller's
+  // down-sweep: the single element of level L has carry-in 0
   for (size_t k = L; k-- > 0;) {
-    const uint32_t* cin = (k + 1 == L) ? top_carry : Cc[k + 1];
+    const uint32_t* cin = (k + 1 == L) ? nullptr : Cc[k + 1];
     if (k > 0) {
-      ScanDownBody<FrP> b{B[k], counts[k], G, factors[k], cin, Cc[k], 0};
+      ScanDownBody<FrP> b{B[k], counts[k], G, factors[k], cin, Cc[k], 0, nullptr};
       be.launch(b, counts[k + 1]);
     } else {
-      ScanDownBody<FrP> b{B[0], counts[0], G, factors[0], cin, out, 1};
+      ScanDownBody<FrP> b{B[0], counts[0], G, factors[0], cin, out, 1, extra};
       be.launch(b, counts[1]);
     }
   }

@@ -92,10 +92,10 @@ class ShardedKzg:
             return arr.reshape(1, -1)
         import torch
         dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(arr.view(np.int64).copy()).to(dev)
-        out = torch.empty((self.world, t.numel()), dtype=torch.int64, device=dev)
+        t = torch.from_numpy(arr.reshape(-1).view(np.int64).copy()).to(dev)
+        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=dev)
         self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().view(np.uint64)
+        return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
 
     def _combine_points(self, local_xy):
         pts = self._all_gather(local_xy)

@@ -1,0 +1,84 @@
+"""Worker for tests/test_sharded_gloo.py: one rank of a world_size-N gloo job.  Exercises the
+index / carry / fold logic of poly-commit_amd/sharded.py with an oracle-backed engine (a test
+double for HipEngine -- there is no GPU here) and compares with the single-process oracle."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch.distributed as dist
+
+import oracle_lib as O
+import pyref as R
+import poly_commit_amd as pc
+from poly_commit_amd import sharded
+
+
+class OracleEngine:
+    """Same interface as sharded.HipEngine, host buffers, CPU oracle arithmetic (TEST DOUBLE)."""
+
+    def __init__(self, curve):
+        self.curve, self.bases, self.phases = curve, None, []
+
+    def load_srs(self, bases):
+        self.bases = np.ascontiguousarray(bases)
+
+    def msm(self, scalars, n, base_offset, elem_off=0):
+        sc = O.f_from_mont(self.curve, 1, np.ascontiguousarray(scalars[elem_off:elem_off + n]))
+        self.phases.append([0.0] * 8)
+        return O.msm_pippenger(self.curve, np.ascontiguousarray(self.bases[base_offset:]), sc, 2, 1)
+
+    def div_scan(self, coeffs, n, z, carry_in):
+        fr = R.CURVES[self.curve]["fr"]
+        p = R.FIELDS[fr]["p"]
+        ci = O.fr_from_mont_array(self.curve, np.ascontiguousarray(coeffs[:n]))
+        zi = O.fr_from_mont_array(self.curve, np.asarray(z).reshape(1, 4))[0]
+        acc = 0 if carry_in is None else O.fr_from_mont_array(self.curve, np.asarray(carry_in).reshape(1, 4))[0]
+        out = [0] * n
+        for i in range(n - 1, -1, -1):
+            acc = (ci[i] + zi * acc) % p
+            out[i] = acc
+        return O.fr_mont_array(self.curve, out)
+
+    def read_elem(self, buf, idx):
+        return np.ascontiguousarray(buf[idx])
+
+    def points_sum(self, pts):
+        return pc.points_sum(self.curve, pts)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok = True
+    for curve in ("bls12_381", "bn254"):
+        n = 96                                     # coefficients per rank
+        total = n * world
+        powers = O.gen_bases(curve, total)         # the "global" SRS
+        coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC0FFEE, total))
+        z = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xBEEF, 1))[0]
+        # rank r's chunk: bases[0] = power r*n - 1 (dummy on rank 0), bases[1 + j] = power r*n + j
+        lo = rank * n
+        chunk = np.zeros((n + 1, powers.shape[1]), dtype=np.uint64)
+        chunk[1:] = powers[lo:lo + n]
+        chunk[0] = powers[lo - 1] if rank else powers[0]
+        job = sharded.ShardedKzg(OracleEngine(curve), curve, rank, world, dist)
+        job.load_srs_chunk(chunk)
+        job.set_point(z)
+        mine = np.ascontiguousarray(coeffs[lo:lo + n])
+        comm = job.commit(mine, n)
+        proof = job.open(mine, n)
+        rc1, want_c = O.kzg_commit(curve, powers, coeffs, 2)
+        rc2, want_w = O.kzg_open(curve, powers, coeffs, z, 2)
+        ok &= rc1 == 0 and rc2 == 0 and bool((comm == want_c).all()) and bool((proof == want_w).all())
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: {'OK' if ok else 'MISMATCH'}")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

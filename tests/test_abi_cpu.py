@@ -1,0 +1,74 @@
+"""CPU suite, part 3: the C-ABI library loads without a GPU, exports every symbol
+include/pc_hip.h declares, and reports PC_ERR_NO_DEVICE instead of computing anything on
+the CPU (there is no fallback path)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    import poly_commit_amd as pc
+    if not os.path.exists(pc.library_path()):
+        import importlib
+        importlib.import_module("poly_commit_amd.build").build()
+    return pc.load_library()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pc_hip_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = _lib()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/pc_hip.h but not exported"
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import poly_commit_amd as pc
+    lib = _lib()
+    assert lib.pc_hip_device_count() == 0
+    h = C.c_void_p()
+    assert lib.pc_hip_init(0, C.byref(h)) == -4          # PC_ERR_NO_DEVICE
+    assert not h.value
+    with pytest.raises(pc.PcHipError):
+        pc.Context(0)
+    assert lib.pc_hip_strerror(-4) == b"no HIP device"
+    assert lib.pc_hip_strerror(0) == b"ok"
+
+
+def test_argument_validation_needs_no_device():
+    lib = _lib()
+    assert lib.pc_hip_init(0, None) == -1                # PC_ERR_INVALID_ARG
+    assert lib.pc_hip_msm(None, None, 0, None, 0, 0, 0, None, None) == -1
+    assert lib.pc_hip_ntt_batch(None, 0, None, 0, 0, 0, 3, None, 0) == -1
+    assert lib.pc_hip_points_sum(7, None, 0, None) == -1
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254", "pallas"])
+def test_points_sum_host_utility(curve):
+    """The handful of host-side point additions (kzg10/mod.rs:206 style) + multi-GPU fold."""
+    import poly_commit_amd as pc
+    _lib()
+    pts = R.gen_bases(curve, 6)
+    arr = O.points_to_array(curve, pts + [None, R.ec_neg(curve, pts[0])])
+    want = None
+    for p in pts[1:]:
+        want = R.ec_add(curve, want, p)
+    assert O.array_to_points(curve, pc.points_sum(curve, arr))[0] == want
+    assert not pc.points_sum(curve, arr[:0]).any()

@@ -1,0 +1,157 @@
+"""CPU suite, part 2: the product's 32-bit-limb field / curve code (host compilation of
+csrc/fp32.hpp, csrc/ec.hpp) and the MSM / division-scan orchestration (csrc/msm.hpp,
+csrc/poly.hpp) stepped lane by lane by tests/emu, against the independent 64-bit oracle.
+This validates the indexing logic of the kernels on a machine without a GPU; the GPU suite
+(-m gpu) validates the same code as compiled for gfx950, through the C ABI."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CURVES = ["bls12_381", "bn254", "pallas"]
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        so = os.path.join(HERE, "emu", "libemu.so")
+        srcs = [os.path.join(HERE, "emu", "emu_msm.cpp")] + [
+            os.path.join(HERE, "..", "poly-commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
+        _emu = C.CDLL(so)
+    return _emu
+
+
+def p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def run_msm(curve, b, s, c=0, T=0, T2=0, K0=0, base_off=0, from_mont=0):
+    out = np.zeros(2 * O.fq_limbs(curve), dtype=np.uint64)
+    emu().emu_msm(O.CURVES[curve], p32(b.view(np.uint32)), p32(s.view(np.uint32)), C.c_size_t(len(s)), base_off, c, T, T2,
+                  K0, from_mont, p32(out.view(np.uint32)))
+    return out
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_field_ops_32bit_vs_bigint(curve):
+    rnd = random.Random(7)
+    ci = O.CURVES[curve]
+    for which, fname in ((0, R.CURVES[curve]["fq"]), (1, R.CURVES[curve]["fr"])):
+        p = R.FIELDS[fname]["p"]
+        n64 = R.FIELDS[fname]["limbs64"]
+        Rm = 1 << (64 * n64)
+        Ri = pow(Rm, -1, p)
+        vals = [0, 1, p - 1, 2, p - 2, Rm % p] + [rnd.randrange(p) for _ in range(20)]
+        for op in range(5):
+            for _ in range(25):
+                a, b = rnd.choice(vals), rnd.choice(vals)
+                A, B = O.ints_to_limbs([a], n64)[0], O.ints_to_limbs([b], n64)[0]
+                out = np.zeros(n64, dtype=np.uint64)
+                emu().emu_fop(ci, which, op, p32(A.view(np.uint32)), p32(B.view(np.uint32)), p32(out.view(np.uint32)))
+                got = O.limbs_to_ints(out.reshape(1, -1))[0]
+                want = [a * b * Ri % p, (a + b) % p, (a - b) % p, (pow(a * Ri % p, -1, p) * Rm % p) if a else 0,
+                        (-a) % p][op]
+                assert got == want, (fname, op, a, b)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_xyzz_group_law_all_special_cases(curve):
+    pts = R.gen_bases(curve, 5)
+    arr = O.points_to_array(curve, pts + [None])
+    for i in range(6):
+        for j in range(6):
+            Pi = pts[i] if i < 5 else None
+            Pj = pts[j] if j < 5 else None
+            for op in range(4):
+                out = np.zeros(arr.shape[1], dtype=np.uint64)
+                emu().emu_ecop(O.CURVES[curve], op, p32(arr[i].view(np.uint32)), p32(arr[j].view(np.uint32)),
+                               p32(out.view(np.uint32)))
+                want = R.ec_add(curve, Pi, Pj) if op < 2 else R.ec_add(curve, Pi, Pi)
+                assert O.array_to_points(curve, out)[0] == want, (op, i, j)
+    # P + (-P) through the mixed add
+    neg = O.points_to_array(curve, [R.ec_neg(curve, pts[2])])[0]
+    out = np.ones(arr.shape[1], dtype=np.uint64)
+    emu().emu_ecop(O.CURVES[curve], 0, p32(arr[2].view(np.uint32)), p32(neg.view(np.uint32)), p32(out.view(np.uint32)))
+    assert not out.any()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_pipeline_stepped(curve):
+    for n in (1, 2, 33, 300):
+        b = O.gen_bases(curve, n)
+        s = O.gen_scalars(curve, n * 7 + 1, n)
+        want = O.msm_pippenger(curve, b, s, 4, 1)
+        for (c, T, T2, K0) in ((0, 0, 0, 0), (4, 3, 4, 2), (5, 1, 4, 4), (7, 16, 16, 8), (8, 5, 5, 2), (2, 2, 4, 2),
+                               (11, 4, 8, 4)):
+            assert (run_msm(curve, b, s, c, T, T2, K0) == want).all(), (n, c, T, T2, K0)
+
+
+def test_msm_stepped_adversarial_scalars():
+    """Bucket collisions / huge buckets / signed-digit carries: the cases SURVEY.md 7 calls out."""
+    curve = "bls12_381"
+    n = 400
+    r = R.FIELDS["bls12_381_fr"]["p"]
+    b = O.gen_bases(curve, n)
+    b[5] = 0                 # infinity among the bases
+    b[11] = b[10]            # repeated base -> doubling inside a bucket
+    rnd = O.gen_scalars(curve, 3, n)
+    cases = {
+        "zeros": np.zeros((n, 4), dtype=np.uint64),
+        "ones": O.ints_to_limbs([1] * n, 4),
+        "r-1": O.ints_to_limbs([r - 1] * n, 4),
+        "same": np.ascontiguousarray(np.repeat(rnd[:1], n, axis=0)),     # one bucket per window holds everything
+        "two-values": np.ascontiguousarray(np.where((np.arange(n) % 2 == 0)[:, None], rnd[:1], rnd[1:2])),
+        "carry-chain": O.ints_to_limbs([(1 << 254) - 1 - i for i in range(n)], 4),
+        "sparse": np.ascontiguousarray(np.where((np.arange(n) % 7 == 0)[:, None], rnd, 0).astype(np.uint64)),
+    }
+    for name, sc in cases.items():
+        want = O.msm_naive(curve, b, sc)
+        for (c, T, T2, K0) in ((0, 0, 0, 0), (6, 4, 4, 2), (9, 7, 5, 4)):
+            assert (run_msm(curve, b, sc, c, T, T2, K0) == want).all(), (name, c, T)
+
+
+def test_msm_stepped_offset_and_montgomery():
+    curve = "bn254"
+    n = 200
+    b = O.gen_bases(curve, n)
+    s = O.gen_scalars(curve, 5, n)
+    want = O.msm_naive(curve, b[50:], s[:150])
+    assert (run_msm(curve, b, np.ascontiguousarray(s[:150]), 6, 4, 4, 4, base_off=50) == want).all()
+    mont = O.f_to_mont(curve, 1, s)
+    assert (run_msm(curve, b, mont, 0, 0, 0, 0, from_mont=1) == O.msm_naive(curve, b, s)).all()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_division_scan_stepped(curve):
+    for n in (1, 2, 3, 64, 65, 130, 1000):
+        for G in (2, 3, 64):
+            co = O.gen_scalars(curve, n, n)
+            z = O.gen_scalars(curve, 999, 1)[0]
+            want = O.witness_poly(curve, co, z)
+            q = np.zeros((max(n - 1, 1), 4), dtype=np.uint64)
+            emu().emu_witness(O.CURVES[curve], p32(co.view(np.uint32)), C.c_size_t(n), p32(z.view(np.uint32)),
+                              p32(q.view(np.uint32)), G)
+            assert (q[: max(n - 1, 0)] == want).all(), (n, G)
+    # with a carry-in: equals the scan of the concatenation [chunk | higher chunk]
+    n = 300
+    full = O.gen_scalars(curve, 1, 2 * n)
+    z = O.gen_scalars(curve, 2, 1)[0]
+    whole = np.zeros((2 * n, 4), dtype=np.uint64)
+    emu().emu_div_scan(O.CURVES[curve], p32(full.view(np.uint32)), C.c_size_t(2 * n), p32(z.view(np.uint32)), None,
+                       p32(whole.view(np.uint32)), 64)
+    lo = np.zeros((n, 4), dtype=np.uint64)
+    low_half = np.ascontiguousarray(full[:n])
+    carry = np.ascontiguousarray(whole[n])          # value after element n = carry into the low chunk
+    emu().emu_div_scan(O.CURVES[curve], p32(low_half.view(np.uint32)), C.c_size_t(n), p32(z.view(np.uint32)),
+                       p32(carry.view(np.uint32)), p32(lo.view(np.uint32)), 64)
+    assert (lo == whole[:n]).all()
