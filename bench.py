@@ -63,6 +63,70 @@ def cpu_baseline(curve, log_d, budget_s=15.0):
                       f"(oracle/oracle.cpp), best of chunk-/window-parallel, {cores} threads"}
 
 
+def bench_ntt(args):
+    """BASELINE configs[4]: LigeroPCS over BLS12-381 Fr, 2^24 coefficients, rho_inv = 4 ->
+    512 x 32768 matrix -> 512 forward NTTs of size 2^17 (linear_codes/mod.rs:118-138)."""
+    import torch
+    import oracle_lib as O
+    import poly_commit_amd as pc
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    curve = args.curve
+    poly_len = 1 << 24
+    n_rows, n_cols, _ = O.ligero_dims(255 if curve != "bn254" else 254, poly_len, 4)
+    log_n = (n_cols * 4 - 1).bit_length()
+    rows = n_rows // world                      # rows are independent: shard by rows, no collective
+    ctx = pc.Context(local_rank)
+    ctx.set_timing(True)
+    co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0500 + rank, rows * n_cols))
+    x = torch.from_numpy(co.view(np.int64)).cuda()
+    y = torch.empty((rows << log_n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ph = np.zeros(2)
+    for _ in range(args.warmup):
+        ctx.ntt_batch(curve, x.data_ptr(), log_n, out=y.data_ptr(), rows=rows, in_cols=n_cols)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.ntt_batch(curve, x.data_ptr(), log_n, out=y.data_ptr(), rows=rows, in_cols=n_cols)
+        ph += np.array(ctx.last_ntt_phases_ms())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ph /= args.steps
+    alg_bytes = rows * (n_cols + (1 << log_n)) * 32
+    kern_ms = float(ph.sum())
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Ligero Reed-Solomon NTT input coefficients/sec (LigeroPCS over BLS12-381 Fr, 2^24 coeffs)",
+            "value": world * rows * n_cols * args.steps / dt, "unit": "coeffs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32 limbs (255-bit Fr modular integer)", "data": "synthetic",
+            "config": {"workload": f"{n_rows} x {n_cols} matrix, {n_rows} forward NTTs of size 2^{log_n} (BASELINE configs[4])",
+                       "parallelism": "1 GPU" if world == 1 else f"rows sharded over {world} GPUs, no collective"},
+            "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
+                         "kernel": "k_ntt_pass_a + k_ntt_pass_b (one batched NTT = both)",
+                         "algorithmic_bytes_per_launch": alg_bytes}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,7 +137,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--workload", default="kzg", choices=["kzg", "ntt"],
+                    help="kzg (default, BASELINE configs[1]) or ntt (configs[4]: Ligero 2^24 coefficients)")
     args = ap.parse_args()
+    if args.workload == "ntt":
+        return bench_ntt(args)
 
     import torch
     import oracle_lib as O          # synthetic inputs + cpu_baseline leg only (never the measured path)

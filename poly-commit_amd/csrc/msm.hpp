@@ -33,6 +33,7 @@
 #include <stdint.h>
 #include <vector>
 #include "ec.hpp"
+#include "host_tail.hpp"
 
 namespace pc {
 
@@ -300,9 +301,9 @@ struct BucketLevelBody {
 struct MsmConfig {
   uint32_t c = 0;            // 0 = choose from n
   uint32_t T = 0;            // 0 = choose from n*W
-  uint32_t T2 = 32;
+  uint32_t T2 = 8;
   uint32_t K0 = 4;           // bucket-reduce group size, level 0 (wide: keep the chain short)
-  uint32_t K1 = 8;           // group size of the later, latency-bound levels
+  uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
 };
 
@@ -412,8 +413,7 @@ class MsmPlan {
       const size_t stride = cnt * Pt::WORDS;
       // previous level's arrays 1..l ([Tw_{l-1}][P_{l-2}]...[P_0]) are contiguous after its S array
       const uint32_t* old_in = l ? prev_base + (size_t)g.W * lvl_m_[l - 1] * Pt::WORDS : nullptr;
-      BucketLevelBody<C> b{K, l == 0 ? 1u : 0u, (uint32_t)cnt, l, x, old_in, lvl_base};
-      be_.launch(b, cnt * (1 + l));
+      be_.template bucket_level<C>(K, l == 0 ? 1u : 0u, (uint32_t)cnt, l, x, old_in, lvl_base);
       x = lvl_base; prev_base = lvl_base; lvl_base += (size_t)(l + 2) * stride;
     }
     be_.mark();   // 6: bucket reduction
@@ -431,31 +431,22 @@ class MsmPlan {
   // Horner over (level, window) on the host.  P_j[w] has weight 2^(c*w + k_0 + ... + k_{j-1}).
   void host_tail(const uint32_t* last_level_dev, uint32_t* out_host) {
     const uint32_t L = n_levels_, W = g_.W;
-    Pt total = Pt::infinity();
+    std::vector<host64::WeightedPoint> items;
     if (L == 0) {   // c == 1: one bucket per window, weight 1
       be_.copy_d2h(result_host_.data(), buckets_, (size_t)W * Pt::WORDS * 4);
-      for (uint32_t w = W; w-- > 0;) {
-        for (uint32_t d = 0; d < g_.c; d++) total = total.dbl();
-        total.add(Pt::load(&result_host_[(size_t)w * Pt::WORDS]));
-      }
+      for (uint32_t w = 0; w < W; w++) items.push_back({g_.c * w, &result_host_[(size_t)w * Pt::WORDS]});
     } else {
-      // arrays 1..L of the last level (array 0 is S, weight 0 -> unused)
+      // arrays 1..L of the last level (array 0 is S, weight 0 -> unused); array a holds P_{L-a}
       be_.copy_d2h(result_host_.data(), last_level_dev + (size_t)W * Pt::WORDS, (size_t)W * L * Pt::WORDS * 4);
-      // array index a (0-based after skipping S) holds P_{L-1-a}
-      for (uint32_t w = W; w-- > 0;) {
-        Pt win = Pt::infinity();
-        for (uint32_t j = L; j-- > 0;) {
-          // win = win * 2^{k_j} + P_j
-          uint32_t kj = 0; while ((1u << kj) < lvl_K_[j]) kj++;
-          for (uint32_t d = 0; d < kj; d++) win = win.dbl();
-          win.add(Pt::load(&result_host_[((size_t)(L - 1 - j) * W + w) * Pt::WORDS]));
-        }
-        for (uint32_t d = 0; d < g_.c; d++) total = total.dbl();
-        total.add(win);
+      uint32_t kbits = 0;
+      for (uint32_t j = 0; j < L; j++) {
+        for (uint32_t w = 0; w < W; w++)
+          items.push_back({g_.c * w + kbits, &result_host_[((size_t)(L - 1 - j) * W + w) * Pt::WORDS]});
+        uint32_t kj = 0; while ((1u << kj) < lvl_K_[j]) kj++;
+        kbits += kj;
       }
     }
-    AffD<C> a = total.to_affine();
-    a.store(out_host);
+    host64::horner_to_affine<C>(items, out_host);
   }
 
   Backend& be_;

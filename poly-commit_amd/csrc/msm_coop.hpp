@@ -1,0 +1,65 @@
+// Workgroup-cooperative bucket-reduction level (HIP only).
+//
+// Same contract as BucketLevelBody (msm.hpp) for one group of K points, but the K points are
+// spread over K lanes of one workgroup and combined through LDS in 2*log2(K) dependent EC
+// additions instead of 2*K: a right-to-left Hillis-Steele scan gives the suffix sums
+// R_l = sum_{i>=l} X_i (S = R_0), a tree reduction gives Tw = sum_l R_l (l >= 1 - weight_off).
+// The later levels of the reduction are pure latency (a few thousand points, one dependent
+// chain per launch), so trading 4x more additions for a 10x shorter chain is the point.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "msm.hpp"
+
+namespace pc {
+
+template <class C>
+struct LdsPoints {
+  typedef XyzzD<C> Pt;
+  uint32_t* base; uint32_t lanes;
+  __device__ __forceinline__ void put(uint32_t lane, const Pt& p) const {
+    uint32_t w[Pt::WORDS]; p.store(w);
+#pragma unroll
+    for (int k = 0; k < Pt::WORDS; k++) base[k * lanes + lane] = w[k];
+  }
+  __device__ __forceinline__ Pt get(uint32_t lane) const {
+    uint32_t w[Pt::WORDS];
+#pragma unroll
+    for (int k = 0; k < Pt::WORDS; k++) w[k] = base[k * lanes + lane];
+    return Pt::load(w);
+  }
+};
+
+// grid = cnt * (1 + n_old) workgroups of K lanes.
+template <class C>
+__global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
+                                                          const uint32_t* x, const uint32_t* old_in, uint32_t* out) {
+  typedef XyzzD<C> Pt;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  LdsPoints<C> lds{smem, K};
+  const uint32_t a = blockIdx.x / cnt, gidx = blockIdx.x % cnt, l = threadIdx.x;
+  const size_t stride = (size_t)cnt * Pt::WORDS;
+  const uint32_t* src = (a == 0) ? x + ((size_t)gidx * K + l) * Pt::WORDS
+                                 : old_in + ((size_t)(a - 1) * cnt * K + (size_t)gidx * K + l) * Pt::WORDS;
+  Pt v = Pt::load(src);
+  if (a == 0) {
+    // suffix scan: after the step with distance d, v_l = sum of X_l .. X_{l+2d-1}
+    for (uint32_t d = 1; d < K; d <<= 1) {
+      lds.put(l, v);
+      __syncthreads();
+      if (l + d < K) v.add(lds.get(l + d));
+      __syncthreads();
+    }
+    if (l == 0) v.store(out + (size_t)gidx * Pt::WORDS);          // S = R_0
+    if (l == 0 && weight_off == 0) v = Pt::infinity();            // weights j: R_0 is not counted
+  }
+  // tree sum of v over the K lanes
+  for (uint32_t d = K >> 1; d >= 1; d >>= 1) {
+    lds.put(l, v);
+    __syncthreads();
+    if (l < d) v.add(lds.get(l + d));
+    __syncthreads();
+  }
+  if (l == 0) v.store(out + (size_t)(1 + a) * stride + (size_t)gidx * Pt::WORDS);
+}
+
+}  // namespace pc

@@ -7,6 +7,23 @@
 #include "../../include/pc_hip.h"
 #include "hip_backend.hpp"
 #include "msm.hpp"
+#include "msm_coop.hpp"
+
+namespace pc {
+template <class C>
+void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x,
+                              const uint32_t* old_in, uint32_t* out) {
+  if (K >= 16 && K <= 256) {
+    size_t lds = (size_t)K * XyzzD<C>::WORDS * 4;
+    hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, weight_off, cnt, n_old, x,
+                       old_in, out);
+    PC_HIP_CHECK(hipGetLastError());
+  } else {
+    BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
+    launch(b, (size_t)cnt * (1 + n_old));
+  }
+}
+}  // namespace pc
 #include "ntt.hpp"
 #include "poly.hpp"
 #include <map>

@@ -22,6 +22,12 @@ struct CpuStepBackend {
     uint32_t acc = 0;
     for (size_t i = 0; i < n; i++) { uint32_t v = in[i]; out[i] = acc; acc += v; }
   }
+  template <class C>
+  void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x, const uint32_t* old_in,
+                    uint32_t* out) {
+    pc::BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
+    launch(b, (size_t)cnt * (1 + n_old));
+  }
   template <class B> void launch(const B& body, size_t lanes) {
     for (size_t i = 0; i < lanes; i++) body((uint32_t)i);
   }
