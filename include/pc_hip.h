@@ -28,6 +28,7 @@ extern "C" {
 
 typedef struct pc_ctx pc_ctx;
 typedef struct pc_srs pc_srs;
+typedef struct pc_job pc_job;
 
 typedef enum { PC_CURVE_BLS12_381 = 0, PC_CURVE_BN254 = 1, PC_CURVE_PALLAS = 2 } pc_curve;
 typedef enum { PC_SCALARS_CANONICAL = 0, PC_SCALARS_MONTGOMERY = 1 } pc_scalar_form;
@@ -79,6 +80,16 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs, const size_t* base_offsets,
                      const void* const* scalars, const size_t* n, size_t n_polys,
                      pc_scalar_form form, pc_mem where, void* out_xy, int* out_is_infinity);
 
+/* Asynchronous form of pc_hip_msm: queues the MSM on one of the SRS's independent pipelines
+ * (own HIP stream + workspace) and returns; pc_hip_job_wait blocks until the result has been
+ * written to out_xy / out_is_infinity (which must stay valid until then) and frees the job.
+ * Lets a prover keep several commitments in flight so that the latency-bound tail of one MSM
+ * overlaps the bucket accumulation of the next (pc_hip_msm_batch does this internally). */
+int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars,
+                     pc_scalar_form form, pc_mem where, size_t n, void* out_xy, int* out_is_infinity,
+                     pc_job** out_job);
+int pc_hip_job_wait(pc_ctx* ctx, pc_job* job);
+
 /* Tuning (optional): window bits c (0 = auto), level-0 chunk length T (0 = auto).  Applies
  * to SRS objects uploaded afterwards. */
 int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
@@ -120,6 +131,29 @@ int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_
  * point additions the reference also performs on the host (e.g. `commitment +=
  * &random_commitment`, kzg10/mod.rs:206) and the fold of per-GPU partial results. */
 int pc_hip_points_sum(pc_curve curve, const void* points_xy, size_t count, void* out_xy);
+
+
+/* ---- InnerProductArgPC halving rounds (poly-commit/src/ipa_pc/mod.rs:664-711) -------------
+ * All vectors are device-resident; `field_of`/the SRS select the curve.  Scalars passed by
+ * value are one Fr on the host in Montgomery form. */
+/* lo[i] += s * hi[i], i < n_half: coeffs_l += u^-1 * coeffs_r and z_l += u * z_r (:691-697). */
+int pc_hip_fr_fold(pc_ctx* ctx, pc_curve field_of, void* lo_dev, const void* hi_dev, size_t n_half,
+                   const void* s_host);
+/* out = <a, b> over n elements (utils.rs:150-155, used at ipa_pc/mod.rs:672,675). */
+int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void* b_dev, size_t n,
+                  void* out_host);
+/* out[i] = z^i, i < n (ipa_pc/mod.rs:641-649). */
+int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t n, void* out_dev);
+/* In-place key fold on the resident comm_key: key[i] = affine(key[i] + u * key[n_half + i]) for
+ * i < n_half -- `k_l += k_r.mul(round_challenge)` followed by normalize_batch (:699-707).  The
+ * following round's MSMs address the halves with base_offset 0 and n_half/2. */
+int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host);
+/* Host-side scalar multiplication of one affine point by one Fr (Montgomery):
+ * `h_prime.mul(inner_product(..))`, ipa_pc/mod.rs:672,675 -- one point, stays on the host as in
+ * the reference. */
+int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy);
+/* Copy `count` resident affine points starting at `offset` back to the host (final_comm_key). */
+int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, void* out_xy);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # The PyTorch wheel bundles its own ROCm runtime; if libpc_hip.so pulls in the system
+    # libamdhip64 first, torch later finds "No HIP GPUs".  Let torch bring its runtime up first
+    # (harness concern only -- a Rust/C++ consumer links one runtime).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise PcHipError(-100, f"{path} not built: run python -m poly_commit_amd.build "
@@ -53,14 +62,22 @@ def load_library():
     lib.pc_hip_msm.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip)]
     lib.pc_hip_msm_batch.argtypes = [vp, vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), sz, ip, ip, vp,
                                      C.POINTER(ip)]
+    lib.pc_hip_msm_async.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip), C.POINTER(vp)]
+    lib.pc_hip_job_wait.argtypes = [vp, vp]
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
     lib.pc_hip_set_timing.argtypes = [vp, ip]
     lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
+    lib.pc_hip_fr_fold.argtypes = [vp, ip, vp, vp, sz, vp]
+    lib.pc_hip_fr_dot.argtypes = [vp, ip, vp, vp, sz, vp]
+    lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
+    lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
+    lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_poly_div_scan.argtypes = [vp, ip, vp, ip, sz, vp, vp, vp, ip]
     lib.pc_hip_points_sum.argtypes = [ip, vp, sz, vp]
+    lib.pc_hip_point_mul.argtypes = [ip, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -160,6 +177,20 @@ class Context:
                                                  pout, wout))
         return out
 
+    # ---- IPA round primitives (device-resident vectors; `dev` = raw device pointer) --------------
+    def fr_fold(self, curve, lo_dev, hi_dev, n_half, s):
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        self.check(self.lib.pc_hip_fr_fold(self.h, CURVES[curve], lo_dev, hi_dev, n_half, C.c_void_p(s.ctypes.data)))
+
+    def fr_dot(self, curve, a_dev, b_dev, n):
+        out = np.zeros(4, dtype=np.uint64)
+        self.check(self.lib.pc_hip_fr_dot(self.h, CURVES[curve], a_dev, b_dev, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def fr_powers(self, curve, z, n, out_dev):
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        self.check(self.lib.pc_hip_fr_powers(self.h, CURVES[curve], C.c_void_p(z.ctypes.data), n, out_dev))
+
     def upload_srs(self, curve, bases, n=None, stride_bytes=0):
         return Srs(self, curve, bases, n, stride_bytes)
 
@@ -193,6 +224,44 @@ class Srs:
                                                where, n, C.c_void_p(out.ctypes.data), C.byref(inf)))
         return out, bool(inf.value)
 
+    def ec_fold(self, n_half, u):
+        """key[i] = affine(key[i] + u * key[n_half + i]) in place on the resident key."""
+        u = np.ascontiguousarray(u, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.pc_hip_ec_fold(self.ctx.h, self.h, n_half, C.c_void_p(u.ctypes.data)))
+
+    def read(self, offset, count):
+        out = np.zeros((count, 2 * FQ_BYTES[self.curve] // 8), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.pc_hip_srs_read(self.ctx.h, self.h, offset, count, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def msm_async(self, scalars, n=None, base_offset=0, montgomery=False):
+        """Queue an MSM; returns a job whose .wait() gives (xy, is_infinity)."""
+        p, where = _ptr(scalars)
+        if n is None:
+            n = scalars.shape[0]
+        return MsmJob(self, p, where, n, base_offset, montgomery)
+
+
+class MsmJob:
+    def __init__(self, srs, p, where, n, base_offset, montgomery):
+        self.srs = srs
+        self.out = np.zeros(2 * FQ_BYTES[srs.curve] // 8, dtype=np.uint64)
+        self.inf = C.c_int(0)
+        self.h = C.c_void_p()
+        ctx = srs.ctx
+        ctx.check(ctx.lib.pc_hip_msm_async(ctx.h, srs.h, base_offset, p,
+                                           PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL, where, n,
+                                           C.c_void_p(self.out.ctypes.data), C.byref(self.inf), C.byref(self.h)))
+        self.phases = None
+
+    def wait(self):
+        ctx = self.srs.ctx
+        if self.h:
+            ctx.check(ctx.lib.pc_hip_job_wait(ctx.h, self.h))
+            self.h = None
+            self.phases = ctx.last_msm_phases_ms()
+        return self.out, bool(self.inf.value)
+
 
 def points_sum(curve, points):
     """Host-side sum of affine points (k x 2*Fq uint64 array) -> one affine point."""
@@ -200,6 +269,19 @@ def points_sum(curve, points):
     points = np.ascontiguousarray(points, dtype=np.uint64)
     out = np.zeros(2 * FQ_BYTES[curve] // 8, dtype=np.uint64)
     rc = lib.pc_hip_points_sum(CURVES[curve], C.c_void_p(points.ctypes.data), points.shape[0], C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise PcHipError(rc, lib.pc_hip_strerror(rc).decode())
+    return out
+
+
+def point_mul(curve, point_xy, scalar_mont):
+    """Host-side k * P for one affine point and one Montgomery-form Fr."""
+    lib = load_library()
+    point_xy = np.ascontiguousarray(point_xy, dtype=np.uint64)
+    scalar_mont = np.ascontiguousarray(scalar_mont, dtype=np.uint64)
+    out = np.zeros(2 * FQ_BYTES[curve] // 8, dtype=np.uint64)
+    rc = lib.pc_hip_point_mul(CURVES[curve], C.c_void_p(point_xy.ctypes.data), C.c_void_p(scalar_mont.ctypes.data),
+                              C.c_void_p(out.ctypes.data))
     if rc != 0:
         raise PcHipError(rc, lib.pc_hip_strerror(rc).decode())
     return out

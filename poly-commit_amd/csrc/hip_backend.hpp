@@ -31,16 +31,19 @@ struct HipBackend {
   // optional phase timing
   static constexpr int MAX_EV = 16;
   hipEvent_t ev[MAX_EV];
+  hipEvent_t done = nullptr;
   int n_ev = 0;
   bool timing = false;
 
   void init() {
     PC_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (int i = 0; i < MAX_EV; i++) PC_HIP_CHECK(hipEventCreate(&ev[i]));
+    PC_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
   void destroy() {
     if (scan_tmp) (void)hipFree(scan_tmp);
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
+    if (done) (void)hipEventDestroy(done);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void mark() { if (timing && n_ev < MAX_EV) PC_HIP_CHECK(hipEventRecord(ev[n_ev++], stream)); }
@@ -55,6 +58,11 @@ struct HipBackend {
     PC_HIP_CHECK(hipStreamSynchronize(stream));
   }
   void sync() { PC_HIP_CHECK(hipStreamSynchronize(stream)); }
+  void copy_d2h_async(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); }
+  void* alloc_host(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault)); return p; }
+  void free_host(void* p) { if (p) (void)hipHostFree(p); }
+  void record_done() { PC_HIP_CHECK(hipEventRecord(done, stream)); }
+  void wait_done() { PC_HIP_CHECK(hipEventSynchronize(done)); }
 
   void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
     size_t need = 0;

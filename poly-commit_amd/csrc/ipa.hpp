@@ -1,0 +1,71 @@
+// Elementwise kernels of the InnerProductArgPC halving rounds
+// (poly-commit/src/ipa_pc/mod.rs:664-711); the two MSMs per round go through msm.hpp.
+//   fr_fold   c_l[i] += s * c_r[i]                    ipa_pc/mod.rs:691-697 (coeffs with u^-1, z with u)
+//   fr_dot    <a, b>                                   utils.rs:150-155 (inner_product), used at :672,:675
+//   ec_fold   k_l[i] = affine(k_l[i] + u * k_r[i])     ipa_pc/mod.rs:699-707 (key fold + normalize_batch)
+//   fr_powers [1, z, z^2, ...]                         ipa_pc/mod.rs:641-649
+// The round challenge u is one scalar shared by every lane, so the double-and-add ladder of
+// ec_fold is branch-uniform across the wave.
+#pragma once
+#include "ec.hpp"
+
+namespace pc {
+
+template <class FrP>
+struct FrFoldBody {
+  typedef Fd<FrP> F;
+  uint32_t* lo; const uint32_t* hi; F s;
+  PC_HD void operator()(uint32_t i) const {
+    F a = F::load(lo + (size_t)i * FrP::N), b = F::load(hi + (size_t)i * FrP::N);
+    a.add(s.mul(b)).store(lo + (size_t)i * FrP::N);
+  }
+};
+
+// partial[t] = sum over i = t, t + stride, ... of a[i]*b[i]; the host adds the partials.
+template <class FrP>
+struct FrDotBody {
+  typedef Fd<FrP> F;
+  const uint32_t* a; const uint32_t* b; uint32_t n; uint32_t stride; uint32_t* partial;
+  PC_HD void operator()(uint32_t t) const {
+    F acc = F::zero();
+    for (uint32_t i = t; i < n; i += stride)
+      acc = acc.add(F::load(a + (size_t)i * FrP::N).mul(F::load(b + (size_t)i * FrP::N)));
+    acc.store(partial + (size_t)t * FrP::N);
+  }
+};
+
+template <class FrP>
+struct FrPowTable { uint32_t w[32][FrP::N]; };   // w[k] = z^(2^k)
+
+template <class FrP>
+struct FrPowersBody {
+  typedef Fd<FrP> F;
+  uint32_t* out; FrPowTable<FrP> pt;
+  PC_HD void operator()(uint32_t i) const {
+    F acc = F::one();
+    for (uint32_t k = 0; (i >> k) != 0; k++)
+      if ((i >> k) & 1) acc = acc.mul(F::load(pt.w[k]));
+    acc.store(out + (size_t)i * FrP::N);
+  }
+};
+
+template <class C>
+struct EcFoldBody {
+  typedef XyzzD<C> Pt;
+  static constexpr int AW = 2 * Fd<typename C::FqP>::N;
+  uint32_t* key;            // affine points; lane i updates key[i] from key[i] and key[half + i]
+  uint32_t half;
+  uint32_t u[C::FrP::N];    // canonical scalar
+  PC_HD void operator()(uint32_t i) const {
+    AffD<C> kl = AffD<C>::load(key + (size_t)i * AW), kr = AffD<C>::load(key + (size_t)(half + i) * AW);
+    Pt acc = Pt::infinity();
+    for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
+      acc = acc.dbl();
+      if ((u[bit >> 5] >> (bit & 31)) & 1) acc.add_affine(kr);
+    }
+    acc.add_affine(kl);
+    acc.to_affine().store(key + (size_t)i * AW);
+  }
+};
+
+}  // namespace pc

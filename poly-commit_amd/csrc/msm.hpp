@@ -356,11 +356,12 @@ class MsmPlan {
       n_levels_++;
     }
     red_ = (uint32_t*)be_.alloc((total ? total : 1) * (size_t)Pt::WORDS * 4);
-    result_host_.resize((size_t)g_.W * (n_levels_ ? n_levels_ : 1) * Pt::WORDS);
+    result_host_ = (uint32_t*)be_.alloc_host((size_t)g_.W * (n_levels_ ? n_levels_ : 1) * Pt::WORDS * 4);
   }
   ~MsmPlan() {
     void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_};
     for (void* p : ps) be_.free(p);
+    be_.free_host(result_host_);
   }
 
   const MsmGeom& geom() const { return g_; }
@@ -370,10 +371,18 @@ class MsmPlan {
   // Writes the affine result (AW words, Montgomery; (0,0) = infinity) to out_host.
   void run(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont,
            uint32_t* out_host) {
+    enqueue(bases_dev, base_off, scalars_dev, n, from_mont);
+    finish(out_host);
+  }
+
+  // All device work of one MSM plus the asynchronous download of the <= W*levels partial
+  // sums; returns as soon as everything is queued on the backend's stream.
+  void enqueue(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont) {
     MsmGeom g = g_;
     g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
     const size_t Mmax = n * g.W;
-    if (n == 0) { for (int i = 0; i < AW; i++) out_host[i] = 0; return; }
+    pending_empty_ = (n == 0);
+    if (n == 0) return;
     uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / cfg_.target_lanes);
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
@@ -418,7 +427,16 @@ class MsmPlan {
     }
     be_.mark();   // 6: bucket reduction
     // download: the last level holds W points per array: [S][P_{L-1}][P_{L-2}]...[P_0]
-    host_tail(prev_base, out_host);
+    if (n_levels_ == 0) be_.copy_d2h_async(result_host_, buckets_, (size_t)g.W * Pt::WORDS * 4);
+    else be_.copy_d2h_async(result_host_, prev_base + (size_t)g.W * Pt::WORDS, (size_t)g.W * n_levels_ * Pt::WORDS * 4);
+    be_.record_done();
+  }
+
+  // Wait for the queued MSM and fold its partial sums on the host (Horner) into one affine point.
+  void finish(uint32_t* out_host) {
+    if (pending_empty_) { for (int i = 0; i < AW; i++) out_host[i] = 0; return; }
+    be_.wait_done();
+    host_tail(out_host);
   }
 
  private:
@@ -429,15 +447,13 @@ class MsmPlan {
   }
 
   // Horner over (level, window) on the host.  P_j[w] has weight 2^(c*w + k_0 + ... + k_{j-1}).
-  void host_tail(const uint32_t* last_level_dev, uint32_t* out_host) {
+  void host_tail(uint32_t* out_host) {
     const uint32_t L = n_levels_, W = g_.W;
     std::vector<host64::WeightedPoint> items;
     if (L == 0) {   // c == 1: one bucket per window, weight 1
-      be_.copy_d2h(result_host_.data(), buckets_, (size_t)W * Pt::WORDS * 4);
       for (uint32_t w = 0; w < W; w++) items.push_back({g_.c * w, &result_host_[(size_t)w * Pt::WORDS]});
     } else {
       // arrays 1..L of the last level (array 0 is S, weight 0 -> unused); array a holds P_{L-a}
-      be_.copy_d2h(result_host_.data(), last_level_dev + (size_t)W * Pt::WORDS, (size_t)W * L * Pt::WORDS * 4);
       uint32_t kbits = 0;
       for (uint32_t j = 0; j < L; j++) {
         for (uint32_t w = 0; w < W; w++)
@@ -457,7 +473,8 @@ class MsmPlan {
   uint32_t *hist_, *offsets_, *cursor_, *entries_, *buckets_, *scalars_, *red_;
   uint32_t* pk_[2]; uint32_t* pp_[2];
   uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32];
-  std::vector<uint32_t> result_host_;
+  uint32_t* result_host_ = nullptr;   // pinned
+  bool pending_empty_ = true;
 };
 
 }  // namespace pc

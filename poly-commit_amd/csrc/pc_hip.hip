@@ -26,6 +26,7 @@ void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uin
 }  // namespace pc
 #include "ntt.hpp"
 #include "poly.hpp"
+#include "ipa.hpp"
 #include <map>
 #include <memory>
 
@@ -33,9 +34,8 @@ namespace {
 
 struct MsmRunner {
   virtual ~MsmRunner() {}
-  virtual void run(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont,
-                   uint32_t* out_host) = 0;
-  virtual int affine_words() const = 0;
+  virtual void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) = 0;
+  virtual void finish(uint32_t* out_host) = 0;
 };
 
 template <class C>
@@ -43,17 +43,26 @@ struct MsmRunnerT : MsmRunner {
   pc::HipBackend& be;
   pc::MsmPlan<C, pc::HipBackend> plan;
   MsmRunnerT(pc::HipBackend& b, size_t n, const pc::MsmConfig& cfg) : be(b), plan(b, n, cfg) {}
-  void run(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont,
-           uint32_t* out_host) override {
+  void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) override {
     const uint32_t* sdev = (const uint32_t*)scalars;
     be.n_ev = 0; be.mark();
     if (where == PC_MEM_HOST && n) {
       be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
       sdev = plan.scalar_staging();
     }
-    plan.run(bases, base_off, sdev, n, from_mont, out_host);
+    plan.enqueue(bases, base_off, sdev, n, from_mont);
   }
-  int affine_words() const override { return pc::MsmPlan<C, pc::HipBackend>::AW; }
+  void finish(uint32_t* out_host) override { plan.finish(out_host); }
+};
+
+// One independent MSM pipeline: own stream, own workspace.  Several lanes per SRS let the
+// latency-bound tail of one MSM (segmented / bucket reduction, download, host Horner) overlap
+// the bucket accumulation of the next.
+struct MsmLane {
+  pc::HipBackend be;
+  MsmRunner* runner = nullptr;
+  struct pc_job* inflight = nullptr;
+  ~MsmLane() { delete runner; be.destroy(); }
 };
 
 }  // namespace
@@ -80,13 +89,21 @@ struct pc_ctx {
   float phases[8] = {0};
 };
 
+static constexpr int PC_MSM_LANES = 3;
 struct pc_srs {
   pc_ctx* ctx = nullptr;
   pc_curve curve = PC_CURVE_BLS12_381;
   size_t n = 0;
   uint32_t* bases = nullptr;     // packed x||y
   int aw = 0;                    // words per affine point
-  MsmRunner* runner = nullptr;
+  pc::MsmConfig cfg;
+  MsmLane* lanes[PC_MSM_LANES] = {nullptr, nullptr, nullptr};
+  int next_lane = 0;
+};
+struct pc_job {
+  pc_srs* srs = nullptr; int lane = 0;
+  uint32_t* out_xy = nullptr; int* out_inf = nullptr;
+  bool done = false; int status = 0;
 };
 
 static int fq_bytes(pc_curve c) { return c == PC_CURVE_BLS12_381 ? 48 : 32; }
@@ -105,6 +122,53 @@ static int guarded(pc_ctx* ctx, Fn fn) {
   } catch (const std::exception& e) {
     ctx->last_error = e.what(); return PC_ERR_HIP;
   }
+}
+
+static MsmLane* srs_lane(pc_srs* srs, int i) {
+  if (srs->lanes[i]) return srs->lanes[i];
+  MsmLane* L = new MsmLane();
+  try {
+    L->be.init();
+    switch (srs->curve) {
+      case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, srs->n, srs->cfg); break;
+      case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, srs->n, srs->cfg); break;
+      default: L->runner = new MsmRunnerT<pc_curve_pallas>(L->be, srs->n, srs->cfg); break;
+    }
+  } catch (...) { delete L; throw; }
+  srs->lanes[i] = L;
+  return L;
+}
+
+// Finish the job occupying a lane: wait for its stream, host tail, outputs, phase times.
+static void complete_job(pc_ctx* ctx, pc_job* job) {
+  pc_srs* srs = job->srs;
+  MsmLane* L = srs->lanes[job->lane];
+  L->runner->finish(job->out_xy);
+  if (job->out_inf) {
+    uint32_t acc = 0;
+    for (int i = 0; i < srs->aw; i++) acc |= job->out_xy[i];
+    *job->out_inf = acc == 0;
+  }
+  for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
+  if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
+  job->done = true; L->inflight = nullptr;
+}
+
+// Queue one MSM on the next lane (completing whatever that lane still holds).
+static int enqueue_job(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form, pc_mem where,
+                       size_t n, void* out_xy, int* out_is_infinity, pc_job* job) {
+  if (base_offset > srs->n) return PC_ERR_INVALID_ARG;
+  size_t avail = srs->n - base_offset;     // msm_bigint semantics: min(bases.len(), scalars.len()) pairs
+  if (n > avail) n = avail;
+  if (n && !scalars) return PC_ERR_INVALID_ARG;
+  int li = srs->next_lane; srs->next_lane = (li + 1) % PC_MSM_LANES;
+  MsmLane* L = srs_lane(srs, li);
+  if (L->inflight) complete_job(ctx, L->inflight);
+  L->be.timing = ctx->be.timing;
+  job->srs = srs; job->lane = li; job->out_xy = (uint32_t*)out_xy; job->out_inf = out_is_infinity; job->done = false;
+  L->runner->enqueue(srs->bases, (uint32_t)base_offset, scalars, where, n, form == PC_SCALARS_MONTGOMERY);
+  L->inflight = job;
+  return PC_OK;
 }
 
 extern "C" {
@@ -192,11 +256,8 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
       }
       ctx->be.sync();
     }
-    switch (curve) {
-      case PC_CURVE_BLS12_381: srs->runner = new MsmRunnerT<pc_curve_bls12_381>(ctx->be, n, ctx->msm_cfg); break;
-      case PC_CURVE_BN254: srs->runner = new MsmRunnerT<pc_curve_bn254>(ctx->be, n, ctx->msm_cfg); break;
-      default: srs->runner = new MsmRunnerT<pc_curve_pallas>(ctx->be, n, ctx->msm_cfg); break;
-    }
+    srs->cfg = ctx->msm_cfg;
+    srs_lane(srs, 0);   // allocate the first pipeline now so that OOM surfaces at upload
     return (int)PC_OK;
   });
   if (rc != PC_OK) { pc_hip_srs_free(srs); return rc; }
@@ -207,52 +268,71 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
 void pc_hip_srs_free(pc_srs* srs) {
   if (!srs) return;
   if (srs->ctx) (void)hipSetDevice(srs->ctx->device);
-  delete srs->runner;
+  for (int i = 0; i < PC_MSM_LANES; i++) {
+    if (srs->lanes[i] && srs->lanes[i]->inflight) {   // abandon: let the stream drain, mark the job failed
+      (void)hipStreamSynchronize(srs->lanes[i]->be.stream);
+      srs->lanes[i]->inflight->done = true; srs->lanes[i]->inflight->status = PC_ERR_INVALID_ARG;
+    }
+    delete srs->lanes[i];
+  }
   if (srs->bases) (void)hipFree(srs->bases);
   delete srs;
 }
 size_t pc_hip_srs_len(const pc_srs* srs) { return srs ? srs->n : 0; }
 void* pc_hip_srs_device_ptr(const pc_srs* srs) { return srs ? srs->bases : nullptr; }
 
-static int msm_one(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form,
-                   pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
-  if (base_offset > srs->n) return PC_ERR_INVALID_ARG;
-  // msm_bigint semantics: min(bases.len(), scalars.len()) pairs
-  size_t avail = srs->n - base_offset;
-  if (n > avail) n = avail;
-  if (n && !scalars) return PC_ERR_INVALID_ARG;
-  uint32_t* out = (uint32_t*)out_xy;
-  srs->runner->run(srs->bases, (uint32_t)base_offset, scalars, where, n, form == PC_SCALARS_MONTGOMERY, out);
-  if (out_is_infinity) {
-    uint32_t acc = 0;
-    for (int i = 0; i < srs->aw; i++) acc |= out[i];
-    *out_is_infinity = acc == 0;
-  }
-  // phase times
-  pc::HipBackend& be = ctx->be;
-  for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
-  if (be.timing) for (int i = 0; i + 1 < be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], be.ev[i], be.ev[i + 1]);
+int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void* scalars, pc_scalar_form form,
+               pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
+  pc_srs* srs = const_cast<pc_srs*>(srs_c);
+  if (!ctx || !srs || !out_xy || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    pc_job job;
+    int rc = enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, &job);
+    if (rc != PC_OK) return rc;
+    complete_job(ctx, &job);
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void* scalars, pc_scalar_form form,
+                     pc_mem where, size_t n, void* out_xy, int* out_is_infinity, pc_job** out_job) {
+  pc_srs* srs = const_cast<pc_srs*>(srs_c);
+  if (!ctx || !srs || !out_xy || !out_job || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *out_job = nullptr;
+  pc_job* job = new (std::nothrow) pc_job();
+  if (!job) return PC_ERR_OOM;
+  int rc = guarded(ctx, [&]() { return enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, job); });
+  if (rc != PC_OK) { delete job; return rc; }
+  *out_job = job;
   return PC_OK;
 }
 
-int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form,
-               pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
-  if (!ctx || !srs || !out_xy || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
+int pc_hip_job_wait(pc_ctx* ctx, pc_job* job) {
+  if (!ctx || !job) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  return guarded(ctx, [&]() { return msm_one(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity); });
+  int rc = job->status;
+  if (!job->done) rc = guarded(ctx, [&]() { complete_job(ctx, job); return job->status; });
+  delete job;
+  return rc;
 }
 
-int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs, const size_t* base_offsets, const void* const* scalars,
+int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offsets, const void* const* scalars,
                      const size_t* n, size_t n_polys, pc_scalar_form form, pc_mem where, void* out_xy,
                      int* out_is_infinity) {
+  pc_srs* srs = const_cast<pc_srs*>(srs_c);
   if (!ctx || !srs || !out_xy || srs->ctx != ctx || (n_polys && (!scalars || !n))) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
+    // software pipeline over the lanes: polynomial k+1 accumulates while k's tail drains
+    std::vector<pc_job> jobs(n_polys);
     for (size_t k = 0; k < n_polys; k++) {
-      int rc = msm_one(ctx, srs, base_offsets ? base_offsets[k] : 0, scalars[k], form, where, n[k],
-                       (uint8_t*)out_xy + k * (size_t)srs->aw * 4, out_is_infinity ? out_is_infinity + k : nullptr);
-      if (rc != PC_OK) return rc;
+      int rc = enqueue_job(ctx, srs, base_offsets ? base_offsets[k] : 0, scalars[k], form, where, n[k],
+                           (uint8_t*)out_xy + k * (size_t)srs->aw * 4, out_is_infinity ? out_is_infinity + k : nullptr, &jobs[k]);
+      if (rc != PC_OK) { for (size_t j = 0; j < k; j++) if (!jobs[j].done) complete_job(ctx, &jobs[j]); return rc; }
     }
+    for (size_t k = 0; k < n_polys; k++) if (!jobs[k].done) complete_job(ctx, &jobs[k]);
     return (int)PC_OK;
   });
 }
@@ -373,6 +453,131 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
       default: pc::witness_polynomial<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
     }
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, (n - 1) * 32);
+    return (int)PC_OK;
+  });
+}
+
+
+// ---- IPA round kernels --------------------------------------------------------------------
+extern "C++" {
+template <class FrP>
+static void fr_fold_t(pc::HipBackend& be, uint32_t* lo, const uint32_t* hi, size_t n, const uint32_t* s) {
+  pc::FrFoldBody<FrP> b{lo, hi, pc::Fd<FrP>::load(s)};
+  be.launch(b, n); be.sync();
+}
+template <class FrP>
+static void fr_dot_t(pc::HipBackend& be, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  typedef pc::Fd<FrP> F;
+  const uint32_t lanes = n < 16384 ? (uint32_t)(n ? n : 1) : 16384;
+  uint32_t* part = (uint32_t*)be.alloc((size_t)lanes * FrP::N * 4);
+  pc::FrDotBody<FrP> body{a, b, (uint32_t)n, lanes, part};
+  be.launch(body, lanes);
+  std::vector<uint32_t> h((size_t)lanes * FrP::N);
+  be.copy_d2h(h.data(), part, h.size() * 4);
+  be.free(part);
+  F acc = F::zero();
+  for (uint32_t t = 0; t < lanes; t++) acc = acc.add(F::load(&h[(size_t)t * FrP::N]));
+  acc.store(out);
+}
+template <class FrP>
+static void fr_powers_t(pc::HipBackend& be, const uint32_t* z, size_t n, uint32_t* out) {
+  typedef pc::Fd<FrP> F;
+  pc::FrPowersBody<FrP> body; body.out = out;
+  F w = F::load(z);
+  for (int k = 0; k < 32; k++) { w.store(body.pt.w[k]); w = w.sqr(); }
+  be.launch(body, n); be.sync();
+}
+template <class C>
+static void ec_fold_t(pc::HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
+  pc::EcFoldBody<C> body; body.key = key; body.half = (uint32_t)half;
+  pc::Fd<typename C::FrP> u = pc::Fd<typename C::FrP>::load(u_mont).from_mont();
+  for (int i = 0; i < C::FrP::N; i++) body.u[i] = u.l[i];
+  be.launch(body, half, 64); be.sync();
+}
+}  // extern "C++"
+
+#define FIELD_DISPATCH(field_of, CALL)                                        \
+  switch (field_of) {                                                         \
+    case PC_CURVE_BLS12_381: { typedef pc_bls12_381_fr FrP; CALL; } break;    \
+    case PC_CURVE_BN254: { typedef pc_bn254_fr FrP; CALL; } break;            \
+    default: { typedef pc_pallas_fr FrP; CALL; } break;                       \
+  }
+
+int pc_hip_fr_fold(pc_ctx* ctx, pc_curve field_of, void* lo_dev, const void* hi_dev, size_t n_half, const void* s_host) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !s_host || (n_half && (!lo_dev || !hi_dev))) return PC_ERR_INVALID_ARG;
+  if (n_half >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (n_half) FIELD_DISPATCH(field_of, fr_fold_t<FrP>(ctx->be, (uint32_t*)lo_dev, (const uint32_t*)hi_dev, n_half, (const uint32_t*)s_host));
+    return (int)PC_OK;
+  });
+}
+int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void* b_dev, size_t n, void* out_host) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !out_host || (n && (!a_dev || !b_dev))) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    FIELD_DISPATCH(field_of, fr_dot_t<FrP>(ctx->be, (const uint32_t*)a_dev, (const uint32_t*)b_dev, n, (uint32_t*)out_host));
+    return (int)PC_OK;
+  });
+}
+int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t n, void* out_dev) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && !out_dev)) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (n) FIELD_DISPATCH(field_of, fr_powers_t<FrP>(ctx->be, (const uint32_t*)z_host, n, (uint32_t*)out_dev));
+    return (int)PC_OK;
+  });
+}
+int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) {
+  if (!ctx || !srs || srs->ctx != ctx || !u_host || 2 * n_half > srs->n) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    for (int i = 0; i < PC_MSM_LANES; i++)      // queued MSMs still read the old key
+      if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
+    if (!n_half) return (int)PC_OK;
+    switch (srs->curve) {
+      case PC_CURVE_BLS12_381: ec_fold_t<pc_curve_bls12_381>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
+      case PC_CURVE_BN254: ec_fold_t<pc_curve_bn254>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
+      default: ec_fold_t<pc_curve_pallas>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
+    }
+    return (int)PC_OK;
+  });
+}
+extern "C++" {
+template <class C>
+static void point_mul_t(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out) {
+  typedef pc::host64::Xyzz64<C> P64;
+  constexpr int FW = C::FqP::N;
+  pc::Fd<typename C::FrP> k = pc::Fd<typename C::FrP>::load(k_mont).from_mont();
+  bool inf = true; for (int i = 0; i < 2 * FW; i++) inf &= pt[i] == 0;
+  P64 base = P64::infinity();
+  if (!inf) {
+    base.X = P64::Fq::load(pt); base.Y = P64::Fq::load(pt + FW); base.ZZ = P64::Fq::one(); base.ZZZ = P64::Fq::one();
+  }
+  P64 acc = P64::infinity();
+  for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
+    acc = acc.dbl();
+    if ((k.l[bit >> 5] >> (bit & 31)) & 1) acc.add(base);
+  }
+  acc.store_affine(out);
+}
+}  // extern "C++"
+int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy) {
+  if ((int)curve < 0 || (int)curve > 2 || !point_xy || !scalar_mont || !out_xy) return PC_ERR_INVALID_ARG;
+  switch (curve) {
+    case PC_CURVE_BLS12_381: point_mul_t<pc_curve_bls12_381>((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy); break;
+    case PC_CURVE_BN254: point_mul_t<pc_curve_bn254>((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy); break;
+    default: point_mul_t<pc_curve_pallas>((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy); break;
+  }
+  return PC_OK;
+}
+int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, void* out_xy) {
+  if (!ctx || !srs || srs->ctx != ctx || offset + count > srs->n || (count && !out_xy)) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (count) ctx->be.copy_d2h(out_xy, srs->bases + offset * (size_t)srs->aw, count * (size_t)srs->aw * 4);
     return (int)PC_OK;
   });
 }

@@ -52,16 +52,32 @@ class HipEngine:
         return buf.data_ptr() + 32 * elem_off
 
     def msm(self, scalars, n, base_offset, elem_off=0):
-        out, _ = self.srs.msm(self._ptr(scalars, elem_off), n=n, base_offset=base_offset, montgomery=True)
-        self.phases.append(self.ctx.last_msm_phases_ms())
-        return out
+        return self.msm_async(scalars, n, base_offset, elem_off).wait()
+
+    def msm_async(self, scalars, n, base_offset, elem_off=0):
+        """Queue the MSM on one of the SRS's pipelines; .wait() returns the affine point."""
+        job = self.srs.msm_async(self._ptr(scalars, elem_off), n=n, base_offset=base_offset, montgomery=True)
+        eng = self
+
+        class _Pending:
+            def wait(self_inner):
+                out, _ = job.wait()
+                if job.phases is not None:
+                    eng.phases.append(job.phases)
+                return out
+        return _Pending()
 
     def div_scan(self, coeffs, n, z, carry_in):
         import torch
-        if self._scratch is None or self._scratch.shape[0] < n:
-            self._scratch = torch.empty((n, 4), dtype=torch.int64, device=coeffs.device)
-        self.ctx.div_scan(self.curve, self._ptr(coeffs), z, carry_in, out=self._scratch.data_ptr(), n=n)
-        return self._scratch
+        # a small ring of quotient buffers: a queued open MSM still reads its quotient while the
+        # next step's division runs
+        if self._scratch is None or self._scratch[0].shape[0] < n:
+            self._scratch = [torch.empty((n, 4), dtype=torch.int64, device=coeffs.device) for _ in range(4)]
+            self._ring = 0
+        buf = self._scratch[self._ring]
+        self._ring = (self._ring + 1) % len(self._scratch)
+        self.ctx.div_scan(self.curve, self._ptr(coeffs), z, carry_in, out=buf.data_ptr(), n=n)
+        return buf
 
     def read_elem(self, buf, idx):
         return buf[idx].cpu().numpy().view(np.uint64).copy()
@@ -105,14 +121,26 @@ class ShardedKzg:
 
     # ---- KZG10::commit ---------------------------------------------------------------------
     def commit(self, coeffs, n):
-        self.e.phases = []
-        local = self.e.msm(coeffs, n, base_offset=1)
-        self.last_phases = list(self.e.phases)
-        return self._combine_points(local)
+        return self.commit_async(coeffs, n).result()
+
+    def commit_async(self, coeffs, n):
+        return _Future(self, self._msm_async(coeffs, n, base_offset=1))
+
+    def _msm_async(self, buf, n, base_offset, elem_off=0):
+        if hasattr(self.e, "msm_async"):
+            return self.e.msm_async(buf, n, base_offset, elem_off)
+        val = self.e.msm(buf, n, base_offset, elem_off)      # engines without pipelines (test doubles)
+
+        class _Done:
+            def wait(self_inner):
+                return val
+        return _Done()
 
     # ---- KZG10::open -----------------------------------------------------------------------
     def open(self, coeffs, n):
-        self.e.phases = []
+        return self.open_async(coeffs, n).result()
+
+    def open_async(self, coeffs, n):
         out = self.e.div_scan(coeffs, n, self.z, None)
         if self.world > 1:
             # carry into shard r = composition of the shards above it: c = B_s + z^n * c
@@ -126,8 +154,18 @@ class ShardedKzg:
             if carry:
                 out = self.e.div_scan(coeffs, n, self.z, _int_to_limbs(carry))
         if self.rank == 0:
-            local = self.e.msm(out, n - 1, base_offset=1, elem_off=1)    # q[i-1] = out[i] pairs with power i-1
+            pend = self._msm_async(out, n - 1, base_offset=1, elem_off=1)    # q[i-1] = out[i] pairs with power i-1
         else:
-            local = self.e.msm(out, n, base_offset=0)                    # out[j] pairs with power r*n + j - 1
-        self.last_phases = list(self.e.phases)
-        return self._combine_points(local)
+            pend = self._msm_async(out, n, base_offset=0)                    # out[j] pairs with power r*n + j - 1
+        return _Future(self, pend)
+
+
+class _Future:
+    """Result of a queued commit/open: .result() waits for the local MSM and folds the ranks."""
+
+    def __init__(self, job, pending):
+        self.job, self.pending = job, pending
+
+    def result(self):
+        local = self.pending.wait()
+        return self.job._combine_points(local)

@@ -8,12 +8,18 @@
 #include <vector>
 #include "../../poly-commit_amd/csrc/msm.hpp"
 #include "../../poly-commit_amd/csrc/poly.hpp"
+#include "../../poly-commit_amd/csrc/ipa.hpp"
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
   void free(void* p) { ::free(p); }
   void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
   void mark() {}
+  void record_done() {}
+  void wait_done() {}
+  void* alloc_host(size_t b) { return calloc(1, b ? b : 1); }
+  void free_host(void* p) { ::free(p); }
+  void copy_d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
   void sync() {}
   void copy_d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
   void copy_d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
@@ -103,5 +109,27 @@ extern "C" void emu_div_scan(int curve, const uint32_t* x, size_t n, const uint3
     case 0: pc::div_scan<pc_bls12_381_fr>(be, x, n, z, carry, out, G); break;
     case 1: pc::div_scan<pc_bn254_fr>(be, x, n, z, carry, out, G); break;
     case 2: pc::div_scan<pc_pallas_fr>(be, x, n, z, carry, out, G); break;
+  }
+}
+
+// IPA round bodies, stepped
+template <class C>
+static void ipa_bodies(uint32_t* key, size_t half, const uint32_t* u_canon, uint32_t* lo, const uint32_t* hi, const uint32_t* s_mont,
+                       uint32_t* dot_out, const uint32_t* z_mont, uint32_t* pow_out, size_t npow) {
+  typedef typename C::FrP FrP; typedef pc::Fd<FrP> F;
+  CpuStepBackend be;
+  { pc::EcFoldBody<C> b; b.key = key; b.half = (uint32_t)half; for (int i = 0; i < FrP::N; i++) b.u[i] = u_canon[i]; be.launch(b, half); }
+  { uint32_t lanes = 7; std::vector<uint32_t> part(lanes * FrP::N);
+    pc::FrDotBody<FrP> b{lo, hi, (uint32_t)half, lanes, part.data()}; be.launch(b, lanes);
+    F acc = F::zero(); for (uint32_t t = 0; t < lanes; t++) acc = acc.add(F::load(&part[t * FrP::N])); acc.store(dot_out); }
+  { pc::FrFoldBody<FrP> b{lo, hi, F::load(s_mont)}; be.launch(b, half); }
+  { pc::FrPowersBody<FrP> b; b.out = pow_out; F w = F::load(z_mont); for (int k = 0; k < 32; k++) { w.store(b.pt.w[k]); w = w.sqr(); } be.launch(b, npow); }
+}
+extern "C" void emu_ipa_bodies(int curve, uint32_t* key, size_t half, const uint32_t* u_canon, uint32_t* lo, const uint32_t* hi,
+                               const uint32_t* s_mont, uint32_t* dot_out, const uint32_t* z_mont, uint32_t* pow_out, size_t npow) {
+  switch (curve) {
+    case 0: ipa_bodies<pc_curve_bls12_381>(key, half, u_canon, lo, hi, s_mont, dot_out, z_mont, pow_out, npow); break;
+    case 1: ipa_bodies<pc_curve_bn254>(key, half, u_canon, lo, hi, s_mont, dot_out, z_mont, pow_out, npow); break;
+    case 2: ipa_bodies<pc_curve_pallas>(key, half, u_canon, lo, hi, s_mont, dot_out, z_mont, pow_out, npow); break;
   }
 }

@@ -72,3 +72,14 @@ def test_points_sum_host_utility(curve):
         want = R.ec_add(curve, want, p)
     assert O.array_to_points(curve, pc.points_sum(curve, arr))[0] == want
     assert not pc.points_sum(curve, arr[:0]).any()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254", "pallas"])
+def test_point_mul_host_utility(curve):
+    import poly_commit_amd as pc
+    _lib()
+    fr = R.CURVES[curve]["fr"]
+    P = R.gen_bases(curve, 3)[2]
+    for k in (0, 1, 2, R.FIELDS[fr]["p"] - 1, R.gen_scalars(fr, 5, 1)[0]):
+        got = pc.point_mul(curve, O.points_to_array(curve, [P])[0], O.fr_mont_array(curve, [k])[0])
+        assert O.array_to_points(curve, got)[0] == R.ec_mul(curve, k, P)

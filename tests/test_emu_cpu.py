@@ -155,3 +155,29 @@ def test_division_scan_stepped(curve):
     emu().emu_div_scan(O.CURVES[curve], p32(low_half.view(np.uint32)), C.c_size_t(n), p32(z.view(np.uint32)),
                        p32(carry.view(np.uint32)), p32(lo.view(np.uint32)), 64)
     assert (lo == whole[:n]).all()
+
+
+@pytest.mark.parametrize("curve", ["pallas", "bls12_381"])
+def test_ipa_round_bodies_stepped(curve):
+    """fr_fold / fr_dot / ec_fold / fr_powers (ipa_pc/mod.rs:641-649, 672-707) vs Python big ints."""
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    half = 5
+    pts = R.gen_bases(curve, 2 * half)
+    key = O.points_to_array(curve, pts)
+    u = R.gen_scalars(fr, 1, 1)[0]
+    lo_i, hi_i = R.gen_scalars(fr, 2, half), R.gen_scalars(fr, 3, half)
+    s_i, z_i = R.gen_scalars(fr, 4, 2)
+    lo, hi = O.fr_mont_array(curve, lo_i), O.fr_mont_array(curve, hi_i)
+    s_m, z_m = O.fr_mont_array(curve, [s_i])[0], O.fr_mont_array(curve, [z_i])[0]
+    u_c = O.ints_to_limbs([u], 4)[0]
+    dot = np.zeros(4, dtype=np.uint64)
+    npow = 37
+    pw = np.zeros((npow, 4), dtype=np.uint64)
+    emu().emu_ipa_bodies(O.CURVES[curve], p32(key.view(np.uint32)), C.c_size_t(half), p32(u_c.view(np.uint32)),
+                         p32(lo.view(np.uint32)), p32(hi.view(np.uint32)), p32(s_m.view(np.uint32)), p32(dot.view(np.uint32)),
+                         p32(z_m.view(np.uint32)), p32(pw.view(np.uint32)), C.c_size_t(npow))
+    assert O.array_to_points(curve, key[:half]) == [R.ec_add(curve, pts[i], R.ec_mul(curve, u, pts[half + i])) for i in range(half)]
+    assert O.fr_from_mont_array(curve, dot.reshape(1, 4))[0] == sum(a * b for a, b in zip(lo_i, hi_i)) % p
+    assert O.fr_from_mont_array(curve, lo) == [(a + s_i * b) % p for a, b in zip(lo_i, hi_i)]
+    assert O.fr_from_mont_array(curve, pw) == [pow(z_i, k, p) for k in range(npow)]

@@ -125,3 +125,30 @@ def test_msm_2_16_bls(ctx):
     srs = ctx.upload_srs(curve, bases)
     _check(srs, curve, bases, scalars)
     srs.free()
+
+
+def test_msm_async_pipeline_and_batch(ctx):
+    """pc_hip_msm_async / pc_hip_job_wait / pc_hip_msm_batch: several MSMs in flight on the
+    SRS's independent pipelines return the same points as the blocking call."""
+    import ctypes as C
+    curve = "bn254"
+    n = 6000
+    bases = O.gen_bases(curve, n)
+    srs = ctx.upload_srs(curve, bases)
+    scal = [O.gen_scalars(curve, 1000 + k, n - 37 * k) for k in range(7)]
+    want = [O.msm_pippenger(curve, bases, s, 8, 1) for s in scal]
+    jobs = [srs.msm_async(s) for s in scal]            # more jobs than lanes: lanes are recycled
+    for j, w in zip(reversed(jobs), reversed(want)):     # wait out of order
+        got, _ = j.wait()
+        assert (got == w).all()
+    # batch entry point (MarlinKZG10::commit's loop over polynomials, marlin_pc/mod.rs:192-237)
+    lib = ctx.lib
+    k = len(scal)
+    ptrs = (C.c_void_p * k)(*[s.ctypes.data for s in scal])
+    lens = (C.c_size_t * k)(*[len(s) for s in scal])
+    out = np.zeros((k, 8), dtype=np.uint64)
+    infs = (C.c_int * k)()
+    ctx.check(lib.pc_hip_msm_batch(ctx.h, srs.h, None, ptrs, lens, k, 0, 0, C.c_void_p(out.ctypes.data), infs))
+    for i in range(k):
+        assert (out[i] == want[i]).all() and infs[i] == 0
+    srs.free()

@@ -1,0 +1,31 @@
+"""Time the IPA halving rounds (BASELINE configs[3] shape) on one GPU: Pallas, n = 2^log_n."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import oracle_lib as O
+import poly_commit_amd as pc
+from poly_commit_amd import ipa
+
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+curve = "pallas"
+n = 1 << log_n
+ctx = pc.Context(0)
+key = O.gen_bases(curve, n + 1)
+coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE, n))
+point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B, 1))[0]
+ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, log_n))
+srs = ctx.upload_srs(curve, np.ascontiguousarray(key[:n]))
+cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+torch.cuda.synchronize()
+t = time.perf_counter(); srs.msm(cdev.data_ptr(), n=n, montgomery=True); t_commit = time.perf_counter() - t
+t = time.perf_counter(); srs.msm(cdev.data_ptr(), n=n, montgomery=True); t_commit = time.perf_counter() - t
+srs.free()
+it = iter(range(log_n))
+t = time.perf_counter()
+ipa.ipa_open_rounds(ctx, curve, key[:n], cdev, n, point, key[n], lambda L, R_: ch[next(it)])
+t_open = time.perf_counter() - t
+print(json.dumps({"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: commit MSM + {log_n} halving rounds (challenges supplied)",
+                  "commit_ms": t_commit * 1e3, "open_rounds_ms": t_open * 1e3,
+                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open}))
