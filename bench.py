@@ -157,7 +157,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):      # the latter: exercise the RCCL path on one GPU
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -42,6 +42,7 @@ struct HipBackend {
   }
   void destroy() {
     if (scan_tmp) (void)hipFree(scan_tmp);
+    if (sort_ws) (void)hipFree(sort_ws);
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
     if (done) (void)hipEventDestroy(done);
     if (stream) (void)hipStreamDestroy(stream);
@@ -73,6 +74,13 @@ struct HipBackend {
     }
     PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, need, in, out, (int)n, stream));
   }
+
+  // steps 1-3 of the MSM: LDS radix sort (msm_sort.hpp) or the atomic reference sort
+  template <class C>
+  void sort_entries(const struct MsmGeom& g, const uint32_t* scalars, uint32_t* hist, uint32_t* offsets, uint32_t* cursor,
+                    uint32_t* entries);
+  void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
+  int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
 
   // one level of the bucket reduction (see BucketLevelBody / k_bucket_level_coop)
   template <class C>

@@ -295,6 +295,21 @@ struct BucketLevelBody {
   }
 };
 
+// Steps 1-3 with device-scope atomics (histogram, scan, cursor scatter).  Used by the CPU
+// stepping backend and available on HIP (PC_HIP_SORT=atomic) as the simple reference sort.
+template <class C, class Backend>
+void sort_entries_atomic(Backend& be, const MsmGeom& g, const uint32_t* scalars_dev, uint32_t* hist, uint32_t* offsets,
+                         uint32_t* cursor, uint32_t* entries) {
+  be.memset(hist, 0, ((size_t)g.NB + 1) * 4);
+  { DigitsHistBody<C> b{g, scalars_dev, hist}; be.launch(b, g.n); }
+  be.mark();   // 1: digits + histogram
+  be.exclusive_scan_u32(hist, offsets, (size_t)g.NB + 1);
+  be.copy_d2d(cursor, offsets, ((size_t)g.NB + 1) * 4);
+  be.mark();   // 2: scan
+  { ScatterBody<C> b{g, scalars_dev, cursor, entries}; be.launch(b, g.n); }
+  be.mark();   // 3: scatter
+}
+
 // ---------------------------------------------------------------------------------------
 // Orchestration
 // ---------------------------------------------------------------------------------------
@@ -305,6 +320,7 @@ struct MsmConfig {
   uint32_t K0 = 4;           // bucket-reduce group size, level 0 (wide: keep the chain short)
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
+  uint32_t coop_max_points = 1u << 17;   // levels with more points than this use the serial fan-in K0
 };
 
 PC_HD uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -315,7 +331,7 @@ inline uint32_t msm_choose_c(size_t n) {
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
   uint32_t c = lg > 4 ? lg - 4 : 2;
   if (c < 4) c = 4;
-  if (c > 16) c = 16;
+  if (c > 20) c = 20;
   return c;
 }
 
@@ -350,7 +366,9 @@ class MsmPlan {
     // bucket-reduce levels
     uint32_t m = g_.nb_win; n_levels_ = 0; size_t total = 0;
     while (m > 1) {
-      uint32_t K = n_levels_ == 0 ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
+      // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
+      // points the chain length is all that matters: workgroup-cooperative fan-in K1.
+      uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
       lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
       total += (size_t)(n_levels_ + 2) * g_.W * m;             // S + Tw + older plain arrays
       n_levels_++;
@@ -388,15 +406,9 @@ class MsmPlan {
     if (T > 4096) T = 4096;
     g.T = T; g.T2 = cfg_.T2;
 
-    be_.memset(hist_, 0, ((size_t)g.NB + 1) * 4);
     be_.memset(buckets_, 0, (size_t)g.NB * Pt::WORDS * 4);
-    { DigitsHistBody<C> b{g, scalars_dev, hist_}; be_.launch(b, n); }
-    be_.mark();   // 1: digits + histogram
-    be_.exclusive_scan_u32(hist_, offsets_, (size_t)g.NB + 1);
-    be_.copy_d2d(cursor_, offsets_, ((size_t)g.NB + 1) * 4);
-    be_.mark();   // 2: scan
-    { ScatterBody<C> b{g, scalars_dev, cursor_, entries_}; be_.launch(b, n); }
-    be_.mark();   // 3: scatter
+    // steps 1-3: entries grouped by bucket + CSR offsets (backend chooses the sort)
+    be_.template sort_entries<C>(g, scalars_dev, hist_, offsets_, cursor_, entries_);
 
     size_t lanes = ceil_div_u32(Mmax, T);
     { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.launch(b, lanes); }

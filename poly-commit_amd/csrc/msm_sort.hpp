@@ -1,0 +1,122 @@
+// Bucket sort of the MSM's (window, bucket) entries without global atomics (HIP only).
+//
+// A two-level MSD radix sort whose counters live in LDS:
+//   count    one workgroup per chunk of scalars: signed digits -> LDS histogram over the COARSE
+//            bins (window, bucket >> fine_bits); the histogram row is stored to a table G[block][bin]
+//   binscan  per bin, exclusive prefix over the blocks; bin totals -> exclusive scan = bin bases
+//   scatter  same chunks again: LDS cursors = bin base + this block's prefix; every digit claims
+//            its slot with an LDS atomic and writes an 8-byte record {entry, fine bucket}
+//   fine     one workgroup per coarse bin: LDS histogram over the <= 1024 fine buckets, LDS scan
+//            (which also yields the CSR offsets of those buckets), LDS-atomic placement of the
+//            4-byte entries
+// Every entry costs two LDS atomics instead of two device-scope atomics (which on this part
+// are served at the memory side, ~10 G/s: 2.3 ms of a 8.6 ms MSM at 2^20, 36 of 94 ms at 2^24).
+// The result -- `entries` grouped by bucket, `offsets` = CSR row pointers -- is what the
+// accumulate kernel consumes; the order inside a bucket is irrelevant (the sum is commutative).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "msm.hpp"
+
+namespace pc {
+
+struct SortGeom {
+  uint32_t n, c, W, nb_win, NB, base_off, from_mont;
+  uint32_t fine_bits, cb, ncw /* coarse bins per window */, NC /* total coarse bins */, S /* scalars per block */, nblocks;
+};
+
+inline SortGeom make_sort_geom(const MsmGeom& g) {
+  SortGeom s;
+  s.n = g.n; s.c = g.c; s.W = g.W; s.nb_win = g.nb_win; s.NB = g.NB; s.base_off = g.base_off; s.from_mont = g.from_mont;
+  uint32_t bbits = g.c - 1;                               // bucket bits per window
+  uint32_t cb_max = 0; while ((2u << cb_max) * g.W <= 32768u) cb_max++;
+  uint32_t cb = bbits > 8 ? bbits - 8 : 0;
+  if (cb > cb_max) cb = cb_max;
+  s.cb = cb; s.fine_bits = bbits - cb; s.ncw = 1u << cb; s.NC = g.W * s.ncw;
+  uint32_t nb = (g.n + 2047) / 2048; if (nb > 512) nb = 512; if (nb == 0) nb = 1;
+  s.nblocks = nb; s.S = (g.n + nb - 1) / nb;
+  return s;
+}
+
+template <class C, bool SCATTER>
+__global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t* scalars, uint32_t* G, const uint32_t* binbase,
+                                                  uint2* records) {
+  typedef typename C::FrP FrP;
+  extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];
+  uint32_t* row = G + (size_t)blockIdx.x * sg.NC;
+  for (uint32_t k = threadIdx.x; k < sg.NC; k += blockDim.x) cnt[k] = SCATTER ? binbase[k] + row[k] : 0u;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * sg.S;
+  const uint32_t hi = (sg.n - lo > sg.S) ? lo + sg.S : sg.n;
+  const uint32_t half = 1u << (sg.c - 1), fmask = (1u << sg.fine_bits) - 1u;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, sg.from_mont);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < sg.W; w++) {
+      uint32_t raw = sd.bits_at(w * sg.c, sg.c) + carry;
+      carry = raw > half;
+      uint32_t mag = carry ? (2 * half - raw) : raw;
+      if (mag) {
+        uint32_t b = mag - 1, bin = w * sg.ncw + (b >> sg.fine_bits);
+        uint32_t pos = atomicAdd(&cnt[bin], 1u);
+        if (SCATTER) records[pos] = make_uint2((sg.base_off + i) | (carry << 31), b & fmask);
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < sg.NC; k += blockDim.x) row[k] = cnt[k];
+  }
+}
+
+// per coarse bin: exclusive prefix over the blocks (in place), total -> bintotal[bin]
+__global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32_t nblocks, uint32_t NC, uint32_t* bintotal) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= NC) { if (k == NC) bintotal[NC] = 0; return; }
+  uint32_t run = 0;
+  for (uint32_t b = 0; b < nblocks; b++) {
+    uint32_t v = G[(size_t)b * NC + k];
+    G[(size_t)b * NC + k] = run;
+    run += v;
+  }
+  bintotal[k] = run;
+}
+
+__global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
+                                                  uint32_t* offsets) {
+  __shared__ uint32_t h[2048];        // [0, F): counts / cursors; [F, 2F): scan ping-pong
+  const uint32_t F = 1u << sg.fine_bits;
+  const uint32_t k = blockIdx.x, start = binbase[k], end = binbase[k + 1];
+  for (uint32_t f = threadIdx.x; f < F; f += 256) h[f] = 0;
+  __syncthreads();
+  for (uint32_t r = start + threadIdx.x; r < end; r += 256) atomicAdd(&h[records[r].y], 1u);
+  __syncthreads();
+  // inclusive Hillis-Steele scan over F counters, ping-pong between h[0..F) and h[F..2F)
+  uint32_t src = 0;
+  for (uint32_t d = 1; d < F; d <<= 1) {
+    for (uint32_t f = threadIdx.x; f < F; f += 256) {
+      uint32_t v = h[src + f];
+      if (f >= d) v += h[src + f - d];
+      h[(src ^ F) + f] = v;
+    }
+    __syncthreads();
+    src ^= F;
+  }
+  // exclusive offsets -> CSR row pointers of this bin's buckets, and the placement cursors
+  const uint32_t w = k / sg.ncw, cbin = k % sg.ncw;
+  const uint32_t key0 = w * sg.nb_win + (cbin << sg.fine_bits);
+  uint32_t excl[8];                   // F / 256 <= 8 values per lane
+  uint32_t q = 0;
+  for (uint32_t f = threadIdx.x; f < F; f += 256, q++) excl[q] = start + (f ? h[src + f - 1] : 0u);
+  __syncthreads();
+  q = 0;
+  for (uint32_t f = threadIdx.x; f < F; f += 256, q++) { h[f] = excl[q]; offsets[key0 + f] = excl[q]; }
+  if (k + 1 == sg.NC && threadIdx.x == 0) offsets[sg.NB] = end;
+  __syncthreads();
+  for (uint32_t r = start + threadIdx.x; r < end; r += 256) {
+    uint2 rec = records[r];
+    uint32_t pos = atomicAdd(&h[rec.y], 1u);
+    entries[pos] = rec.x;
+  }
+}
+
+}  // namespace pc

@@ -65,10 +65,10 @@ struct LdsTile {
 // pos = line * (len + 1) + p (bit-reversed input, natural output).
 template <class FrP>
 __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t lines, uint32_t lg, const uint32_t* W,
-                                               uint32_t log_n_total) {
+                                               uint32_t log_n_total, uint32_t first_stage = 1) {
   typedef Fd<FrP> F;
   const uint32_t len = 1u << lg, halfs = len >> 1;
-  for (uint32_t s = 1; s <= lg; s++) {
+  for (uint32_t s = first_stage; s <= lg; s++) {
     const uint32_t h = 1u << (s - 1);
     const uint32_t tw_shift = log_n_total - s;       // omega_{2^s}^j = W[j << (log_n - s)]
     for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t l
 
 template <class FrP>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, uint32_t in_cols, uint32_t* tmp, const uint32_t* W,
-                                                           uint32_t log_n, uint32_t lg1, uint32_t C) {
+                                                           uint32_t log_n, uint32_t lg1, uint32_t C, uint32_t zskip) {
   typedef Fd<FrP> F;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
@@ -93,14 +93,19 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   const uint32_t row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   LdsTile<FrP> t{smem, C * (N1 + 1)};
   const uint32_t* rin = in + (size_t)row * in_cols * FrP::N;
-  for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
+  // Zero padding: if only the first N >> z coefficients can be non-zero (rho_inv = 4 -> z = 2), a
+  // column holds data only at i1 < N1 >> z, i.e. (bit-reversed) at LDS positions = 0 mod 2^z, and
+  // the first z DIT stages just replicate each value over its group of 2^z: skip them.
+  const uint32_t zpow = 1u << zskip, n1nz = N1 >> zskip;
+  for (uint32_t idx = threadIdx.x; idx < C * n1nz; idx += NTT_THREADS) {
     uint32_t c = idx % C, i1 = idx / C;
     uint32_t i = i1 * N2 + tile * C + c;
     F v = (i < in_cols) ? F::load(rin + (size_t)i * FrP::N) : F::zero();
-    t.put(c * (N1 + 1) + bitrev(i1, lg1), v);
+    uint32_t pos = c * (N1 + 1) + bitrev(i1, lg1);
+    for (uint32_t r = 0; r < zpow; r++) t.put(pos + r, v);
   }
   __syncthreads();
-  lds_ntt_stages<FrP>(t, C, lg1, W, log_n);
+  lds_ntt_stages<FrP>(t, C, lg1, W, log_n, zskip + 1);
   uint32_t* rout = tmp + (size_t)row * N * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
     uint32_t c = idx % C, j1 = idx / C;
@@ -167,9 +172,10 @@ class NttPlan {
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) throw std::runtime_error("NTT size exceeds the LDS tile");
     if (lds_a > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_a<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     if (lds_b > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_b<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    uint32_t zskip = 0; while (zskip < lg1_ && in_cols <= ((size_t)N >> (zskip + 1))) zskip++;
     be_.mark();
     hipLaunchKernelGGL(k_ntt_pass_a<FrP>, dim3((unsigned)(rows * (N2 / C))), dim3(NTT_THREADS), lds_a, be_.stream, in,
-                       (uint32_t)in_cols, tmp_, W_, log_n_, lg1_, C);
+                       (uint32_t)in_cols, tmp_, W_, log_n_, lg1_, C, zskip);
     PC_HIP_CHECK(hipGetLastError());
     be_.mark();
     hipLaunchKernelGGL(k_ntt_pass_b<FrP>, dim3((unsigned)(rows * (N1 / R))), dim3(NTT_THREADS), lds_b, be_.stream, tmp_, out, W_,

@@ -52,18 +52,23 @@ struct ScanDownBody {
 // carry_in_host: one Montgomery Fr on the host, or null.  x / out are device pointers.
 template <class FrP, class Backend>
 void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* z_host, const uint32_t* carry_in_host,
-              uint32_t* out, uint32_t G = 64) {
+              uint32_t* out, uint32_t G = 64, uint32_t G0 = 8) {
   typedef Fd<FrP> F;
   if (count_in == 0) return;
   // A carry-in c is the same as one more (virtual) coefficient on top: acc = c + z*0 = c.
   uint32_t count0 = (uint32_t)count_in + (carry_in_host ? 1 : 0);
   F z = F::load(z_host);
-  std::vector<uint32_t> counts; std::vector<F> factors;
+  // Level 0 touches every coefficient: short chunks (G0 = 8 -> 256 contiguous bytes per lane,
+  // count0/8 lanes) keep it bandwidth-bound instead of latency-bound; upper levels are tiny and
+  // use fan-in G.
+  std::vector<uint32_t> counts, fan; std::vector<F> factors;
   counts.push_back(count0); factors.push_back(z);
   do {
+    const uint32_t g = counts.size() == 1 ? G0 : G;
     F f = factors.back(), fg = F::one();
-    for (uint32_t i = 0; i < G; i++) fg = fg.mul(f);      // f^G
-    counts.push_back((counts.back() + G - 1) / G); factors.push_back(fg);
+    for (uint32_t i = 0; i < g; i++) fg = fg.mul(f);      // f^g
+    fan.push_back(g);
+    counts.push_back((counts.back() + g - 1) / g); factors.push_back(fg);
   } while (counts.back() > 1);
   const size_t L = counts.size() - 1;                       // number of up-sweeps
   size_t total = 0; for (size_t k = 1; k <= L; k++) total += counts[k];
@@ -76,17 +81,17 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
   if (carry_in_host) { extra = cur; be.copy_h2d(extra, carry_in_host, (size_t)FrP::N * 4); }
   B[0] = const_cast<uint32_t*>(x0);
   for (size_t k = 0; k < L; k++) {
-    ScanUpBody<FrP> b{B[k], counts[k], G, factors[k], B[k + 1], k == 0 ? extra : nullptr};
+    ScanUpBody<FrP> b{B[k], counts[k], fan[k], factors[k], B[k + 1], k == 0 ? extra : nullptr};
     be.launch(b, counts[k + 1]);
   }
   // down-sweep: the single element of level L has carry-in 0
   for (size_t k = L; k-- > 0;) {
     const uint32_t* cin = (k + 1 == L) ? nullptr : Cc[k + 1];
     if (k > 0) {
-      ScanDownBody<FrP> b{B[k], counts[k], G, factors[k], cin, Cc[k], 0, nullptr};
+      ScanDownBody<FrP> b{B[k], counts[k], fan[k], factors[k], cin, Cc[k], 0, nullptr};
       be.launch(b, counts[k + 1]);
     } else {
-      ScanDownBody<FrP> b{B[0], counts[0], G, factors[0], cin, out, 1, extra};
+      ScanDownBody<FrP> b{B[0], counts[0], fan[0], factors[0], cin, out, 1, extra};
       be.launch(b, counts[1]);
     }
   }
@@ -96,9 +101,10 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
 
 // q (n-1 elements) = p (n elements) / (x - z): q[i-1] = value after element i, i = n-1 .. 1.
 template <class FrP, class Backend>
-void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t G = 64) {
+void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t G = 64,
+                        uint32_t G0 = 8) {
   if (n <= 1) return;
-  div_scan<FrP>(be, p + FrP::N, n - 1, z_host, nullptr, q, G);
+  div_scan<FrP>(be, p + FrP::N, n - 1, z_host, nullptr, q, G, G0);
 }
 
 }  // namespace pc

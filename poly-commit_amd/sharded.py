@@ -104,7 +104,7 @@ class ShardedKzg:
     # ---- collectives -----------------------------------------------------------------------
     def _all_gather(self, arr):
         """arr: small uint64 numpy array -> (world, len) array, same on every rank."""
-        if self.world == 1:
+        if self.dist is None:
             return arr.reshape(1, -1)
         import torch
         dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"

@@ -29,6 +29,11 @@ struct CpuStepBackend {
     for (size_t i = 0; i < n; i++) { uint32_t v = in[i]; out[i] = acc; acc += v; }
   }
   template <class C>
+  void sort_entries(const pc::MsmGeom& g, const uint32_t* scalars, uint32_t* hist, uint32_t* offsets, uint32_t* cursor,
+                    uint32_t* entries) {
+    pc::sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries);
+  }
+  template <class C>
   void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x, const uint32_t* old_in,
                     uint32_t* out) {
     pc::BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
@@ -43,7 +48,7 @@ template <class C>
 static void run(const uint32_t* bases, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int T, int T2, int K0,
                 int from_mont, uint32_t* out) {
   CpuStepBackend be;
-  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; }
+  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; }
   pc::MsmPlan<C, CpuStepBackend> plan(be, n, cfg);
   plan.run(bases, base_off, scalars, n, from_mont != 0, out);
 }
@@ -97,9 +102,9 @@ extern "C" void emu_ecop(int curve, int op, const uint32_t* a, const uint32_t* b
 extern "C" void emu_witness(int curve, const uint32_t* p, size_t n, const uint32_t* z, uint32_t* q, uint32_t G) {
   CpuStepBackend be;
   switch (curve) {
-    case 0: pc::witness_polynomial<pc_bls12_381_fr>(be, p, n, z, q, G); break;
-    case 1: pc::witness_polynomial<pc_bn254_fr>(be, p, n, z, q, G); break;
-    case 2: pc::witness_polynomial<pc_pallas_fr>(be, p, n, z, q, G); break;
+    case 0: pc::witness_polynomial<pc_bls12_381_fr>(be, p, n, z, q, G, G == 64 ? 8 : G); break;
+    case 1: pc::witness_polynomial<pc_bn254_fr>(be, p, n, z, q, G, 5); break;
+    case 2: pc::witness_polynomial<pc_pallas_fr>(be, p, n, z, q, G, G); break;
   }
 }
 
