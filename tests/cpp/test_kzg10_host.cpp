@@ -1,0 +1,127 @@
+// Host-layer tests for pc_host::KZG10 (poly-commit_amd/host/kzg10.hpp), written after the
+// reference's own KZG10 tests (poly-commit/src/kzg10/mod.rs:519-674).  The reference checks
+// openings with a pairing; no pairing exists here, so `check` is replaced by the same equation
+// evaluated in G1 with the test's known trapdoor beta:
+//     C - v*g - v_bar*gamma_g  ==  (beta - z) * W          (kzg10/mod.rs:314-333)
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../poly-commit_amd/host/kzg10.hpp"
+
+using namespace pc_host;
+
+template <class E>
+struct TestRng : RngCore<E> {
+  uint64_t s;
+  explicit TestRng(uint64_t seed) : s(seed) {}
+  uint64_t next() { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  FrT<E> next_fr() override {   // uniform canonical value < r, then into Montgomery form
+    typedef pc::host64::F64<typename E::C::FrP> F;
+    for (;;) {
+      F t; for (int i = 0; i < 4; i++) t.l[i] = next();
+      t.l[3] &= (1ull << (E::C::FrP::BITS - 192)) - 1;
+      if (F::geq(t.l)) continue;
+      F r2; memcpy(r2.l, E::C::FrP::R2, 32);
+      return FrT<E>::of(t.mul(r2));
+    }
+  }
+};
+
+#define CHECK(cond) do { if (!(cond)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } } while (0)
+
+template <class E>
+static G1Affine<E> generator() {
+  uint64_t xy[2 * E::NQ];
+  memcpy(xy, E::C::GX, 8 * E::NQ); memcpy(xy + E::NQ, E::C::GY, 8 * E::NQ);
+  return G1Affine<E>::from_xy(xy, false);
+}
+
+template <class E>
+static DensePolynomial<E> rand_poly(size_t degree, TestRng<E>& rng) {
+  DensePolynomial<E> p; for (size_t i = 0; i <= degree; i++) p.coeffs.push_back(rng.next_fr()); return p;
+}
+
+template <class E>
+static void run(pc_ctx* ctx, const char* name) {
+  typedef KZG10<E> K; typedef FrT<E> Fr;
+  TestRng<E> rng(0x5EED);
+  const size_t max_degree = 24;
+  Fr beta = rng.next_fr();
+  G1Affine<E> g = generator<E>(), gamma_g = g.mul(rng.next_fr());
+  std::vector<G1Affine<E>> pg, pgg;
+  K::setup_for_tests(max_degree, beta, g, gamma_g, pg, pgg);
+  Powers<E> powers;
+  Error e = Powers<E>::upload(ctx, pg.data(), pg.size(), pgg.data(), pgg.size(), powers);
+  CHECK(!e);
+
+  // add_commitments_test (kzg10/mod.rs:520-544): commit(f * p) == f * commit(p)
+  {
+    DensePolynomial<E> p = rand_poly<E>(10, rng);
+    Fr f = rng.next_fr();
+    DensePolynomial<E> f_p = p; for (auto& c : f_p.coeffs) c = c * f;
+    Commitment<E> comm, f_comm; Randomness<E> r1, r2;
+    CHECK(!K::commit(powers, p, nullptr, nullptr, comm, r1));
+    CHECK(!K::commit(powers, f_p, nullptr, nullptr, f_comm, r2));
+    CHECK(!comm.comm.is_zero() && !r1.is_hiding());
+    CHECK(comm.comm.mul(f) == f_comm.comm);
+  }
+  // end_to_end_test (kzg10/mod.rs:546-575), hiding on; the pairing check in G1 via the trapdoor
+  for (int iter = 0; iter < 12; iter++) {
+    size_t degree = 1 + rng.next() % 19;
+    DensePolynomial<E> p = rand_poly<E>(degree, rng);
+    size_t hiding_bound = 1 + rng.next() % 3;
+    const bool hide = iter % 3 != 0;
+    Commitment<E> comm; Randomness<E> rand;
+    CHECK(!K::commit(powers, p, hide ? &hiding_bound : nullptr, hide ? &rng : nullptr, comm, rand));
+    CHECK(rand.is_hiding() == hide);
+    Fr point = rng.next_fr();
+    Fr value = p.evaluate(point);
+    Proof<E> proof;
+    CHECK(!K::open(powers, p, point, rand, proof));
+    CHECK(proof.has_random_v == hide);
+    G1Affine<E> lhs = comm.comm.add(g.mul(value).neg());
+    if (hide) lhs = lhs.add(gamma_g.mul(proof.random_v).neg());
+    G1Affine<E> rhs = proof.w.mul(beta - point);
+    CHECK(lhs == rhs);
+    // a wrong value must not satisfy the equation
+    G1Affine<E> bad = comm.comm.add(g.mul(value + Fr::one()).neg());
+    if (hide) bad = bad.add(gamma_g.mul(proof.random_v).neg());
+    CHECK(!(bad == rhs));
+  }
+  // leading-zero coefficients: skip_leading_zeros_and_convert_to_bigints (:452-461)
+  {
+    DensePolynomial<E> p = rand_poly<E>(12, rng);
+    p.coeffs[0] = p.coeffs[1] = Fr::zero();
+    Commitment<E> c1; Randomness<E> r;
+    CHECK(!K::commit(powers, p, nullptr, nullptr, c1, r));
+    G1Affine<E> want = G1Affine<E>::zero();
+    for (size_t i = 0; i < p.coeffs.size(); i++) want = want.add(pg[i].mul(p.coeffs[i]));
+    CHECK(c1.comm == want);
+  }
+  // test_degree_is_too_large (kzg10/mod.rs:663-674) and the rng / hiding-bound errors
+  {
+    DensePolynomial<E> p = rand_poly<E>(max_degree + 1, rng);
+    Commitment<E> c; Randomness<E> r;
+    Error err = K::commit(powers, p, nullptr, nullptr, c, r);
+    CHECK(err.kind == Error::TooManyCoefficients && err.a == max_degree + 2 && err.b == max_degree + 1);
+    DensePolynomial<E> q = rand_poly<E>(5, rng);
+    size_t hb = 2;
+    CHECK(K::commit(powers, q, &hb, nullptr, c, r).kind == Error::MissingRng);
+    size_t huge = max_degree + 5;
+    CHECK(K::commit(powers, q, &huge, &rng, c, r).kind == Error::HidingBoundToolarge);
+    Proof<E> pr;
+    CHECK(K::open(powers, p, rng.next_fr(), Randomness<E>::empty(), pr).kind == Error::TooManyCoefficients);
+  }
+  powers.release();
+  printf("%s: add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
+}
+
+int main() {
+  pc_ctx* ctx = nullptr;
+  int rc = pc_hip_init(0, &ctx);
+  if (rc != PC_OK) { printf("pc_hip_init failed: %s\n", pc_hip_strerror(rc)); return rc == PC_ERR_NO_DEVICE ? 77 : 1; }
+  run<Bls12_381>(ctx, "bls12_381");
+  run<Bn254>(ctx, "bn254");
+  run<Pallas>(ctx, "pallas");
+  pc_hip_shutdown(ctx);
+  return 0;
+}
