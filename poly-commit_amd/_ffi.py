@@ -224,6 +224,19 @@ class Srs:
                                                where, n, C.c_void_p(out.ctypes.data), C.byref(inf)))
         return out, bool(inf.value)
 
+    def msm_batch(self, scalar_ptrs, lens, base_offsets=None, montgomery=True):
+        """pc_hip_msm_batch over device pointers: k scalar vectors against this SRS -> (k, 2*Fq) points."""
+        k = len(scalar_ptrs)
+        ptrs = (C.c_void_p * k)(*scalar_ptrs)
+        ns = (C.c_size_t * k)(*lens)
+        offs = (C.c_size_t * k)(*base_offsets) if base_offsets is not None else None
+        out = np.zeros((k, 2 * FQ_BYTES[self.curve] // 8), dtype=np.uint64)
+        infs = (C.c_int * k)()
+        self.ctx.check(self.ctx.lib.pc_hip_msm_batch(self.ctx.h, self.h, offs, ptrs, ns, k,
+                                                     PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
+                                                     PC_MEM_DEVICE, C.c_void_p(out.ctypes.data), infs))
+        return out
+
     def ec_fold(self, n_half, u):
         """key[i] = affine(key[i] + u * key[n_half + i]) in place on the resident key."""
         u = np.ascontiguousarray(u, dtype=np.uint64)
