@@ -5,6 +5,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace pc {
 
@@ -35,8 +36,23 @@ struct HipBackend {
   int n_ev = 0;
   bool timing = false;
 
-  void init() {
-    PC_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  // cu_part / cu_parts: restrict this backend's stream to one interleaved share of the CUs
+  // (every cu_parts-th CU).  Pipelines that each own a share run side by side, so the
+  // latency-bound tail of one MSM overlaps the bucket accumulation of the others even though a
+  // 218-VGPR accumulate wave leaves no room for a second kernel on the same SIMD.
+  void init(int cu_part = 0, int cu_parts = 1) {
+    if (cu_parts > 1) {
+      hipDeviceProp_t prop; int dev = 0;
+      PC_HIP_CHECK(hipGetDevice(&dev));
+      PC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int cu = 0; cu < ncu; cu++)
+        if ((cu / 2) % cu_parts == cu_part) mask[cu / 32] |= 1u << (cu % 32);   // pairs of CUs (a WGP-like unit) stay together
+      PC_HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data()));
+    } else {
+      PC_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
     for (int i = 0; i < MAX_EV; i++) PC_HIP_CHECK(hipEventCreate(&ev[i]));
     PC_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
@@ -81,6 +97,11 @@ struct HipBackend {
                     uint32_t* entries);
   void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
   int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
+
+  // all remaining (small) levels of the segmented reduction in one launch
+  template <class C>
+  void seg_reduce_tail(const struct MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
+                       const uint32_t* offsets, uint32_t* buckets);
 
   // one level of the bucket reduction (see BucketLevelBody / k_bucket_level_coop)
   template <class C>

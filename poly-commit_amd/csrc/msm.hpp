@@ -295,6 +295,20 @@ struct BucketLevelBody {
   }
 };
 
+// All remaining seg-reduce levels, one after the other (the CPU stepping backend's version of
+// HipBackend::seg_reduce_tail, which runs the same loop inside one workgroup).
+template <class C, class Backend>
+void seg_reduce_tail_serial(Backend& be, const MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp,
+                            int cur, const uint32_t* offsets, uint32_t* buckets) {
+  for (;;) {
+    uint32_t lanes2 = (slots + g.T2 - 1) / g.T2;
+    SegReduceBody<C> b{g, level, slots, pk[cur], pp[cur], offsets, buckets, pk[cur ^ 1], pp[cur ^ 1]};
+    be.launch(b, lanes2);
+    if (lanes2 == 1) break;
+    slots = 2 * lanes2; level++; cur ^= 1;
+  }
+}
+
 // Steps 1-3 with device-scope atomics (histogram, scan, cursor scatter).  Used by the CPU
 // stepping backend and available on HIP (PC_HIP_SORT=atomic) as the simple reference sort.
 template <class C, class Backend>
@@ -320,6 +334,7 @@ struct MsmConfig {
   uint32_t K0 = 4;           // bucket-reduce group size, level 0 (wide: keep the chain short)
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
+  uint32_t seg_tail_lanes = 256;         // seg-reduce levels with at most this many lanes run inside one launch
   uint32_t coop_max_points = 1u << 17;   // levels with more points than this use the serial fan-in K0
 };
 
@@ -416,9 +431,13 @@ class MsmPlan {
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
       size_t lanes2 = ceil_div_u32(slots, g.T2);
+      if (lanes2 <= cfg_.seg_tail_lanes) {
+        // the remaining levels are tiny: one workgroup walks them all in a single launch
+        be_.template seg_reduce_tail<C>(g, level, (uint32_t)slots, pk_, pp_, cur, offsets_, buckets_);
+        break;
+      }
       SegReduceBody<C> b{g, level, (uint32_t)slots, pk_[cur], pp_[cur], offsets_, buckets_, pk_[cur ^ 1], pp_[cur ^ 1]};
       be_.launch(b, lanes2);
-      if (lanes2 == 1) break;
       slots = 2 * lanes2; level++; cur ^= 1;
     }
 

@@ -62,4 +62,24 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t 
   if (l == 0) v.store(out + (size_t)(1 + a) * stride + (size_t)gidx * Pt::WORDS);
 }
 
+
+// The tail of the segmented reduction: levels whose lane count fits one workgroup are walked
+// inside a single launch (lane u of level L = thread u, u + 1024, ...), with a workgroup barrier
+// between levels instead of a kernel boundary (~60 us each on an otherwise idle stream).
+template <class C>
+__global__ void __launch_bounds__(256) k_seg_reduce_tail(MsmGeom g, uint32_t level, uint32_t slots, uint32_t* pk0, uint32_t* pk1,
+                                                         uint32_t* pp0, uint32_t* pp1, int cur, const uint32_t* offsets,
+                                                         uint32_t* buckets) {
+  uint32_t* pk[2] = {pk0, pk1}; uint32_t* pp[2] = {pp0, pp1};
+  for (;;) {
+    const uint32_t lanes2 = (slots + g.T2 - 1) / g.T2;
+    SegReduceBody<C> b{g, level, slots, pk[cur], pp[cur], offsets, buckets, pk[cur ^ 1], pp[cur ^ 1]};
+    for (uint32_t u = threadIdx.x; u < lanes2; u += blockDim.x) b(u);
+    if (lanes2 == 1) break;
+    __threadfence_block();
+    __syncthreads();
+    slots = 2 * lanes2; level++; cur ^= 1;
+  }
+}
+
 }  // namespace pc

@@ -52,6 +52,13 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
 }
 
 template <class C>
+void HipBackend::seg_reduce_tail(const MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
+                                 const uint32_t* offsets, uint32_t* buckets) {
+  hipLaunchKernelGGL(k_seg_reduce_tail<C>, dim3(1), dim3(256), 0, stream, g, level, slots, pk[0], pk[1], pp[0], pp[1], cur, offsets, buckets);
+  PC_HIP_CHECK(hipGetLastError());
+}
+
+template <class C>
 void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x,
                               const uint32_t* old_in, uint32_t* out) {
   if (K >= 16 && K <= 256) {
@@ -130,6 +137,8 @@ struct pc_ctx {
   float phases[8] = {0};
 };
 
+// lane 0: whole GPU, used by the blocking pc_hip_msm.  lanes 1..2: half the CUs each, used by
+// pc_hip_msm_async / pc_hip_msm_batch so that two MSMs genuinely run side by side.
 static constexpr int PC_MSM_LANES = 3;
 struct pc_srs {
   pc_ctx* ctx = nullptr;
@@ -169,7 +178,8 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
   if (srs->lanes[i]) return srs->lanes[i];
   MsmLane* L = new MsmLane();
   try {
-    L->be.init();
+    static const bool split = []() { const char* e = getenv("PC_HIP_SPLIT_CUS"); return !(e && e[0] == '0'); }();
+    if (i == 0 || !split) L->be.init(); else L->be.init(i - 1, PC_MSM_LANES - 1);
     switch (srs->curve) {
       case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, srs->n, srs->cfg); break;
       case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, srs->n, srs->cfg); break;
@@ -197,12 +207,13 @@ static void complete_job(pc_ctx* ctx, pc_job* job) {
 
 // Queue one MSM on the next lane (completing whatever that lane still holds).
 static int enqueue_job(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form, pc_mem where,
-                       size_t n, void* out_xy, int* out_is_infinity, pc_job* job) {
+                       size_t n, void* out_xy, int* out_is_infinity, pc_job* job, bool pipelined) {
   if (base_offset > srs->n) return PC_ERR_INVALID_ARG;
   size_t avail = srs->n - base_offset;     // msm_bigint semantics: min(bases.len(), scalars.len()) pairs
   if (n > avail) n = avail;
   if (n && !scalars) return PC_ERR_INVALID_ARG;
-  int li = srs->next_lane; srs->next_lane = (li + 1) % PC_MSM_LANES;
+  int li = 0;
+  if (pipelined) { li = 1 + srs->next_lane; srs->next_lane = (srs->next_lane + 1) % (PC_MSM_LANES - 1); }
   MsmLane* L = srs_lane(srs, li);
   if (L->inflight) complete_job(ctx, L->inflight);
   L->be.timing = ctx->be.timing;
@@ -329,7 +340,7 @@ int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void*
   std::lock_guard<std::mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     pc_job job;
-    int rc = enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, &job);
+    int rc = enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, &job, false);
     if (rc != PC_OK) return rc;
     complete_job(ctx, &job);
     return (int)PC_OK;
@@ -344,7 +355,7 @@ int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const
   *out_job = nullptr;
   pc_job* job = new (std::nothrow) pc_job();
   if (!job) return PC_ERR_OOM;
-  int rc = guarded(ctx, [&]() { return enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, job); });
+  int rc = guarded(ctx, [&]() { return enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, job, true); });
   if (rc != PC_OK) { delete job; return rc; }
   *out_job = job;
   return PC_OK;
@@ -370,7 +381,7 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
     std::vector<pc_job> jobs(n_polys);
     for (size_t k = 0; k < n_polys; k++) {
       int rc = enqueue_job(ctx, srs, base_offsets ? base_offsets[k] : 0, scalars[k], form, where, n[k],
-                           (uint8_t*)out_xy + k * (size_t)srs->aw * 4, out_is_infinity ? out_is_infinity + k : nullptr, &jobs[k]);
+                           (uint8_t*)out_xy + k * (size_t)srs->aw * 4, out_is_infinity ? out_is_infinity + k : nullptr, &jobs[k], n_polys > 1);
       if (rc != PC_OK) { for (size_t j = 0; j < k; j++) if (!jobs[j].done) complete_job(ctx, &jobs[j]); return rc; }
     }
     for (size_t k = 0; k < n_polys; k++) if (!jobs[k].done) complete_job(ctx, &jobs[k]);

@@ -34,6 +34,11 @@ struct CpuStepBackend {
     pc::sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries);
   }
   template <class C>
+  void seg_reduce_tail(const pc::MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
+                       const uint32_t* offsets, uint32_t* buckets) {
+    pc::seg_reduce_tail_serial<C>(*this, g, level, slots, pk, pp, cur, offsets, buckets);
+  }
+  template <class C>
   void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x, const uint32_t* old_in,
                     uint32_t* out) {
     pc::BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
@@ -48,7 +53,7 @@ template <class C>
 static void run(const uint32_t* bases, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int T, int T2, int K0,
                 int from_mont, uint32_t* out) {
   CpuStepBackend be;
-  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; }
+  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; cfg.seg_tail_lanes = (T2 == 5) ? 1 : 3; }
   pc::MsmPlan<C, CpuStepBackend> plan(be, n, cfg);
   plan.run(bases, base_off, scalars, n, from_mont != 0, out);
 }
