@@ -1,0 +1,76 @@
+// C++ host mirror of the Ligero encoder glue (poly-commit/src/linear_codes/), above the C ABI.
+//
+//   calculate_t                         linear_codes/utils.rs:156-184
+//   LigeroPCParams::compute_dimensions  linear_codes/ligero.rs:118-128
+//   reed_solomon                        linear_codes/utils.rs:112-127
+//   LinearEncode::compute_matrices      linear_codes/mod.rs:118-138
+// Matrix<F> is the reference's dense row-major matrix (utils.rs:49-147) flattened.
+#pragma once
+#include <math.h>
+#include "kzg10.hpp"
+
+namespace pc_host {
+
+inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+inline uint32_t ark_log2(size_t x) { if (x <= 1) return 0; uint32_t b = 0; size_t v = x - 1; while (v) { b++; v >>= 1; } return b; }   // ark_std::log2
+
+// Ok(t) or -1 (Error::InvalidParameters)
+inline long calculate_t(int field_bits, size_t sec_param, size_t dist_num, size_t dist_den, size_t codeword_len) {
+  double residual = (double)codeword_len / pow(2.0, field_bits);
+  double rhs = log2(pow(2.0, -(double)sec_param) - residual);
+  if (!isnormal(rhs)) return -1;
+  double nom = rhs - 1.0;
+  double denom = log2(1.0 - 0.5 * (double)dist_num / (double)dist_den);
+  if (!isnormal(denom)) return -1;
+  size_t t = (size_t)ceil(nom / denom);
+  return (long)(t < codeword_len ? t : codeword_len);
+}
+
+struct LigeroPCParams {              // linear_codes/ligero.rs:22-39 (the fields the encoder needs)
+  size_t sec_param = 128, rho_inv = 4;
+  // (n_rows, n_cols) for a polynomial of poly_len coefficients
+  template <class E>
+  std::pair<size_t, size_t> compute_dimensions(size_t poly_len) const {
+    long t = calculate_t(E::C::FrP::BITS, sec_param, rho_inv - 1, rho_inv, poly_len);
+    size_t n = (size_t)1 << ark_log2((size_t)ceil(sqrt((double)ceil_div(2 * poly_len, (size_t)t))));
+    size_t m = ceil_div(poly_len, n);
+    return {n, m};
+  }
+};
+
+template <class E>
+struct Matrix { size_t n = 0, m = 0; std::vector<FrT<E>> entries; FrT<E>& at(size_t r, size_t c) { return entries[r * m + c]; } };
+
+template <class E>
+struct LinearEncode {
+  // reed_solomon(msg, rho_inv): one row -> next_pow2(len * rho_inv) evaluations
+  static Error reed_solomon(pc_ctx* ctx, const std::vector<FrT<E>>& msg, size_t rho_inv, std::vector<FrT<E>>& out) {
+    Matrix<E> in; in.n = 1; in.m = msg.size(); in.entries = msg;
+    Matrix<E> ext; Error e = encode_rows(ctx, in, rho_inv, ext); out = ext.entries; return e;
+  }
+  static Error encode_rows(pc_ctx* ctx, const Matrix<E>& mat, size_t rho_inv, Matrix<E>& ext) {
+    size_t size = 1; unsigned lg = 0; while (size < mat.m * rho_inv) { size <<= 1; lg++; }
+    ext.n = mat.n; ext.m = size; ext.entries.assign(mat.n * size, FrT<E>::zero());
+    int rc = pc_hip_ntt_batch(ctx, E::ID, mat.entries.data(), PC_MEM_HOST, mat.n, mat.m, lg, ext.entries.data(), PC_MEM_HOST);
+    if (rc != PC_OK) { Error e; e.kind = Error::Backend; e.msg = pc_hip_strerror(rc); return e; }
+    return Error();
+  }
+  // compute_matrices: pad the coefficients to n_rows*n_cols, row-major, encode every row
+  static Error compute_matrices(pc_ctx* ctx, const DensePolynomial<E>& polynomial, const LigeroPCParams& param, Matrix<E>& mat, Matrix<E>& ext_mat) {
+    std::vector<FrT<E>> coeffs = polynomial.coeffs;
+    auto dims = param.compute_dimensions<E>(coeffs.size());
+    coeffs.resize(dims.first * dims.second, FrT<E>::zero());
+    mat.n = dims.first; mat.m = dims.second; mat.entries = coeffs;
+    return encode_rows(ctx, mat, param.rho_inv, ext_mat);
+  }
+};
+
+// omega of the size-2^lg domain (arkworks FftField constants), host side
+template <class E>
+FrT<E> domain_generator(unsigned lg) {
+  FrT<E> w; memcpy(w.l, E::C::FrP::ROOT, 32);
+  for (unsigned i = lg; i < (unsigned)E::C::FrP::TWO_ADICITY; i++) w = w * w;
+  return w;
+}
+
+}  // namespace pc_host

@@ -5,7 +5,8 @@
 //     C - v*g - v_bar*gamma_g  ==  (beta - z) * W          (kzg10/mod.rs:314-333)
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../poly-commit_amd/host/kzg10.hpp"
+#include "../../poly-commit_amd/host/marlin_kzg10.hpp"
+#include "../../poly-commit_amd/host/linear_codes.hpp"
 
 using namespace pc_host;
 
@@ -112,7 +113,86 @@ static void run(pc_ctx* ctx, const char* name) {
     CHECK(K::open(powers, p, rng.next_fr(), Randomness<E>::empty(), pr).kind == Error::TooManyCoefficients);
   }
   powers.release();
-  printf("%s: add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
+
+  // ---- MarlinKZG10 (marlin_pc tests: single_poly / two_polys_degree_bound / full_end_to_end shapes, marlin_pc/mod.rs:570-814)
+  // The verifier's equation (marlin/mod.rs:109-148 + kzg10 check) is evaluated in G1 with the trapdoor:
+  //   sum_j xi_j (C_j - v_j g) + sum_{bounded j} xi'_j (shC_j - v_j beta^(max - d_j) g) - random_v gamma_g == (beta - z) w
+  {
+    typedef MarlinKZG10<E> M;
+    struct Chal : ChallengeSource<E> { TestRng<E> r{0xC4A1}; std::vector<FrT<E>> log; FrT<E> squeeze_challenge() override { FrT<E> c = r.next_fr(); log.push_back(c); return c; } };
+    for (int variant = 0; variant < 3; variant++) {
+      const bool hiding = variant == 1;
+      std::vector<size_t> bounds = {9, 14, 20};
+      CommitterKey<E> ck;
+      CHECK(!M::trim(ctx, pg, pgg, 22, 2, &bounds, ck));
+      std::vector<LabeledPolynomial<E>> polys;
+      size_t degs[4] = {7, 14, 22, 3};
+      for (int j = 0; j < 4; j++) {
+        LabeledPolynomial<E> lp; lp.label = "p" + std::to_string(j); lp.polynomial = rand_poly<E>(degs[j], rng);
+        if (j == 0) lp.degree_bound = 9;
+        if (j == 1 && variant != 2) lp.degree_bound = 14;
+        if (hiding) lp.hiding_bound = 1;
+        polys.push_back(lp);
+      }
+      std::vector<MarlinCommitment<E>> comms; std::vector<MarlinRandomness<E>> states;
+      CHECK(!M::commit(ck, polys, hiding ? &rng : nullptr, comms, states));
+      // degree-bound commitments: shifted_comm == beta^(max_degree - d) * comm when nothing is hidden
+      if (!hiding) {
+        Fr bp = Fr::one(); for (size_t i = 0; i < ck.max_degree - 9; i++) bp = bp * beta;
+        CHECK(comms[0].shifted_comm.has_value() && *comms[0].shifted_comm == comms[0].comm.mul(bp));
+      }
+      Fr z = rng.next_fr();
+      Chal sponge;
+      Proof<E> proof;
+      CHECK(!M::open(ck, polys, z, sponge, states, proof));
+      CHECK(proof.has_random_v == hiding);
+      G1Affine<E> lhs = G1Affine<E>::zero();
+      size_t ci = 0;
+      for (int j = 0; j < 4; j++) {
+        Fr v = polys[j].polynomial.evaluate(z);
+        Fr xi = sponge.log[ci++];
+        lhs = lhs.add(comms[j].comm.add(g.mul(v).neg()).mul(xi));
+        if (polys[j].degree_bound) {
+          Fr xi1 = sponge.log[ci++];
+          Fr bp = Fr::one(); for (size_t i = 0; i < ck.max_degree - *polys[j].degree_bound; i++) bp = bp * beta;
+          lhs = lhs.add(comms[j].shifted_comm->add(g.mul(v * bp).neg()).mul(xi1));
+        }
+      }
+      if (hiding) lhs = lhs.add(gamma_g.mul(proof.random_v).neg());
+      CHECK(lhs == proof.w.mul(beta - z));
+      // a degree bound the key does not enforce is rejected (Error::UnsupportedDegreeBound, kzg10/mod.rs:430-434)
+      LabeledPolynomial<E> bad = polys[0]; bad.degree_bound = 11;
+      CHECK(M::check_degrees_and_bounds(ck, bad).kind == Error::UnsupportedDegreeBound);
+      ck.release();
+    }
+  }
+  // ---- Ligero encoder: test_reed_solomon (linear_codes/utils.rs:303-331) and the matrix shape ----
+  {
+    const size_t rho_inv = 3;
+    for (int i = 1; i < 10; i++) {
+      size_t m = (size_t)1 << i;
+      DensePolynomial<E> pol = rand_poly<E>(m - 1, rng);
+      std::vector<FrT<E>> encoded;
+      CHECK(!LinearEncode<E>::reed_solomon(ctx, pol.coeffs, rho_inv, encoded));
+      size_t size = 1; unsigned lg = 0; while (size < m * rho_inv) { size <<= 1; lg++; }
+      CHECK(encoded.size() == size);
+      FrT<E> w = domain_generator<E>(lg), x = FrT<E>::one();
+      for (size_t j = 0; j < size; j++) { CHECK(pol.evaluate(x) == encoded[j]); x = x * w; }   // large_domain.element(j)
+    }
+    LigeroPCParams param;                                       // rho_inv 4, lambda 128
+    auto d24 = param.compute_dimensions<E>((size_t)1 << 24);
+    if (E::ID != PC_CURVE_BN254) CHECK(d24.first == 512 && d24.second == 32768);
+    DensePolynomial<E> pol = rand_poly<E>(999, rng);
+    Matrix<E> mat, ext;
+    CHECK(!LinearEncode<E>::compute_matrices(ctx, pol, param, mat, ext));
+    CHECK(mat.n * mat.m >= 1000 && ext.n == mat.n && ext.m >= 4 * mat.m);
+    FrT<E> w = domain_generator<E>(ark_log2(ext.m));
+    for (size_t r = 0; r < mat.n; r++) {                        // every encoded row agrees with its row polynomial at omega^3
+      DensePolynomial<E> row; row.coeffs.assign(mat.entries.begin() + r * mat.m, mat.entries.begin() + (r + 1) * mat.m);
+      CHECK(row.evaluate(w * w * w) == ext.at(r, 3));
+    }
+  }
+  printf("%s: ligero reed_solomon/compute_matrices, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
 }
 
 int main() {
