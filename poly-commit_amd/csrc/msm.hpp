@@ -31,6 +31,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <algorithm>
 #include <vector>
 #include "ec.hpp"
 #include "host_tail.hpp"
@@ -361,35 +362,37 @@ class MsmPlan {
     if (cfg_.T2 < 4) cfg_.T2 = 4;       // each level must shrink the list: 2*ceil(s/T2) < s
     if (cfg_.K0 < 2) cfg_.K0 = 2;
     if (cfg_.K1 < 2) cfg_.K1 = 2;
-    uint32_t c = cfg.c ? cfg.c : msm_choose_c(n_max);
-    setup_geometry(c, n_max);
-    const size_t Mmax = (size_t)n_max * g_.W;
-    hist_ = (uint32_t*)be_.alloc(((size_t)g_.NB + 1) * 4);
-    offsets_ = (uint32_t*)be_.alloc(((size_t)g_.NB + 1) * 4);
-    cursor_ = (uint32_t*)be_.alloc(((size_t)g_.NB + 1) * 4);
-    entries_ = (uint32_t*)be_.alloc((Mmax ? Mmax : 1) * 4);
-    buckets_ = (uint32_t*)be_.alloc((size_t)g_.NB * Pt::WORDS * 4);
+    min_T_ = cfg_.T ? cfg_.T : 16;
+    // The window width is chosen per call from the call's n (a resident SRS serves MSMs of many
+    // lengths: KZG opens, IPA halving rounds).  Size every buffer for the worst call n <= n_max.
+    size_t NBmax = 1, Mmax = 1, red_max = 1, res_max = 1;
+    for (size_t n = 1;; n = (n * 2 < n_max) ? n * 2 : n_max) {
+      plan_geometry(n);
+      NBmax = std::max<size_t>(NBmax, g_.NB);
+      Mmax = std::max<size_t>(Mmax, n * (size_t)g_.W);
+      size_t total = 0;
+      for (uint32_t l = 0; l < n_levels_; l++) total += (size_t)(l + 2) * g_.W * lvl_m_[l];
+      red_max = std::max(red_max, total);
+      res_max = std::max<size_t>(res_max, (size_t)g_.W * (n_levels_ ? n_levels_ : 1));
+      if (n >= n_max) break;
+    }
+    hist_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
+    offsets_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
+    cursor_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
+    entries_ = (uint32_t*)be_.alloc(Mmax * 4);
+    buckets_ = (uint32_t*)be_.alloc(NBmax * Pt::WORDS * 4);
     scalars_ = (uint32_t*)be_.alloc((n_max ? n_max : 1) * (size_t)FrP::N * 4);
     // partial levels
-    size_t lanes0 = ceil_div_u32(Mmax ? Mmax : 1, min_T_);
+    size_t lanes0 = ceil_div_u32(Mmax, min_T_);
     size_t slots = 2 * lanes0;
     for (int i = 0; i < 2; i++) {
       pk_[i] = (uint32_t*)be_.alloc(slots * 4);
       pp_[i] = (uint32_t*)be_.alloc(slots * (size_t)Pt::WORDS * 4);
       slots = 2 * (size_t)ceil_div_u32(slots, cfg_.T2);
     }
-    // bucket-reduce levels
-    uint32_t m = g_.nb_win; n_levels_ = 0; size_t total = 0;
-    while (m > 1) {
-      // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
-      // points the chain length is all that matters: workgroup-cooperative fan-in K1.
-      uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
-      lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
-      total += (size_t)(n_levels_ + 2) * g_.W * m;             // S + Tw + older plain arrays
-      n_levels_++;
-    }
-    red_ = (uint32_t*)be_.alloc((total ? total : 1) * (size_t)Pt::WORDS * 4);
-    result_host_ = (uint32_t*)be_.alloc_host((size_t)g_.W * (n_levels_ ? n_levels_ : 1) * Pt::WORDS * 4);
+    red_ = (uint32_t*)be_.alloc(red_max * (size_t)Pt::WORDS * 4);
+    result_host_ = (uint32_t*)be_.alloc_host(res_max * Pt::WORDS * 4);
+    plan_geometry(n_max);
   }
   ~MsmPlan() {
     void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_};
@@ -411,11 +414,12 @@ class MsmPlan {
   // All device work of one MSM plus the asynchronous download of the <= W*levels partial
   // sums; returns as soon as everything is queued on the backend's stream.
   void enqueue(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont) {
+    pending_empty_ = (n == 0);
+    if (n == 0) return;
+    plan_geometry(n);
     MsmGeom g = g_;
     g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
     const size_t Mmax = n * g.W;
-    pending_empty_ = (n == 0);
-    if (n == 0) return;
     uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / cfg_.target_lanes);
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
@@ -471,10 +475,19 @@ class MsmPlan {
   }
 
  private:
-  void setup_geometry(uint32_t c, size_t n_max) {
+  // window width, bucket counts and the reduction-level plan for a call of n pairs
+  void plan_geometry(size_t n) {
+    uint32_t c = cfg_.c ? cfg_.c : msm_choose_c(n);
     g_.c = c; g_.W = msm_num_windows(FrP::BITS, c); g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
-    g_.n = (uint32_t)n_max; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2;
-    min_T_ = cfg_.T ? cfg_.T : 16;
+    g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2;
+    uint32_t m = g_.nb_win; n_levels_ = 0;
+    while (m > 1) {
+      // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
+      // points the chain length is all that matters: workgroup-cooperative fan-in K1.
+      uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
+      lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
+      n_levels_++;
+    }
   }
 
   // Horner over (level, window) on the host.  P_j[w] has weight 2^(c*w + k_0 + ... + k_{j-1}).

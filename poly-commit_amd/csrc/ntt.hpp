@@ -68,13 +68,15 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t l
                                                uint32_t log_n_total, uint32_t first_stage = 1) {
   typedef Fd<FrP> F;
   const uint32_t len = 1u << lg, halfs = len >> 1;
+  // every size is a power of two: index arithmetic is shifts and masks (an integer divide by a
+  // run-time value costs ~30 VALU instructions on this ISA, four of them per butterfly)
   for (uint32_t s = first_stage; s <= lg; s++) {
     const uint32_t h = 1u << (s - 1);
     const uint32_t tw_shift = log_n_total - s;       // omega_{2^s}^j = W[j << (log_n - s)]
     for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
-      uint32_t line = b / halfs, k = b % halfs;
-      uint32_t g = k / h, j = k % h;
-      uint32_t p0 = line * (len + 1) + g * 2 * h + j, p1 = p0 + h;
+      uint32_t line = b >> (lg - 1), k = b & (halfs - 1);
+      uint32_t g = k >> (s - 1), j = k & (h - 1);
+      uint32_t p0 = line * (len + 1) + (g << s) + j, p1 = p0 + h;
       F u = t.get(p0), v = t.get(p1);
       if (j) v = v.mul(F::load(W + ((size_t)j << tw_shift) * FrP::N));
       t.put(p0, u.add(v)); t.put(p1, u.sub(v));
@@ -89,8 +91,8 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   typedef Fd<FrP> F;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
-  const uint32_t tiles = N2 / C;
-  const uint32_t row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const uint32_t lgC = 31 - __builtin_clz(C), tile_bits = lg2 - lgC;
+  const uint32_t row = blockIdx.x >> tile_bits, tile = blockIdx.x & ((1u << tile_bits) - 1);
   LdsTile<FrP> t{smem, C * (N1 + 1)};
   const uint32_t* rin = in + (size_t)row * in_cols * FrP::N;
   // Zero padding: if only the first N >> z coefficients can be non-zero (rho_inv = 4 -> z = 2), a
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   // the first z DIT stages just replicate each value over its group of 2^z: skip them.
   const uint32_t zpow = 1u << zskip, n1nz = N1 >> zskip;
   for (uint32_t idx = threadIdx.x; idx < C * n1nz; idx += NTT_THREADS) {
-    uint32_t c = idx % C, i1 = idx / C;
+    uint32_t c = idx & (C - 1), i1 = idx >> lgC;
     uint32_t i = i1 * N2 + tile * C + c;
     F v = (i < in_cols) ? F::load(rin + (size_t)i * FrP::N) : F::zero();
     uint32_t pos = c * (N1 + 1) + bitrev(i1, lg1);
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   lds_ntt_stages<FrP>(t, C, lg1, W, log_n, zskip + 1);
   uint32_t* rout = tmp + (size_t)row * N * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
-    uint32_t c = idx % C, j1 = idx / C;
+    uint32_t c = idx & (C - 1), j1 = idx >> lgC;
     uint32_t i2 = tile * C + c;
     F v = t.get(c * (N1 + 1) + j1);
     uint32_t e = i2 * j1;                       // < N
@@ -123,19 +125,19 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const uint32_t* tmp,
   typedef Fd<FrP> F;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
-  const uint32_t tiles = N1 / R;
-  const uint32_t row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const uint32_t lgR = 31 - __builtin_clz(R), tile_bits = lg1 - lgR;
+  const uint32_t row = blockIdx.x >> tile_bits, tile = blockIdx.x & ((1u << tile_bits) - 1);
   LdsTile<FrP> t{smem, R * (N2 + 1)};
   const uint32_t* rin = tmp + ((size_t)row * N + (size_t)tile * R * N2) * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
-    uint32_t r = idx / N2, i2 = idx % N2;
+    uint32_t r = idx >> lg2, i2 = idx & (N2 - 1);
     t.put(r * (N2 + 1) + bitrev(i2, lg2), F::load(rin + (size_t)idx * FrP::N));
   }
   __syncthreads();
   lds_ntt_stages<FrP>(t, R, lg2, W, log_n);
   uint32_t* rout = out + (size_t)row * N * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
-    uint32_t r = idx % R, j2 = idx / R;
+    uint32_t r = idx & (R - 1), j2 = idx >> lgR;
     F v = t.get(r * (N2 + 1) + j2);
     v.store(rout + ((size_t)(tile * R + r) + (size_t)N1 * j2) * FrP::N);
   }
