@@ -152,6 +152,11 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host);
  * `h_prime.mul(inner_product(..))`, ipa_pc/mod.rs:672,675 -- one point, stays on the host as in
  * the reference. */
 int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy);
+/* out[i] = scalars[i] * g for one fixed base (scalars: n Fr, Montgomery, device; out: n affine
+ * points, device): `g.batch_mul(&powers_of_beta)` of KZG10::setup (kzg10/mod.rs:76,83).  Builds a
+ * true SRS for end-to-end tests; not on the commit/open path. */
+int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_host, const void* scalars_dev,
+                                size_t n, void* out_points_dev);
 /* Copy `count` resident affine points starting at `offset` back to the host (final_comm_key). */
 int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, void* out_xy);
 

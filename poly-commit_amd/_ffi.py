@@ -75,6 +75,7 @@ def load_library():
     lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
     lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
+    lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_poly_div_scan.argtypes = [vp, ip, vp, ip, sz, vp, vp, vp, ip]
     lib.pc_hip_points_sum.argtypes = [ip, vp, sz, vp]
     lib.pc_hip_point_mul.argtypes = [ip, vp, vp, vp]
@@ -190,6 +191,11 @@ class Context:
     def fr_powers(self, curve, z, n, out_dev):
         z = np.ascontiguousarray(z, dtype=np.uint64)
         self.check(self.lib.pc_hip_fr_powers(self.h, CURVES[curve], C.c_void_p(z.ctypes.data), n, out_dev))
+
+    def fixed_base_batch_mul(self, curve, g_xy, scalars_dev, n, out_dev):
+        """out[i] = scalars[i] * g (device buffers): the SRS generation of KZG10::setup."""
+        g_xy = np.ascontiguousarray(g_xy, dtype=np.uint64)
+        self.check(self.lib.pc_hip_fixed_base_batch_mul(self.h, CURVES[curve], C.c_void_p(g_xy.ctypes.data), scalars_dev, n, out_dev))
 
     def upload_srs(self, curve, bases, n=None, stride_bytes=0):
         return Srs(self, curve, bases, n, stride_bytes)

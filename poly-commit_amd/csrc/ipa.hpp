@@ -68,4 +68,29 @@ struct EcFoldBody {
   }
 };
 
+
+// out[i] = scalars[i] * g for one fixed base g: `g.batch_mul(powers_of_beta)`, the SRS generation
+// of KZG10::setup (poly-commit/src/kzg10/mod.rs:76,83).  One lane per scalar, plain
+// double-and-add; affine output.  Used to build TRUE structured reference strings for the
+// trapdoor-checked end-to-end tests, not on the commit/open path.
+template <class C>
+struct FixedBaseMulBody {
+  typedef XyzzD<C> Pt;
+  static constexpr int AW = 2 * Fd<typename C::FqP>::N;
+  const uint32_t* scalars;   // n x Fr, Montgomery
+  uint32_t g[AW];
+  uint32_t* out;             // n affine points
+  PC_HD void operator()(uint32_t i) const {
+    typedef Fd<typename C::FrP> Fr;
+    Fr k = Fr::load(scalars + (size_t)i * C::FrP::N).from_mont();
+    AffD<C> base = AffD<C>::load(g);
+    Pt acc = Pt::infinity();
+    for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
+      acc = acc.dbl();
+      if ((k.l[bit >> 5] >> (bit & 31)) & 1) acc.add_affine(base);
+    }
+    acc.to_affine().store(out + (size_t)i * AW);
+  }
+};
+
 }  // namespace pc

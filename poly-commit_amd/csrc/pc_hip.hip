@@ -625,6 +625,29 @@ int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mo
   }
   return PC_OK;
 }
+extern "C++" {
+template <class C>
+static void fixed_base_t(pc::HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out) {
+  pc::FixedBaseMulBody<C> body; body.scalars = scalars; body.out = out;
+  for (int i = 0; i < pc::FixedBaseMulBody<C>::AW; i++) body.g[i] = g[i];
+  be.launch(body, n, 64); be.sync();
+}
+}  // extern "C++"
+int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_host, const void* scalars_dev, size_t n,
+                                void* out_points_dev) {
+  if (!ctx || (int)curve < 0 || (int)curve > 2 || !g_xy_host || (n && (!scalars_dev || !out_points_dev))) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (!n) return (int)PC_OK;
+    switch (curve) {
+      case PC_CURVE_BLS12_381: fixed_base_t<pc_curve_bls12_381>(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev); break;
+      case PC_CURVE_BN254: fixed_base_t<pc_curve_bn254>(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev); break;
+      default: fixed_base_t<pc_curve_pallas>(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev); break;
+    }
+    return (int)PC_OK;
+  });
+}
 int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, void* out_xy) {
   if (!ctx || !srs || srs->ctx != ctx || offset + count > srs->n || (count && !out_xy)) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -152,3 +152,25 @@ def test_msm_async_pipeline_and_batch(ctx):
     for i in range(k):
         assert (out[i] == want[i]).all() and infs[i] == 0
     srs.free()
+
+
+def test_msm_full_size_2_20_parity_and_linearity(ctx):
+    """BASELINE configs[1] size (2^20 + 1 pairs): parity with the oracle and, independently of
+    it, linearity msm(s) + msm(t) == msm(s + t)."""
+    import poly_commit_amd as pc
+    curve = "bls12_381"
+    n = (1 << 20) + 1
+    fr = R.FIELDS["bls12_381_fr"]["p"]
+    bases = O.gen_bases(curve, n)
+    s = O.gen_scalars(curve, 0x5EED0001, n)
+    t = O.gen_scalars(curve, 0x5EED0002, n)
+    srs = ctx.upload_srs(curve, bases)
+    a, _ = srs.msm(s)
+    b, _ = srs.msm(t)
+    # s + t mod r with numpy object ints would be slow: use the Montgomery path, (s + t) via host big ints on a sample is not
+    # enough, so add limb-wise in Python ints
+    st = O.ints_to_limbs([(x + y) % fr for x, y in zip(O.limbs_to_ints(s), O.limbs_to_ints(t))], 4)
+    c, _ = srs.msm(st)
+    assert (pc.points_sum(curve, np.stack([a, b])) == c).all()
+    assert (a == O.msm_pippenger(curve, bases, s, 16, 1)).all()
+    srs.free()
