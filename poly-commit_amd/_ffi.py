@@ -21,7 +21,8 @@ class PcHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "libpc_hip.so")
+    # PC_HIP_LIB: alternative build of the same library (kernel tuning experiments)
+    return os.environ.get("PC_HIP_LIB") or os.path.join(HERE, "libpc_hip.so")
 
 
 def load_library():

@@ -23,7 +23,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
+           "-Wno-unused-value"] + os.environ.get("PC_HIP_CXXFLAGS", "").split() + \
+          ["-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

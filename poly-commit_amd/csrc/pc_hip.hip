@@ -137,8 +137,8 @@ struct pc_ctx {
   float phases[8] = {0};
 };
 
-// lane 0: whole GPU, used by the blocking pc_hip_msm.  lanes 1..2: half the CUs each, used by
-// pc_hip_msm_async / pc_hip_msm_batch so that two MSMs genuinely run side by side.
+// Independent pipelines per SRS (stream + workspace each), used round-robin; a pipeline that still
+// holds a job is drained before it is reused.
 static constexpr int PC_MSM_LANES = 3;
 struct pc_srs {
   pc_ctx* ctx = nullptr;
@@ -178,7 +178,9 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
   if (srs->lanes[i]) return srs->lanes[i];
   MsmLane* L = new MsmLane();
   try {
-    static const bool split = []() { const char* e = getenv("PC_HIP_SPLIT_CUS"); return !(e && e[0] == '0'); }();
+    // CU-partitioned pipelines are opt-in (PC_HIP_SPLIT_CUS=1): on this part a masked stream lost far
+    // more throughput than the share of CUs it gave up (accumulate 3.65 ms on 256 CUs, 6.8 ms on 240).
+    static const bool split = []() { const char* e = getenv("PC_HIP_SPLIT_CUS"); return e && e[0] == '1'; }();
     if (i == 0 || !split) L->be.init(); else L->be.init(i - 1, PC_MSM_LANES - 1);
     switch (srs->curve) {
       case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, srs->n, srs->cfg); break;
@@ -212,8 +214,8 @@ static int enqueue_job(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void*
   size_t avail = srs->n - base_offset;     // msm_bigint semantics: min(bases.len(), scalars.len()) pairs
   if (n > avail) n = avail;
   if (n && !scalars) return PC_ERR_INVALID_ARG;
-  int li = 0;
-  if (pipelined) { li = 1 + srs->next_lane; srs->next_lane = (srs->next_lane + 1) % (PC_MSM_LANES - 1); }
+  (void)pipelined;
+  int li = srs->next_lane; srs->next_lane = (srs->next_lane + 1) % PC_MSM_LANES;
   MsmLane* L = srs_lane(srs, li);
   if (L->inflight) complete_job(ctx, L->inflight);
   L->be.timing = ctx->be.timing;
