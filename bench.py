@@ -331,7 +331,7 @@ def main():
                          "kernel": "k_run<AccumulateBody> (bucket accumulation), avg of hipEvent-timed launches",
                          "algorithmic_bytes_per_launch": pairs_per_launch * PAIR_BYTES[curve]},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(curve, args.log_degree)
         print(json.dumps(out))
     if dist is not None:

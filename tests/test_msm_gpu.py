@@ -174,3 +174,46 @@ def test_msm_full_size_2_20_parity_and_linearity(ctx):
     assert (pc.points_sum(curve, np.stack([a, b])) == c).all()
     assert (a == O.msm_pippenger(curve, bases, s, 16, 1)).all()
     srs.free()
+
+
+def test_msm_large_adversarial_and_known_answer(ctx):
+    """2^18 pairs with scalar distributions that defeat a naive bucket method (every scalar
+    equal -> one bucket per window holds everything; two values; mostly zero), and the closed
+    form  sum_i 1 * (i+1)G = n(n+1)/2 * G  that needs no oracle MSM at all."""
+    import poly_commit_amd as pc
+    curve = "bls12_381"
+    n = 1 << 18
+    fr = R.FIELDS["bls12_381_fr"]["p"]
+    bases = O.gen_bases(curve, n)
+    srs = ctx.upload_srs(curve, bases)
+    g = bases[0]
+    ones = O.ints_to_limbs([1], 4).repeat(n, axis=0)
+    got, _ = srs.msm(np.ascontiguousarray(ones))
+    want = pc.point_mul(curve, g, O.fr_mont_array(curve, [n * (n + 1) // 2 % fr])[0])
+    assert (got == want).all()
+    rnd = O.gen_scalars(curve, 5, n)
+    same = np.ascontiguousarray(np.repeat(rnd[:1], n, axis=0))
+    got, _ = srs.msm(same)
+    want = pc.point_mul(curve, want, O.f_to_mont(curve, 1, rnd[:1])[0])          # k * sum P_i
+    assert (got == want).all()
+    two = np.ascontiguousarray(np.where((np.arange(n) % 2 == 0)[:, None], rnd[:1], rnd[1:2]))
+    assert (srs.msm(two)[0] == O.msm_pippenger(curve, bases, two, 16, 1)).all()
+    sparse = np.ascontiguousarray(np.where((np.arange(n) % 97 == 0)[:, None], rnd, 0).astype(np.uint64))
+    assert (srs.msm(sparse)[0] == O.msm_pippenger(curve, bases, sparse, 16, 1)).all()
+    srs.free()
+
+
+def test_msm_2_22_known_answer_and_parity(ctx):
+    """Beyond the bench size: 2^22 pairs (auto window c = 18)."""
+    import poly_commit_amd as pc
+    curve = "bn254"
+    n = 1 << 22
+    fr = R.FIELDS["bn254_fr"]["p"]
+    bases = O.gen_bases(curve, n)
+    srs = ctx.upload_srs(curve, bases)
+    ones = np.ascontiguousarray(O.ints_to_limbs([1], 4).repeat(n, axis=0))
+    got, _ = srs.msm(ones)
+    assert (got == pc.point_mul(curve, bases[0], O.fr_mont_array(curve, [n * (n + 1) // 2 % fr])[0])).all()
+    s = O.gen_scalars(curve, 77, n)
+    assert (srs.msm(s)[0] == O.msm_pippenger(curve, bases, s, 64, 1)).all()
+    srs.free()
