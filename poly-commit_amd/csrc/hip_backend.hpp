@@ -9,6 +9,8 @@
 
 namespace pc {
 
+template <class C> struct AccumulateBody;
+
 struct HipError : std::runtime_error {
   hipError_t code;
   HipError(hipError_t c, const char* what) : std::runtime_error(std::string(what) + ": " + hipGetErrorString(c)), code(c) {}
@@ -97,6 +99,10 @@ struct HipBackend {
                     uint32_t* entries);
   void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
   int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
+
+  // bucket accumulation with the neighbour merge of cut runs (msm_coop.hpp)
+  template <class C>
+  void accumulate(const struct AccumulateBody<C>& body, size_t lanes);
 
   // all remaining (small) levels of the segmented reduction in one launch
   template <class C>

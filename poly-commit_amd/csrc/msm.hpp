@@ -167,10 +167,12 @@ struct AccumulateBody {
     acc.store(ppts + (size_t)slot * Pt::WORDS);
     if (first) k0 = k; else k1 = k;
   }
-  PC_HD void operator()(uint32_t t) const {
+  // One lane's chunk.  Returns the keys of its (at most two) partial runs -- their points are in
+  // slots 2t / 2t+1 -- and, in `last`, the register copy of the last run's sum (valid iff k1 is).
+  PC_HD void chunk(uint32_t t, uint32_t& k0, uint32_t& k1, Pt& last) const {
     const uint32_t M = offsets[g.NB];
     const uint64_t s64 = (uint64_t)t * g.T;
-    uint32_t k0 = KEY_INVALID, k1 = KEY_INVALID;
+    k0 = KEY_INVALID; k1 = KEY_INVALID;
     if (s64 < M) {
       const uint32_t s = (uint32_t)s64;
       const uint32_t e = (M - s > g.T) ? s + g.T : M;
@@ -194,7 +196,12 @@ struct AccumulateBody {
         val = nval; pt = npt;
       }
       flush(acc, k, s, e, t, first, k0, k1);
+      last = acc;
     }
+  }
+  PC_HD void operator()(uint32_t t) const {
+    uint32_t k0, k1; Pt last;
+    chunk(t, k0, k1, last);
     pkeys[2 * t] = k0; pkeys[2 * t + 1] = k1;
   }
 };
@@ -430,7 +437,7 @@ class MsmPlan {
     be_.template sort_entries<C>(g, scalars_dev, hist_, offsets_, cursor_, entries_);
 
     size_t lanes = ceil_div_u32(Mmax, T);
-    { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.launch(b, lanes); }
+    { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
     be_.mark();   // 4: accumulate
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {

@@ -63,6 +63,45 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t 
 }
 
 
+// Bucket accumulation with an in-workgroup merge of the runs that chunk edges cut in two.
+// AccumulateBody::chunk leaves, per lane, a partial for its first run (bucket began in an earlier
+// chunk) and one for its last run (bucket continues in the next chunk).  With ~32 entries per
+// bucket and 64 per chunk nearly every bucket is cut exactly once, i.e. its two halves sit in
+// neighbouring lanes: lane t hands its last-run sum to lane t+1 through LDS, lane t+1 adds it to
+// its first-run partial and, if the bucket ends inside its chunk, writes the finished bucket.
+// Only buckets spanning >= 3 chunks or a workgroup edge still go through the partial list.
+template <class C>
+__global__ void __launch_bounds__(256) k_accumulate(AccumulateBody<C> b, uint32_t lanes) {
+  typedef XyzzD<C> Pt;
+  __shared__ uint32_t xch[Pt::WORDS * 256];
+  __shared__ uint32_t key_offer[256], key_first[256];
+  const uint32_t tid = threadIdx.x, t = blockIdx.x * 256 + tid;
+  const bool valid = t < lanes;
+  uint32_t k0 = KEY_INVALID, k1 = KEY_INVALID;
+  Pt last = Pt::infinity();
+  if (valid) b.chunk(t, k0, k1, last);
+  LdsPoints<C> lds{xch, 256};
+  key_offer[tid] = k1; key_first[tid] = k0;
+  if (k1 != KEY_INVALID) lds.put(tid, last);
+  __syncthreads();
+  const bool give = k1 != KEY_INVALID && tid < 255 && key_first[tid + 1] == k1;
+  const bool take = k0 != KEY_INVALID && tid > 0 && key_offer[tid - 1] == k0;
+  if (take) {
+    uint32_t* slot = b.ppts + (size_t)(2 * t) * Pt::WORDS;
+    Pt f = Pt::load(slot);
+    f.add(lds.get(tid - 1));
+    // the merged sum covers the bucket from its start (inside lane t-1's chunk) to where lane t's
+    // first run stopped: complete iff the bucket ends inside this chunk
+    const uint32_t M = b.offsets[b.g.NB];
+    const uint64_t s64 = (uint64_t)t * b.g.T;
+    const uint32_t e = (M - (uint32_t)s64 > b.g.T) ? (uint32_t)s64 + b.g.T : M;
+    if (b.offsets[k0 + 1] <= e) { f.store(b.buckets + (size_t)k0 * Pt::WORDS); k0 = KEY_INVALID; }
+    else f.store(slot);
+  }
+  if (give) k1 = KEY_INVALID;
+  if (valid) { b.pkeys[2 * t] = k0; b.pkeys[2 * t + 1] = k1; }
+}
+
 // The tail of the segmented reduction: levels whose lane count fits one workgroup are walked
 // inside a single launch (lane u of level L = thread u, u + 1024, ...), with a workgroup barrier
 // between levels instead of a kernel boundary (~60 us each on an otherwise idle stream).

@@ -52,6 +52,13 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
 }
 
 template <class C>
+void HipBackend::accumulate(const AccumulateBody<C>& body, size_t lanes) {
+  if (lanes == 0) return;
+  hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, body, (uint32_t)lanes);
+  PC_HIP_CHECK(hipGetLastError());
+}
+
+template <class C>
 void HipBackend::seg_reduce_tail(const MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
                                  const uint32_t* offsets, uint32_t* buckets) {
   hipLaunchKernelGGL(k_seg_reduce_tail<C>, dim3(1), dim3(256), 0, stream, g, level, slots, pk[0], pk[1], pp[0], pp[1], cur, offsets, buckets);

@@ -34,6 +34,8 @@ struct CpuStepBackend {
     pc::sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries);
   }
   template <class C>
+  void accumulate(const pc::AccumulateBody<C>& body, size_t lanes) { launch(body, lanes); }
+  template <class C>
   void seg_reduce_tail(const pc::MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
                        const uint32_t* offsets, uint32_t* buckets) {
     pc::seg_reduce_tail_serial<C>(*this, g, level, slots, pk, pp, cur, offsets, buckets);
