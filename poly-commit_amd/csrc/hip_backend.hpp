@@ -2,7 +2,6 @@
 // kernel body launched through a single generic __global__ wrapper, scans through hipCUB.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -25,6 +24,52 @@ template <class Body>
 __global__ void __launch_bounds__(256) k_run(Body body, uint32_t lanes) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < lanes) body(i);
+}
+
+// ---- exclusive scan of u32 (three small kernels; n up to 2^32) --------------------------------
+// tile = 1024 elements per workgroup (256 lanes x 4): tile sums -> scan of the tile sums (recursive
+// for > 1M tiles, which never happens here) -> per-tile exclusive scan seeded with the tile base.
+static constexpr uint32_t SCAN_TILE = 1024;
+__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* lds /* 256 */, uint32_t& total) {
+  const uint32_t tid = threadIdx.x;
+  lds[tid] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t x = tid >= d ? lds[tid - d] : 0u;
+    __syncthreads();
+    lds[tid] += x;
+    __syncthreads();
+  }
+  total = lds[255];
+  return lds[tid] - v;
+}
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* in, size_t n, uint32_t* tile_sums) {
+  __shared__ uint32_t lds[256];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  uint32_t s = 0;
+  for (int k = 0; k < 4; k++) if (base + k < n) s += in[base + k];
+  uint32_t total; (void)wg_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256) k_scan_small(uint32_t* v, uint32_t n) {   // in place, n <= 2^20, one workgroup
+  __shared__ uint32_t lds[256];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += SCAN_TILE) {
+    uint32_t a[4]; uint32_t s = 0;
+    for (int k = 0; k < 4; k++) { uint32_t i = base + threadIdx.x * 4 + k; a[k] = i < n ? v[i] : 0u; s += a[k]; }
+    uint32_t total; uint32_t ex = wg_exclusive_scan(s, lds, total) + carry;
+    for (int k = 0; k < 4; k++) { uint32_t i = base + threadIdx.x * 4 + k; if (i < n) v[i] = ex; ex += a[k]; }
+    carry += total;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* in, size_t n, const uint32_t* tile_base, uint32_t* out) {
+  __shared__ uint32_t lds[256];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  uint32_t a[4]; uint32_t s = 0;
+  for (int k = 0; k < 4; k++) { a[k] = base + k < n ? in[base + k] : 0u; s += a[k]; }
+  uint32_t total; uint32_t ex = wg_exclusive_scan(s, lds, total) + tile_base[blockIdx.x];
+  for (int k = 0; k < 4; k++) { if (base + k < n) out[base + k] = ex; ex += a[k]; }
 }
 
 struct HipBackend {
@@ -84,13 +129,18 @@ struct HipBackend {
   void wait_done() { PC_HIP_CHECK(hipEventSynchronize(done)); }
 
   void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n) {
-    size_t need = 0;
-    PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, stream));
-    if (need > scan_tmp_bytes) {
+    if (n == 0) return;
+    const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tiles > (1u << 20)) throw std::runtime_error("exclusive_scan_u32: input too large");
+    if (tiles * 4 > scan_tmp_bytes) {
       if (scan_tmp) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(scan_tmp); }
-      PC_HIP_CHECK(hipMalloc(&scan_tmp, need)); scan_tmp_bytes = need;
+      PC_HIP_CHECK(hipMalloc(&scan_tmp, tiles * 4)); scan_tmp_bytes = tiles * 4;
     }
-    PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, need, in, out, (int)n, stream));
+    uint32_t* sums = (uint32_t*)scan_tmp;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)tiles), dim3(256), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, stream, sums, (uint32_t)tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(256), 0, stream, in, n, (const uint32_t*)sums, out);
+    PC_HIP_CHECK(hipGetLastError());
   }
 
   // steps 1-3 of the MSM: LDS radix sort (msm_sort.hpp) or the atomic reference sort
