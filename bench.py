@@ -328,7 +328,7 @@ def main():
                 ["digits_hist", "scan", "scatter", "accumulate", "seg_reduce", "bucket_reduce"], ph[:6])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_run<AccumulateBody> (bucket accumulation), avg of hipEvent-timed launches",
+                         "kernel": "k_accumulate (bucket accumulation), avg of hipEvent-timed launches on the MSM pipelines' streams",
                          "algorithmic_bytes_per_launch": pairs_per_launch * PAIR_BYTES[curve]},
         }
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
