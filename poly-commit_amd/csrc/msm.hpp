@@ -442,7 +442,7 @@ class MsmPlan {
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
       size_t lanes2 = ceil_div_u32(slots, g.T2);
-      if (lanes2 <= cfg_.seg_tail_lanes) {
+      if (lanes2 <= (cfg_.seg_tail_lanes ? cfg_.seg_tail_lanes : 1u)) {   // lanes2 == 1 always ends the walk
         // the remaining levels are tiny: one workgroup walks them all in a single launch
         be_.template seg_reduce_tail<C>(g, level, (uint32_t)slots, pk_, pp_, cur, offsets_, buckets_);
         break;
