@@ -303,6 +303,41 @@ struct BucketLevelBody {
   }
 };
 
+// "Bits" level (K >= 16): the weighted sum of a group is returned as log2(K) plain partial sums
+//   A_b = sum of the X_l whose index l has bit b set,   sum_l l*X_l = sum_b 2^b A_b,
+// whose weights 2^b are applied by the host's Horner chain.  Workgroup-cooperatively (msm_coop.hpp)
+// all of them and S fall out of ONE binary tree of log2(K) dependent additions; this lane-serial
+// form is what the CPU stepping backend runs.  Output arrays: [0] = S, [1+b] = A_b,
+// [1+log2 K] = copy of S when the level's weights are l+1 (weight_off), then the older arrays.
+template <class C>
+struct BucketLevelBitsBody {
+  typedef XyzzD<C> Pt;
+  uint32_t K, lgK, weight_off, cnt, n_old;
+  const uint32_t* x; const uint32_t* old_in; uint32_t* out;
+  PC_HD void operator()(uint32_t lane) const {
+    const uint32_t a = lane / cnt, gidx = lane % cnt;
+    const size_t stride = (size_t)cnt * Pt::WORDS;
+    const uint32_t nw = lgK + weight_off;
+    if (a == 0) {
+      const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;
+      Pt S = Pt::infinity();
+      for (uint32_t l = 0; l < K; l++) S.add(Pt::load(base + (size_t)l * Pt::WORDS));
+      S.store(out + (size_t)gidx * Pt::WORDS);
+      if (weight_off) S.store(out + (size_t)(1 + lgK) * stride + (size_t)gidx * Pt::WORDS);
+      for (uint32_t b = 0; b < lgK; b++) {
+        Pt A = Pt::infinity();
+        for (uint32_t l = 0; l < K; l++) if ((l >> b) & 1) A.add(Pt::load(base + (size_t)l * Pt::WORDS));
+        A.store(out + (size_t)(1 + b) * stride + (size_t)gidx * Pt::WORDS);
+      }
+    } else {
+      const uint32_t* base = old_in + (size_t)(a - 1) * cnt * K * Pt::WORDS + (size_t)gidx * K * Pt::WORDS;
+      Pt acc = Pt::infinity();
+      for (uint32_t j = 0; j < K; j++) acc.add(Pt::load(base + (size_t)j * Pt::WORDS));
+      acc.store(out + (size_t)(nw + a) * stride + (size_t)gidx * Pt::WORDS);
+    }
+  }
+};
+
 // All remaining seg-reduce levels, one after the other (the CPU stepping backend's version of
 // HipBackend::seg_reduce_tail, which runs the same loop inside one workgroup).
 template <class C, class Backend>
@@ -378,9 +413,9 @@ class MsmPlan {
       NBmax = std::max<size_t>(NBmax, g_.NB);
       Mmax = std::max<size_t>(Mmax, n * (size_t)g_.W);
       size_t total = 0;
-      for (uint32_t l = 0; l < n_levels_; l++) total += (size_t)(l + 2) * g_.W * lvl_m_[l];
+      for (uint32_t l = 0; l < n_levels_; l++) total += (size_t)(1 + lvl_narr_[l]) * g_.W * lvl_m_[l];
       red_max = std::max(red_max, total);
-      res_max = std::max<size_t>(res_max, (size_t)g_.W * (n_levels_ ? n_levels_ : 1));
+      res_max = std::max<size_t>(res_max, (size_t)g_.W * (n_levels_ ? lvl_narr_[n_levels_ - 1] : 1));
       if (n >= n_max) break;
     }
     hist_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
@@ -454,7 +489,7 @@ class MsmPlan {
 
     be_.mark();   // 5: segmented reduction of partials
     // bucket reduction
-    // layout of red_: per level l: [S_l][Tw_l = P_l][P_{l-1} reduced]...[P_0 reduced], each W * lvl_m_[l] points
+    // layout of red_: per level l: [S_l][this level's weighted arrays][older arrays, folded], each W * lvl_m_[l] points
     const uint32_t* x = buckets_;
     uint32_t* lvl_base = red_;
     uint32_t* prev_base = nullptr;
@@ -462,15 +497,15 @@ class MsmPlan {
       const uint32_t K = lvl_K_[l], m_out = lvl_m_[l];
       const size_t cnt = (size_t)g.W * m_out;           // groups at this level
       const size_t stride = cnt * Pt::WORDS;
-      // previous level's arrays 1..l ([Tw_{l-1}][P_{l-2}]...[P_0]) are contiguous after its S array
+      const uint32_t n_old = l ? lvl_narr_[l - 1] : 0;  // previous level's arrays after its S array, contiguous
       const uint32_t* old_in = l ? prev_base + (size_t)g.W * lvl_m_[l - 1] * Pt::WORDS : nullptr;
-      be_.template bucket_level<C>(K, l == 0 ? 1u : 0u, (uint32_t)cnt, l, x, old_in, lvl_base);
-      x = lvl_base; prev_base = lvl_base; lvl_base += (size_t)(l + 2) * stride;
+      be_.template bucket_level<C>(K, l == 0 ? 1u : 0u, (uint32_t)cnt, n_old, lvl_bits_[l] != 0, x, old_in, lvl_base);
+      x = lvl_base; prev_base = lvl_base; lvl_base += (size_t)(1 + lvl_narr_[l]) * stride;
     }
     be_.mark();   // 6: bucket reduction
-    // download: the last level holds W points per array: [S][P_{L-1}][P_{L-2}]...[P_0]
+    // download: the last level holds W points per array, S first
     if (n_levels_ == 0) be_.copy_d2h_async(result_host_, buckets_, (size_t)g.W * Pt::WORDS * 4);
-    else be_.copy_d2h_async(result_host_, prev_base + (size_t)g.W * Pt::WORDS, (size_t)g.W * n_levels_ * Pt::WORDS * 4);
+    else be_.copy_d2h_async(result_host_, prev_base + (size_t)g.W * Pt::WORDS, (size_t)g.W * lvl_narr_[n_levels_ - 1] * Pt::WORDS * 4);
     be_.record_done();
   }
 
@@ -488,11 +523,25 @@ class MsmPlan {
     g_.c = c; g_.W = msm_num_windows(FrP::BITS, c); g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2;
     uint32_t m = g_.nb_win; n_levels_ = 0;
+    uint32_t kbits = 0; arr_exp_.clear();
     while (m > 1) {
       // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
-      // points the chain length is all that matters: workgroup-cooperative fan-in K1.
+      // points the chain length is all that matters: workgroup-cooperative "bits" levels (K1).
       uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
+      uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
+      const bool bits = K >= 16;
+      const uint32_t woff = n_levels_ == 0 ? 1u : 0u;
+      const uint32_t nw = bits ? lgK + woff : 1u;
       lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
+      lvl_bits_[n_levels_] = bits;
+      lvl_narr_[n_levels_] = nw + (n_levels_ ? lvl_narr_[n_levels_ - 1] : 0);
+      // weights of the new arrays (as powers of two), then the older arrays keep theirs
+      std::vector<uint32_t> e;
+      if (bits) { for (uint32_t b = 0; b < lgK; b++) e.push_back(kbits + b); if (woff) e.push_back(kbits); }
+      else e.push_back(kbits);
+      e.insert(e.end(), arr_exp_.begin(), arr_exp_.end());
+      arr_exp_.swap(e);
+      kbits += lgK;
       n_levels_++;
     }
   }
@@ -504,14 +553,10 @@ class MsmPlan {
     if (L == 0) {   // c == 1: one bucket per window, weight 1
       for (uint32_t w = 0; w < W; w++) items.push_back({g_.c * w, &result_host_[(size_t)w * Pt::WORDS]});
     } else {
-      // arrays 1..L of the last level (array 0 is S, weight 0 -> unused); array a holds P_{L-a}
-      uint32_t kbits = 0;
-      for (uint32_t j = 0; j < L; j++) {
+      // arrays after S of the last level, weights 2^(c*w + arr_exp_[a])
+      for (size_t a = 0; a < arr_exp_.size(); a++)
         for (uint32_t w = 0; w < W; w++)
-          items.push_back({g_.c * w + kbits, &result_host_[((size_t)(L - 1 - j) * W + w) * Pt::WORDS]});
-        uint32_t kj = 0; while ((1u << kj) < lvl_K_[j]) kj++;
-        kbits += kj;
-      }
+          items.push_back({g_.c * w + arr_exp_[a], &result_host_[(a * W + w) * Pt::WORDS]});
     }
     host64::horner_to_affine<C>(items, out_host);
   }
@@ -523,7 +568,8 @@ class MsmPlan {
   uint32_t min_T_;
   uint32_t *hist_, *offsets_, *cursor_, *entries_, *buckets_, *scalars_, *red_;
   uint32_t* pk_[2]; uint32_t* pp_[2];
-  uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32];
+  uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32]; uint32_t lvl_bits_[32]; uint32_t lvl_narr_[32];
+  std::vector<uint32_t> arr_exp_;   // log2 weight of every array after S at the last level
   uint32_t* result_host_ = nullptr;   // pinned
   bool pending_empty_ = true;
 };

@@ -1,11 +1,9 @@
 // Workgroup-cooperative bucket-reduction level (HIP only).
 //
-// Same contract as BucketLevelBody (msm.hpp) for one group of K points, but the K points are
-// spread over K lanes of one workgroup and combined through LDS in 2*log2(K) dependent EC
-// additions instead of 2*K: a right-to-left Hillis-Steele scan gives the suffix sums
-// R_l = sum_{i>=l} X_i (S = R_0), a tree reduction gives Tw = sum_l R_l (l >= 1 - weight_off).
-// The later levels of the reduction are pure latency (a few thousand points, one dependent
-// chain per launch), so trading 4x more additions for a 10x shorter chain is the point.
+// Contract of BucketLevelBitsBody (msm.hpp) for one group of K points, with the K points spread
+// over K lanes of one workgroup and combined through LDS in log2(K) dependent EC additions (a
+// lane-serial running sum needs 2*K): the later levels of the reduction are pure latency (a few
+// thousand points, one dependent chain per launch), so the chain length is what counts.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "msm.hpp"
@@ -30,38 +28,43 @@ struct LdsPoints {
 };
 
 // grid = cnt * (1 + n_old) workgroups of K lanes.
+// Weighted groups (a == 0): ONE binary tree yields S and every A_b (BucketLevelBitsBody's contract).
+// At step d lane l adds the value of lane l + 2^d iff  l mod 2^(d+1)  is 0 (the S chain) or a power
+// of two below 2^d (the tree of A_p, p = position of that bit); a lane whose lowest set bit is d is
+// read but keeps its value, which seeds A_d.  After log2(K) steps lane 0 holds S, lane 2^b holds A_b.
 template <class C>
-__global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
+__global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t lgK, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
                                                           const uint32_t* x, const uint32_t* old_in, uint32_t* out) {
   typedef XyzzD<C> Pt;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   LdsPoints<C> lds{smem, K};
   const uint32_t a = blockIdx.x / cnt, gidx = blockIdx.x % cnt, l = threadIdx.x;
   const size_t stride = (size_t)cnt * Pt::WORDS;
+  const uint32_t nw = lgK + weight_off;
   const uint32_t* src = (a == 0) ? x + ((size_t)gidx * K + l) * Pt::WORDS
                                  : old_in + ((size_t)(a - 1) * cnt * K + (size_t)gidx * K + l) * Pt::WORDS;
   Pt v = Pt::load(src);
   if (a == 0) {
-    // suffix scan: after the step with distance d, v_l = sum of X_l .. X_{l+2d-1}
-    for (uint32_t d = 1; d < K; d <<= 1) {
+    for (uint32_t d = 0; d < lgK; d++) {
       lds.put(l, v);
       __syncthreads();
-      if (l + d < K) v.add(lds.get(l + d));
+      const uint32_t low = l & ((2u << d) - 1u);
+      if ((low & (low - 1u)) == 0 && low < (1u << d)) v.add(lds.get(l + (1u << d)));
       __syncthreads();
     }
-    if (l == 0) v.store(out + (size_t)gidx * Pt::WORDS);          // S = R_0
-    if (l == 0 && weight_off == 0) v = Pt::infinity();            // weights j: R_0 is not counted
+    uint32_t* o = out + (size_t)gidx * Pt::WORDS;
+    if (l == 0) { v.store(o); if (weight_off) v.store(o + (size_t)(1 + lgK) * stride); }
+    else if ((l & (l - 1u)) == 0) { uint32_t b = 31 - __builtin_clz(l); v.store(o + (size_t)(1 + b) * stride); }
+  } else {
+    for (uint32_t d = K >> 1; d >= 1; d >>= 1) {     // plain tree sum of an older array
+      lds.put(l, v);
+      __syncthreads();
+      if (l < d) v.add(lds.get(l + d));
+      __syncthreads();
+    }
+    if (l == 0) v.store(out + (size_t)(nw + a) * stride + (size_t)gidx * Pt::WORDS);
   }
-  // tree sum of v over the K lanes
-  for (uint32_t d = K >> 1; d >= 1; d >>= 1) {
-    lds.put(l, v);
-    __syncthreads();
-    if (l < d) v.add(lds.get(l + d));
-    __syncthreads();
-  }
-  if (l == 0) v.store(out + (size_t)(1 + a) * stride + (size_t)gidx * Pt::WORDS);
 }
-
 
 // Bucket accumulation with an in-workgroup merge of the runs that chunk edges cut in two.
 // AccumulateBody::chunk leaves, per lane, a partial for its first run (bucket began in an earlier

@@ -66,11 +66,12 @@ void HipBackend::seg_reduce_tail(const MsmGeom& g, uint32_t level, uint32_t slot
 }
 
 template <class C>
-void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x,
+void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, bool bits, const uint32_t* x,
                               const uint32_t* old_in, uint32_t* out) {
-  if (K >= 16 && K <= 256) {
+  if (bits) {   // 16 <= K <= 256: one workgroup of K lanes per group
+    uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
     size_t lds = (size_t)K * XyzzD<C>::WORDS * 4;
-    hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, weight_off, cnt, n_old, x,
+    hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, lgK, weight_off, cnt, n_old, x,
                        old_in, out);
     PC_HIP_CHECK(hipGetLastError());
   } else {

@@ -41,10 +41,16 @@ struct CpuStepBackend {
     pc::seg_reduce_tail_serial<C>(*this, g, level, slots, pk, pp, cur, offsets, buckets);
   }
   template <class C>
-  void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, const uint32_t* x, const uint32_t* old_in,
+  void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, bool bits, const uint32_t* x, const uint32_t* old_in,
                     uint32_t* out) {
-    pc::BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
-    launch(b, (size_t)cnt * (1 + n_old));
+    if (bits) {
+      uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
+      pc::BucketLevelBitsBody<C> b{K, lgK, weight_off, cnt, n_old, x, old_in, out};
+      launch(b, (size_t)cnt * (1 + n_old));
+    } else {
+      pc::BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
+      launch(b, (size_t)cnt * (1 + n_old));
+    }
   }
   template <class B> void launch(const B& body, size_t lanes) {
     for (size_t i = 0; i < lanes; i++) body((uint32_t)i);

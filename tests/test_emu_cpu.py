@@ -91,8 +91,10 @@ def test_msm_pipeline_stepped(curve):
         b = O.gen_bases(curve, n)
         s = O.gen_scalars(curve, n * 7 + 1, n)
         want = O.msm_pippenger(curve, b, s, 4, 1)
+        # the last three use "bits" reduction levels (fan-in >= 16): at level 0 with weights l+1, then
+        # twice in a row (older arrays folded by a bits level), then bits followed by a serial level
         for (c, T, T2, K0) in ((0, 0, 0, 0), (4, 3, 4, 2), (5, 1, 4, 4), (7, 16, 16, 8), (8, 5, 5, 2), (2, 2, 4, 2),
-                               (11, 4, 8, 4)):
+                               (11, 4, 8, 4), (7, 0, 0, 0), (9, 5, 4, 16), (10, 0, 0, 0)):
             assert (run_msm(curve, b, s, c, T, T2, K0) == want).all(), (n, c, T, T2, K0)
 
 
