@@ -383,13 +383,28 @@ struct MsmConfig {
 
 PC_HD uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-inline uint32_t msm_choose_c(size_t n) {
+inline uint32_t msm_choose_c(size_t n, uint32_t scalar_bits = 255) {
   // window width: balances n*W mixed adds against ~2*W*2^(c-1) full adds of the reduction
   if (n < 32) return 3;
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
   uint32_t c = lg > 4 ? lg - 4 : 2;
   if (c < 4) c = 4;
   if (c > 20) c = 20;
+  if (n >= (1u << 16)) {
+    // Avoid a degenerate top window.  With W = bits/c + 1 windows the last one holds only
+    // bits - (W-1)*c scalar bits; when that is ~0-3 (c = 15, 17, 18 for 255-bit scalars) its few
+    // buckets each receive n/8 .. n/2 entries: one workgroup of the fine sort then walks a
+    // giant bin alone (measured 0.17 -> 1.3 ms at 2^20).  Take the nearest width with >= 7 top bits.
+    for (uint32_t d = 0; d <= 3; d++) {
+      const uint32_t cand[2] = {c - d, c + d};
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t cc = cand[k];
+        if (cc < 8 || cc > 20) continue;
+        const uint32_t W = scalar_bits / cc + 1, tb = scalar_bits - (W - 1) * cc;
+        if (tb >= 7) return cc;
+      }
+    }
+  }
   return c;
 }
 
@@ -519,7 +534,7 @@ class MsmPlan {
  private:
   // window width, bucket counts and the reduction-level plan for a call of n pairs
   void plan_geometry(size_t n) {
-    uint32_t c = cfg_.c ? cfg_.c : msm_choose_c(n);
+    uint32_t c = cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
     g_.c = c; g_.W = msm_num_windows(FrP::BITS, c); g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2;
     uint32_t m = g_.nb_win; n_levels_ = 0;

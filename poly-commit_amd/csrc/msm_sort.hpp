@@ -22,9 +22,10 @@ namespace pc {
 struct SortGeom {
   uint32_t n, c, W, nb_win, NB, base_off, from_mont;
   uint32_t fine_bits, cb, ncw /* coarse bins per window */, NC /* total coarse bins */, S /* scalars per block */, nblocks;
+  uint32_t top_w, top_fine_bits;   // the last window only uses 2^(tb-1) buckets: it gets its own (smaller) fine width
 };
 
-inline SortGeom make_sort_geom(const MsmGeom& g) {
+inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   SortGeom s;
   s.n = g.n; s.c = g.c; s.W = g.W; s.nb_win = g.nb_win; s.NB = g.NB; s.base_off = g.base_off; s.from_mont = g.from_mont;
   uint32_t bbits = g.c - 1;                               // bucket bits per window
@@ -32,6 +33,17 @@ inline SortGeom make_sort_geom(const MsmGeom& g) {
   uint32_t cb = bbits > 8 ? bbits - 8 : 0;
   if (cb > cb_max) cb = cb_max;
   s.cb = cb; s.fine_bits = bbits - cb; s.ncw = 1u << cb; s.NC = g.W * s.ncw;
+  // The top window holds tb = bits - (W-1)*c scalar bits, i.e. only 2^tb of its 2^(c-1) buckets are reachable.
+  // With the common fine width all of its n entries would land in one or two coarse bins (one
+  // workgroup of the fine sort walking n records alone); give it fine width (tb-1) - cb instead so
+  // that its buckets spread over up to 2^cb bins.
+  s.top_w = g.W - 1;
+  {
+    uint32_t tb = scalar_bits > (g.W - 1) * g.c ? scalar_bits - (g.W - 1) * g.c : 0;
+    uint32_t used = tb;                                    // its digits are unsigned in [0, 2^tb]: buckets 0 .. 2^tb - 1
+    s.top_fine_bits = used > cb ? used - cb : 0;
+    if (s.top_fine_bits > s.fine_bits) s.top_fine_bits = s.fine_bits;
+  }
   uint32_t nb = (g.n + 2047) / 2048; if (nb > 512) nb = 512; if (nb == 0) nb = 1;
   s.nblocks = nb; s.S = (g.n + nb - 1) / nb;
   return s;
@@ -47,7 +59,7 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
   __syncthreads();
   const uint32_t lo = blockIdx.x * sg.S;
   const uint32_t hi = (sg.n - lo > sg.S) ? lo + sg.S : sg.n;
-  const uint32_t half = 1u << (sg.c - 1), fmask = (1u << sg.fine_bits) - 1u;
+  const uint32_t half = 1u << (sg.c - 1);
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, sg.from_mont);
     uint32_t carry = 0;
@@ -56,9 +68,12 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
       if (mag) {
-        uint32_t b = mag - 1, bin = w * sg.ncw + (b >> sg.fine_bits);
+        const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
+        uint32_t b = mag - 1, cbin = b >> fb;
+        if (cbin >= sg.ncw) cbin = sg.ncw - 1;           // (top window, magnitude 2^(tb-1): one past its range)
+        uint32_t bin = w * sg.ncw + cbin;
         uint32_t pos = atomicAdd(&cnt[bin], 1u);
-        if (SCATTER) records[pos] = make_uint2((sg.base_off + i) | (carry << 31), b & fmask);
+        if (SCATTER) records[pos] = make_uint2((sg.base_off + i) | (carry << 31), b - (cbin << fb));
       }
     }
   }
@@ -84,8 +99,10 @@ __global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32_t nblo
 __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
                                                   uint32_t* offsets) {
   __shared__ uint32_t h[2048];        // [0, F): counts / cursors; [F, 2F): scan ping-pong
-  const uint32_t F = 1u << sg.fine_bits;
   const uint32_t k = blockIdx.x, start = binbase[k], end = binbase[k + 1];
+  const uint32_t w = k / sg.ncw, cbin = k % sg.ncw;
+  const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
+  const uint32_t F = 1u << fb;
   for (uint32_t f = threadIdx.x; f < F; f += 256) h[f] = 0;
   __syncthreads();
   for (uint32_t r = start + threadIdx.x; r < end; r += 256) atomicAdd(&h[records[r].y], 1u);
@@ -102,15 +119,19 @@ __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* 
     src ^= F;
   }
   // exclusive offsets -> CSR row pointers of this bin's buckets, and the placement cursors
-  const uint32_t w = k / sg.ncw, cbin = k % sg.ncw;
-  const uint32_t key0 = w * sg.nb_win + (cbin << sg.fine_bits);
+  const uint32_t key0 = w * sg.nb_win + (cbin << fb);
   uint32_t excl[8];                   // F / 256 <= 8 values per lane
   uint32_t q = 0;
   for (uint32_t f = threadIdx.x; f < F; f += 256, q++) excl[q] = start + (f ? h[src + f - 1] : 0u);
   __syncthreads();
   q = 0;
   for (uint32_t f = threadIdx.x; f < F; f += 256, q++) { h[f] = excl[q]; offsets[key0 + f] = excl[q]; }
-  if (k + 1 == sg.NC && threadIdx.x == 0) offsets[sg.NB] = end;
+  if (cbin + 1 == sg.ncw) {
+    // buckets of this window beyond the last bin's range (top window only) are empty: their row
+    // pointers equal the end of the window
+    for (uint32_t kk = key0 + F + threadIdx.x; kk < (w + 1) * sg.nb_win; kk += 256) offsets[kk] = end;
+    if (k + 1 == sg.NC && threadIdx.x == 0) offsets[sg.NB] = end;
+  }
   __syncthreads();
   for (uint32_t r = start + threadIdx.x; r < end; r += 256) {
     uint2 rec = records[r];

@@ -18,7 +18,7 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
                               uint32_t* entries) {
   if (sort_mode < 0) { const char* e = getenv("PC_HIP_SORT"); sort_mode = (e && !strcmp(e, "atomic")) ? 0 : 1; }
   if (sort_mode == 0) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }
-  SortGeom sg = make_sort_geom(g);
+  SortGeom sg = make_sort_geom(g, C::FrP::BITS);
   if (sg.fine_bits > 10) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }   // c > 22
   // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)
   const size_t gw = (size_t)sg.nblocks * sg.NC, nb1 = (size_t)sg.NC + 1;
