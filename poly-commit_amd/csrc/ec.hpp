@@ -106,4 +106,77 @@ struct XyzzD {
   }
 };
 
+
+// Jacobian coordinates (x = X/Z^2, y = Y/Z^3), a = 0: cheaper doubling (2M + 5S, dbl-2009-l) than
+// XYZZ (6M + 3S).  Used by the per-element scalar multiplications (IPA key fold, fixed-base SRS
+// generation), where doublings outnumber additions 3:1 after NAF recoding.
+template <class C>
+struct JacD {
+  typedef Fd<typename C::FqP> Fq;
+  Fq X, Y, Z;
+  static PC_HD JacD infinity() { JacD r; r.X = Fq::one(); r.Y = Fq::one(); r.Z = Fq::zero(); return r; }
+  PC_HD bool is_inf() const { return Z.is_zero(); }
+  PC_HD JacD dbl() const {
+    if (is_inf() || Y.is_zero()) return infinity();
+    Fq A = X.sqr(), B = Y.sqr(), Cc = B.sqr();
+    Fq t = X.add(B).sqr().sub(A).sub(Cc);
+    Fq D = t.dbl(), E = A.dbl().add(A), F = E.sqr();
+    JacD r;
+    r.X = F.sub(D.dbl());
+    r.Z = Y.mul(Z).dbl();
+    r.Y = E.mul(D.sub(r.X)).sub(Cc.dbl().dbl().dbl());
+    return r;
+  }
+  // this += affine (madd-2007-bl), all special cases handled
+  PC_HD void add_affine(const AffD<C>& a) {
+    if (a.is_inf()) return;
+    if (is_inf()) { X = a.x; Y = a.y; Z = Fq::one(); return; }
+    Fq Z1Z1 = Z.sqr(), U2 = a.x.mul(Z1Z1), S2 = a.y.mul(Z).mul(Z1Z1);
+    Fq H = U2.sub(X), rr = S2.sub(Y);
+    if (H.is_zero()) {
+      if (rr.is_zero()) *this = dbl(); else *this = infinity();
+      return;
+    }
+    rr = rr.dbl();
+    Fq HH = H.sqr(), I = HH.dbl().dbl(), J = H.mul(I), V = X.mul(I);
+    Fq X3 = rr.sqr().sub(J).sub(V.dbl());
+    Fq Y3 = rr.mul(V.sub(X3)).sub(Y.mul(J).dbl());
+    Z = Z.add(H).sqr().sub(Z1Z1).sub(HH);
+    X = X3; Y = Y3;
+  }
+  PC_HD AffD<C> to_affine() const {
+    if (is_inf()) return AffD<C>::infinity();
+    Fq zi = Z.inv(), zi2 = zi.sqr();
+    AffD<C> a; a.x = X.mul(zi2); a.y = Y.mul(zi2).mul(zi); return a;
+  }
+};
+
+// Non-adjacent form of a canonical scalar as two bit masks (digit +1 / -1 per position):
+// on average a third of the digits are non-zero (binary: a half).  NW = limbs of the scalar.
+template <int NW>
+struct NafMasks {
+  uint32_t pos[NW + 1], neg[NW + 1];
+  PC_HD void from_scalar(const uint32_t* k) {
+    uint32_t t[NW + 1];
+    for (int i = 0; i < NW; i++) t[i] = k[i];
+    t[NW] = 0;
+    for (int i = 0; i <= NW; i++) { pos[i] = 0; neg[i] = 0; }
+    for (int bit = 0; bit < 32 * (NW + 1); bit++) {
+      bool any = false; for (int i = 0; i <= NW; i++) any |= t[i] != 0;
+      if (!any) break;
+      if (t[0] & 1) {
+        if ((t[0] & 3) == 3) {          // digit -1: t += 1
+          neg[bit >> 5] |= 1u << (bit & 31);
+          uint64_t c = 1; for (int i = 0; i <= NW; i++) { c += t[i]; t[i] = (uint32_t)c; c >>= 32; }
+        } else {                        // digit +1: t -= 1
+          pos[bit >> 5] |= 1u << (bit & 31);
+          t[0] -= 1;
+        }
+      }
+      for (int i = 0; i < NW; i++) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+      t[NW] >>= 1;
+    }
+  }
+};
+
 }  // namespace pc

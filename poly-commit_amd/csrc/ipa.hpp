@@ -34,6 +34,18 @@ struct FrDotBody {
   }
 };
 
+// partial[t] = sum over i = t, t + stride, ... of a[i]  (second stage of fr_dot)
+template <class FrP>
+struct FrSumBody {
+  typedef Fd<FrP> F;
+  const uint32_t* a; uint32_t n; uint32_t stride; uint32_t* partial;
+  PC_HD void operator()(uint32_t t) const {
+    F acc = F::zero();
+    for (uint32_t i = t; i < n; i += stride) acc = acc.add(F::load(a + (size_t)i * FrP::N));
+    acc.store(partial + (size_t)t * FrP::N);
+  }
+};
+
 template <class FrP>
 struct FrPowTable { uint32_t w[32][FrP::N]; };   // w[k] = z^(2^k)
 
@@ -49,33 +61,40 @@ struct FrPowersBody {
   }
 };
 
+// scalar * affine point with a NAF-recoded scalar shared by all lanes (branch-uniform), Jacobian
+template <class C, int NW>
+PC_HD JacD<C> naf_mul(const NafMasks<NW>& naf, const AffD<C>& p) {
+  JacD<C> acc = JacD<C>::infinity();
+  const AffD<C> np = p.neg_if(true);
+  for (int bit = 32 * (NW + 1) - 1; bit >= 0; bit--) {
+    acc = acc.dbl();
+    const uint32_t m = 1u << (bit & 31);
+    if (naf.pos[bit >> 5] & m) acc.add_affine(p);
+    else if (naf.neg[bit >> 5] & m) acc.add_affine(np);
+  }
+  return acc;
+}
+
 template <class C>
 struct EcFoldBody {
-  typedef XyzzD<C> Pt;
   static constexpr int AW = 2 * Fd<typename C::FqP>::N;
   uint32_t* key;            // affine points; lane i updates key[i] from key[i] and key[half + i]
   uint32_t half;
-  uint32_t u[C::FrP::N];    // canonical scalar
+  NafMasks<C::FrP::N> naf;  // the round challenge u, NAF-recoded on the host
   PC_HD void operator()(uint32_t i) const {
     AffD<C> kl = AffD<C>::load(key + (size_t)i * AW), kr = AffD<C>::load(key + (size_t)(half + i) * AW);
-    Pt acc = Pt::infinity();
-    for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
-      acc = acc.dbl();
-      if ((u[bit >> 5] >> (bit & 31)) & 1) acc.add_affine(kr);
-    }
+    JacD<C> acc = naf_mul<C, C::FrP::N>(naf, kr);
     acc.add_affine(kl);
     acc.to_affine().store(key + (size_t)i * AW);
   }
 };
 
-
 // out[i] = scalars[i] * g for one fixed base g: `g.batch_mul(powers_of_beta)`, the SRS generation
-// of KZG10::setup (poly-commit/src/kzg10/mod.rs:76,83).  One lane per scalar, plain
-// double-and-add; affine output.  Used to build TRUE structured reference strings for the
-// trapdoor-checked end-to-end tests, not on the commit/open path.
+// of KZG10::setup (poly-commit/src/kzg10/mod.rs:76,83).  One lane per scalar (per-lane NAF);
+// affine output.  Used to build TRUE structured reference strings for the trapdoor-checked
+// end-to-end tests, not on the commit/open path.
 template <class C>
 struct FixedBaseMulBody {
-  typedef XyzzD<C> Pt;
   static constexpr int AW = 2 * Fd<typename C::FqP>::N;
   const uint32_t* scalars;   // n x Fr, Montgomery
   uint32_t g[AW];
@@ -83,13 +102,8 @@ struct FixedBaseMulBody {
   PC_HD void operator()(uint32_t i) const {
     typedef Fd<typename C::FrP> Fr;
     Fr k = Fr::load(scalars + (size_t)i * C::FrP::N).from_mont();
-    AffD<C> base = AffD<C>::load(g);
-    Pt acc = Pt::infinity();
-    for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
-      acc = acc.dbl();
-      if ((k.l[bit >> 5] >> (bit & 31)) & 1) acc.add_affine(base);
-    }
-    acc.to_affine().store(out + (size_t)i * AW);
+    NafMasks<C::FrP::N> naf; naf.from_scalar(k.l);
+    naf_mul<C, C::FrP::N>(naf, AffD<C>::load(g)).to_affine().store(out + (size_t)i * AW);
   }
 };
 

@@ -532,13 +532,23 @@ static void fr_fold_t(pc::HipBackend& be, uint32_t* lo, const uint32_t* hi, size
 template <class FrP>
 static void fr_dot_t(pc::HipBackend& be, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
   typedef pc::Fd<FrP> F;
-  const uint32_t lanes = n < 16384 ? (uint32_t)(n ? n : 1) : 16384;
-  uint32_t* part = (uint32_t*)be.alloc((size_t)lanes * FrP::N * 4);
-  pc::FrDotBody<FrP> body{a, b, (uint32_t)n, lanes, part};
-  be.launch(body, lanes);
-  std::vector<uint32_t> h((size_t)lanes * FrP::N);
+  // stage 1: up to 2^17 strided partial products-sums (wide); stage 2: 256 strided sums of those;
+  // the host folds the last 256 (~15 us)
+  const uint32_t wide = n < (1u << 17) ? (uint32_t)(n ? n : 1) : (1u << 17);
+  const uint32_t lanes = wide < 256 ? wide : 256;
+  static thread_local std::vector<uint32_t> h;
+  h.resize((size_t)lanes * FrP::N);
+  const size_t need = ((size_t)wide + lanes) * FrP::N * 4;
+  if (need > be.scan_tmp_bytes) {      // reuse the backend's small scratch buffer
+    if (be.scan_tmp) { be.sync(); (void)hipFree(be.scan_tmp); }
+    PC_HIP_CHECK(hipMalloc(&be.scan_tmp, need)); be.scan_tmp_bytes = need;
+  }
+  uint32_t* part1 = (uint32_t*)be.scan_tmp; uint32_t* part = part1 + (size_t)wide * FrP::N;
+  pc::FrDotBody<FrP> body{a, b, (uint32_t)n, wide, part1};
+  be.launch(body, wide);
+  pc::FrSumBody<FrP> body2{part1, wide, lanes, part};
+  be.launch(body2, lanes);
   be.copy_d2h(h.data(), part, h.size() * 4);
-  be.free(part);
   F acc = F::zero();
   for (uint32_t t = 0; t < lanes; t++) acc = acc.add(F::load(&h[(size_t)t * FrP::N]));
   acc.store(out);
@@ -555,7 +565,7 @@ template <class C>
 static void ec_fold_t(pc::HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
   pc::EcFoldBody<C> body; body.key = key; body.half = (uint32_t)half;
   pc::Fd<typename C::FrP> u = pc::Fd<typename C::FrP>::load(u_mont).from_mont();
-  for (int i = 0; i < C::FrP::N; i++) body.u[i] = u.l[i];
+  body.naf.from_scalar(u.l);
   be.launch(body, half, 64); be.sync();
 }
 }  // extern "C++"

@@ -136,7 +136,7 @@ static void ipa_bodies(uint32_t* key, size_t half, const uint32_t* u_canon, uint
                        uint32_t* dot_out, const uint32_t* z_mont, uint32_t* pow_out, size_t npow) {
   typedef typename C::FrP FrP; typedef pc::Fd<FrP> F;
   CpuStepBackend be;
-  { pc::EcFoldBody<C> b; b.key = key; b.half = (uint32_t)half; for (int i = 0; i < FrP::N; i++) b.u[i] = u_canon[i]; be.launch(b, half); }
+  { pc::EcFoldBody<C> b; b.key = key; b.half = (uint32_t)half; b.naf.from_scalar(u_canon); be.launch(b, half); }
   { uint32_t lanes = 7; std::vector<uint32_t> part(lanes * FrP::N);
     pc::FrDotBody<FrP> b{lo, hi, (uint32_t)half, lanes, part.data()}; be.launch(b, lanes);
     F acc = F::zero(); for (uint32_t t = 0; t < lanes; t++) acc = acc.add(F::load(&part[t * FrP::N])); acc.store(dot_out); }
@@ -149,5 +149,14 @@ extern "C" void emu_ipa_bodies(int curve, uint32_t* key, size_t half, const uint
     case 0: ipa_bodies<pc_curve_bls12_381>(key, half, u_canon, lo, hi, s_mont, dot_out, z_mont, pow_out, npow); break;
     case 1: ipa_bodies<pc_curve_bn254>(key, half, u_canon, lo, hi, s_mont, dot_out, z_mont, pow_out, npow); break;
     case 2: ipa_bodies<pc_curve_pallas>(key, half, u_canon, lo, hi, s_mont, dot_out, z_mont, pow_out, npow); break;
+  }
+}
+
+extern "C" void emu_fixed_base(int curve, const uint32_t* g, const uint32_t* scalars_mont, size_t n, uint32_t* out) {
+  CpuStepBackend be;
+  switch (curve) {
+    case 0: { pc::FixedBaseMulBody<pc_curve_bls12_381> b; b.scalars = scalars_mont; b.out = out; for (int i = 0; i < 24; i++) b.g[i] = g[i]; be.launch(b, n); } break;
+    case 1: { pc::FixedBaseMulBody<pc_curve_bn254> b; b.scalars = scalars_mont; b.out = out; for (int i = 0; i < 16; i++) b.g[i] = g[i]; be.launch(b, n); } break;
+    case 2: { pc::FixedBaseMulBody<pc_curve_pallas> b; b.scalars = scalars_mont; b.out = out; for (int i = 0; i < 16; i++) b.g[i] = g[i]; be.launch(b, n); } break;
   }
 }

@@ -183,3 +183,21 @@ def test_ipa_round_bodies_stepped(curve):
     assert O.fr_from_mont_array(curve, dot.reshape(1, 4))[0] == sum(a * b for a, b in zip(lo_i, hi_i)) % p
     assert O.fr_from_mont_array(curve, lo) == [(a + s_i * b) % p for a, b in zip(lo_i, hi_i)]
     assert O.fr_from_mont_array(curve, pw) == [pow(z_i, k, p) for k in range(npow)]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_naf_jacobian_scalar_mul_stepped(curve):
+    """NAF recoding + Jacobian ladder (csrc/ec.hpp JacD / NafMasks, used by ec_fold and the
+    fixed-base SRS generator) against Python big ints, including the scalars whose NAF carries
+    out of the top limb."""
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    G = R.gen_bases(curve, 3)[2]
+    ks = [0, 1, 2, 3, 7, p - 1, p - 2, (1 << 254) - 1 if p > (1 << 254) else (1 << 253) - 1, 0xAAAAAAAAAAAAAAAA, 0xFFFFFFFFFFFFFFFFFFFFFFFF] + \
+        R.gen_scalars(fr, 21, 6)
+    ks = [k % p for k in ks]
+    sc = O.fr_mont_array(curve, ks)
+    g = O.points_to_array(curve, [G])[0]
+    out = np.zeros((len(ks), 2 * O.fq_limbs(curve)), dtype=np.uint64)
+    emu().emu_fixed_base(O.CURVES[curve], p32(g.view(np.uint32)), p32(sc.view(np.uint32)), C.c_size_t(len(ks)), p32(out.view(np.uint32)))
+    assert O.array_to_points(curve, out) == [R.ec_mul(curve, k, G) for k in ks]

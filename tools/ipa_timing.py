@@ -24,8 +24,9 @@ t = time.perf_counter(); srs.msm(cdev.data_ptr(), n=n, montgomery=True); t_commi
 srs.free()
 it = iter(range(log_n))
 t = time.perf_counter()
-ipa.ipa_open_rounds(ctx, curve, key[:n], cdev, n, point, key[n], lambda L, R_: ch[next(it)])
+tm = {}
+ipa.ipa_open_rounds(ctx, curve, key[:n], cdev, n, point, key[n], lambda L, R_: ch[next(it)], timings=tm)
 t_open = time.perf_counter() - t
 print(json.dumps({"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: commit MSM + {log_n} halving rounds (challenges supplied)",
                   "commit_ms": t_commit * 1e3, "open_rounds_ms": t_open * 1e3,
-                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open}))
+                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open, "open_breakdown_ms": {k: round(v, 1) for k, v in tm.items()}}))
