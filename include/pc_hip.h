@@ -34,6 +34,8 @@ typedef enum { PC_CURVE_BLS12_381 = 0, PC_CURVE_BN254 = 1, PC_CURVE_PALLAS = 2 }
 typedef enum { PC_SCALARS_CANONICAL = 0, PC_SCALARS_MONTGOMERY = 1 } pc_scalar_form;
 typedef enum { PC_MEM_HOST = 0, PC_MEM_DEVICE = 1 } pc_mem;
 
+typedef enum { PC_HASH_SHA256 = 0, PC_HASH_BLAKE2S = 1 } pc_hash;
+
 typedef enum {
   PC_OK = 0,
   PC_ERR_INVALID_ARG = -1,
@@ -114,6 +116,16 @@ int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem wher
                      size_t in_cols, unsigned log_n, void* out, pc_mem where_out);
 /* Kernel-only milliseconds of the last pc_hip_ntt_batch: [pass A, pass B]. */
 int pc_hip_last_ntt_phases_ms(const pc_ctx* ctx, float out[2]);
+
+/* Column digests of the encoded matrix: step 2 of LinearCodePCS::commit
+ * (poly-commit/src/linear_codes/mod.rs:256-263) for the byte-digest column hasher
+ * FieldToBytesColHasher<F, D> (bench-templates/src/lib.rs:309-338):
+ *   out[j] = D( to_bytes!(column j) ),  to_bytes! = u64 LE length || 32-byte LE canonical residues,
+ * D = SHA-256 or BLAKE2s-256.  ext_mat: rows x n_cols (row-major, Montgomery) -- the output of
+ * pc_hip_ntt_batch, which therefore never has to leave HBM; out_digests: n_cols x 32 bytes.  The
+ * Merkle tree over the digests (131072 leaves at 2^24 coefficients) stays with the caller. */
+int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_mem where_in, size_t rows,
+                       size_t n_cols, pc_hash hash, void* out_digests, pc_mem where_out);
 
 /* Witness polynomial q = p / (x - z): KZG10::compute_witness_polynomial,
  * poly-commit/src/kzg10/mod.rs:217-240.  coeffs: n Fr (Montgomery); z: one Fr (Montgomery,

@@ -71,6 +71,7 @@ def load_library():
     lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
+    lib.pc_hip_column_hash.argtypes = [vp, ip, vp, ip, sz, sz, ip, vp, ip]
     lib.pc_hip_fr_fold.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_dot.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
@@ -141,6 +142,21 @@ class Context:
             out = np.zeros((rows, 1 << log_n, 4), dtype=np.uint64)
         pout, wout = _ptr(out)
         self.check(self.lib.pc_hip_ntt_batch(self.h, CURVES[curve], pin, win, rows, in_cols, log_n, pout, wout))
+        return out
+
+    def column_hash(self, curve, ext, hash_name="blake2s", out=None, rows=None, n_cols=None):
+        """Digests of the columns of the encoded matrix (rows x n_cols x Fr, Montgomery):
+        FieldToBytesColHasher<F, D>, D = 'sha256' | 'blake2s'.  Returns (n_cols, 32) uint8 for host
+        input; device buffers (raw pointers + rows/n_cols, out = device pointer) stay on the device."""
+        pin, win = _ptr(ext)
+        if rows is None:
+            rows, n_cols = ext.shape[0], ext.shape[1]
+        if out is None:
+            assert win == PC_MEM_HOST
+            out = np.zeros((n_cols, 32), dtype=np.uint8)
+        pout, wout = _ptr(out)
+        hid = {"sha256": 0, "blake2s": 1}[hash_name]
+        self.check(self.lib.pc_hip_column_hash(self.h, CURVES[curve], pin, win, rows, n_cols, hid, pout, wout))
         return out
 
     def last_ntt_phases_ms(self):

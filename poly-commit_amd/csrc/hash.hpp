@@ -1,0 +1,124 @@
+// Column hashing for the linear-code commitments (Ligero): the step right after the row
+// encoding in LinearCodePCS::commit (poly-commit/src/linear_codes/mod.rs:256-263),
+//     leaves[j] = H::evaluate(col_hash_params, ext_mat.cols()[j]),
+// for the byte-digest column hashers the reference's tests and benches use,
+// FieldToBytesColHasher<F, D> (bench-templates/src/lib.rs:309-338, D = Blake2s256 / Sha256):
+//     D::digest(to_bytes!(column))
+// where to_bytes! is ark-serialize's compressed encoding of Vec<F>: the length as u64
+// little-endian, then every element as 32 little-endian bytes of its CANONICAL residue.
+// One lane per column: consecutive lanes read consecutive columns of the same row, so the
+// row-major encoded matrix is streamed with perfectly coalesced 32-byte loads and never has to
+// be transposed or leave HBM (2 GiB at 2^24 coefficients -> 4 MiB of digests).
+// SHA-256 (FIPS 180-4) and BLAKE2s-256 (RFC 7693) are written as word-streaming states:
+// every input item is a multiple of 4 bytes and 4-byte aligned in the message.
+#pragma once
+#include "fp32.hpp"
+#include "hash_constants.h"
+
+namespace pc {
+
+PC_HD uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+PC_HD uint32_t bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
+
+struct Sha256 {
+  uint32_t h[8], buf[16], nbuf; uint64_t bytes;
+  PC_HD void init() { PC_UNROLL for (int i = 0; i < 8; i++) h[i] = pc_hash_constants::IV[i]; nbuf = 0; bytes = 0; }
+  PC_HD void compress() {
+    uint32_t w[16], s[8];
+    PC_UNROLL for (int i = 0; i < 16; i++) w[i] = buf[i];
+    PC_UNROLL for (int i = 0; i < 8; i++) s[i] = h[i];
+    PC_UNROLL for (int t = 0; t < 64; t++) {
+      if (t >= 16) {
+        uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+        uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+        uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+        w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+      }
+      uint32_t S1 = rotr32(s[4], 6) ^ rotr32(s[4], 11) ^ rotr32(s[4], 25);
+      uint32_t ch = (s[4] & s[5]) ^ (~s[4] & s[6]);
+      uint32_t t1 = s[7] + S1 + ch + pc_hash_constants::K[t] + w[t & 15];
+      uint32_t S0 = rotr32(s[0], 2) ^ rotr32(s[0], 13) ^ rotr32(s[0], 22);
+      uint32_t maj = (s[0] & s[1]) ^ (s[0] & s[2]) ^ (s[1] & s[2]);
+      uint32_t t2 = S0 + maj;
+      s[7] = s[6]; s[6] = s[5]; s[5] = s[4]; s[4] = s[3] + t1; s[3] = s[2]; s[2] = s[1]; s[1] = s[0]; s[0] = t1 + t2;
+    }
+    PC_UNROLL for (int i = 0; i < 8; i++) h[i] += s[i];
+    nbuf = 0;
+  }
+  // four message bytes, first byte in the low 8 bits
+  PC_HD void push_le32(uint32_t w) { buf[nbuf++] = bswap32(w); bytes += 4; if (nbuf == 16) compress(); }
+  // digest as 8 words whose little-endian memory image is the 32 digest bytes
+  PC_HD void finish(uint32_t* out) {
+    const uint64_t bits = bytes * 8;
+    buf[nbuf++] = 0x80000000u; if (nbuf == 16) compress();
+    while (nbuf != 14) { buf[nbuf++] = 0; if (nbuf == 16) compress(); }
+    buf[14] = (uint32_t)(bits >> 32); buf[15] = (uint32_t)bits; nbuf = 16; compress();
+    PC_UNROLL for (int i = 0; i < 8; i++) out[i] = bswap32(h[i]);
+  }
+};
+
+struct Blake2s256 {
+  uint32_t h[8], buf[16], nbuf; uint64_t t;
+  PC_HD void init() {
+    PC_UNROLL for (int i = 0; i < 8; i++) h[i] = pc_hash_constants::IV[i];
+    h[0] ^= 0x01010020u;   // digest length 32, no key, fanout 1, depth 1
+    nbuf = 0; t = 0;
+  }
+  PC_HD void compress(bool last) {
+    uint32_t v[16], m[16];
+    PC_UNROLL for (int i = 0; i < 16; i++) m[i] = buf[i];
+    PC_UNROLL for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = pc_hash_constants::IV[i]; }
+    v[12] ^= (uint32_t)t; v[13] ^= (uint32_t)(t >> 32);
+    if (last) v[14] = ~v[14];
+#define PC_B2S_G(a, b, c, d, x, y)                                                   \
+    v[a] = v[a] + v[b] + (x); v[d] = rotr32(v[d] ^ v[a], 16); v[c] = v[c] + v[d];  \
+    v[b] = rotr32(v[b] ^ v[c], 12); v[a] = v[a] + v[b] + (y);                       \
+    v[d] = rotr32(v[d] ^ v[a], 8); v[c] = v[c] + v[d]; v[b] = rotr32(v[b] ^ v[c], 7);
+    PC_UNROLL for (int r = 0; r < 10; r++) {
+      const uint8_t* sg = pc_hash_constants::SIGMA[r];
+      PC_B2S_G(0, 4, 8, 12, m[sg[0]], m[sg[1]])
+      PC_B2S_G(1, 5, 9, 13, m[sg[2]], m[sg[3]])
+      PC_B2S_G(2, 6, 10, 14, m[sg[4]], m[sg[5]])
+      PC_B2S_G(3, 7, 11, 15, m[sg[6]], m[sg[7]])
+      PC_B2S_G(0, 5, 10, 15, m[sg[8]], m[sg[9]])
+      PC_B2S_G(1, 6, 11, 12, m[sg[10]], m[sg[11]])
+      PC_B2S_G(2, 7, 8, 13, m[sg[12]], m[sg[13]])
+      PC_B2S_G(3, 4, 9, 14, m[sg[14]], m[sg[15]])
+    }
+#undef PC_B2S_G
+    PC_UNROLL for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+  }
+  PC_HD void push_le32(uint32_t w) {
+    if (nbuf == 16) { t += 64; compress(false); nbuf = 0; }   // a full buffer is only compressed once more input arrives
+    buf[nbuf++] = w;
+  }
+  PC_HD void finish(uint32_t* out) {
+    t += 4ull * nbuf;
+    while (nbuf < 16) buf[nbuf++] = 0;
+    compress(true);
+    PC_UNROLL for (int i = 0; i < 8; i++) out[i] = h[i];
+  }
+};
+
+enum : uint32_t { PC_HASH_SHA256_ID = 0, PC_HASH_BLAKE2S_ID = 1 };
+
+// digest[j] = D(len_u64_le || canonical_le(ext[0][j]) || ... || canonical_le(ext[rows-1][j]))
+template <class FrP, class D>
+struct ColumnHashBody {
+  typedef Fd<FrP> F;
+  const uint32_t* ext;   // rows x n_cols elements, row-major, Montgomery
+  uint32_t rows, n_cols;
+  uint32_t* out;         // n_cols x 8 words
+  PC_HD void operator()(uint32_t j) const {
+    D d; d.init();
+    d.push_le32(rows); d.push_le32(0);                       // Vec length as u64 LE
+    for (uint32_t r = 0; r < rows; r++) {
+      F v = F::load(ext + ((size_t)r * n_cols + j) * FrP::N).from_mont();
+      PC_UNROLL for (int k = 0; k < FrP::N; k++) d.push_le32(v.l[k]);
+    }
+    uint32_t dig[8]; d.finish(dig);
+    PC_UNROLL for (int k = 0; k < 8; k++) out[(size_t)j * 8 + k] = dig[k];
+  }
+};
+
+}  // namespace pc

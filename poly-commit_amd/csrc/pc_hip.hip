@@ -83,6 +83,7 @@ void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uin
 #include "ntt.hpp"
 #include "poly.hpp"
 #include "ipa.hpp"
+#include "hash.hpp"
 #include <map>
 #include <memory>
 
@@ -499,6 +500,35 @@ int pc_hip_points_sum(pc_curve curve, const void* points_xy, size_t count, void*
     default: points_sum_t<pc_curve_pallas>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
   }
   return PC_OK;
+}
+
+int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_mem where_in, size_t rows, size_t n_cols,
+                       pc_hash hash, void* out_digests, pc_mem where_out) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || ((int)hash != PC_HASH_SHA256 && (int)hash != PC_HASH_BLAKE2S) ||
+      (rows && n_cols && (!ext_mat || !out_digests))) return PC_ERR_INVALID_ARG;
+  if (rows >= (1ull << 32) || n_cols >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (!n_cols) return (int)PC_OK;
+    Staged sin(ctx->be, ext_mat, where_in, rows * n_cols * 32, true);
+    Staged sout(ctx->be, out_digests, where_out, n_cols * 32, false);
+    const uint32_t* e = (const uint32_t*)sin.dev; uint32_t* o = (uint32_t*)sout.dev;
+    ctx->be.n_ev = 0; ctx->be.mark();
+#define PC_COLHASH(FrP)                                                                                              \
+    if (hash == PC_HASH_SHA256) { pc::ColumnHashBody<FrP, pc::Sha256> b{e, (uint32_t)rows, (uint32_t)n_cols, o}; ctx->be.launch(b, n_cols, 64); } \
+    else { pc::ColumnHashBody<FrP, pc::Blake2s256> b{e, (uint32_t)rows, (uint32_t)n_cols, o}; ctx->be.launch(b, n_cols, 64); }
+    switch (field_of) {
+      case PC_CURVE_BLS12_381: PC_COLHASH(pc_bls12_381_fr) break;
+      case PC_CURVE_BN254: PC_COLHASH(pc_bn254_fr) break;
+      default: PC_COLHASH(pc_pallas_fr) break;
+    }
+#undef PC_COLHASH
+    ctx->be.mark();
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out_digests, sout.dev, n_cols * 32); else ctx->be.sync();
+    ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
+    if (ctx->be.timing && ctx->be.n_ev >= 2) (void)hipEventElapsedTime(&ctx->ntt_phases[0], ctx->be.ev[0], ctx->be.ev[1]);
+    return (int)PC_OK;
+  });
 }
 
 int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,

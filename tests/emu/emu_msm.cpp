@@ -9,6 +9,7 @@
 #include "../../poly-commit_amd/csrc/msm.hpp"
 #include "../../poly-commit_amd/csrc/poly.hpp"
 #include "../../poly-commit_amd/csrc/ipa.hpp"
+#include "../../poly-commit_amd/csrc/hash.hpp"
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
@@ -158,5 +159,19 @@ extern "C" void emu_fixed_base(int curve, const uint32_t* g, const uint32_t* sca
     case 0: { pc::FixedBaseMulBody<pc_curve_bls12_381> b; b.scalars = scalars_mont; b.out = out; for (int i = 0; i < 24; i++) b.g[i] = g[i]; be.launch(b, n); } break;
     case 1: { pc::FixedBaseMulBody<pc_curve_bn254> b; b.scalars = scalars_mont; b.out = out; for (int i = 0; i < 16; i++) b.g[i] = g[i]; be.launch(b, n); } break;
     case 2: { pc::FixedBaseMulBody<pc_curve_pallas> b; b.scalars = scalars_mont; b.out = out; for (int i = 0; i < 16; i++) b.g[i] = g[i]; be.launch(b, n); } break;
+  }
+}
+
+template <class FrP>
+static void colhash(const uint32_t* ext, uint32_t rows, uint32_t n_cols, int hash_id, uint32_t* out) {
+  CpuStepBackend be;
+  if (hash_id == 0) { pc::ColumnHashBody<FrP, pc::Sha256> b{ext, rows, n_cols, out}; be.launch(b, n_cols); }
+  else { pc::ColumnHashBody<FrP, pc::Blake2s256> b{ext, rows, n_cols, out}; be.launch(b, n_cols); }
+}
+extern "C" void emu_column_hash(int curve, const uint32_t* ext, uint32_t rows, uint32_t n_cols, int hash_id, uint32_t* out) {
+  switch (curve) {
+    case 0: colhash<pc_bls12_381_fr>(ext, rows, n_cols, hash_id, out); break;
+    case 1: colhash<pc_bn254_fr>(ext, rows, n_cols, hash_id, out); break;
+    case 2: colhash<pc_pallas_fr>(ext, rows, n_cols, hash_id, out); break;
   }
 }

@@ -201,3 +201,30 @@ def test_naf_jacobian_scalar_mul_stepped(curve):
     out = np.zeros((len(ks), 2 * O.fq_limbs(curve)), dtype=np.uint64)
     emu().emu_fixed_base(O.CURVES[curve], p32(g.view(np.uint32)), p32(sc.view(np.uint32)), C.c_size_t(len(ks)), p32(out.view(np.uint32)))
     assert O.array_to_points(curve, out) == [R.ec_mul(curve, k, G) for k in ks]
+
+
+def _column_digests_hashlib(curve, ext_mont, hash_name):
+    """FieldToBytesColHasher<F, D> (bench-templates/src/lib.rs:309-338) with Python's hashlib:
+    D(u64_le(len) || 32-byte LE canonical residues of the column)."""
+    import hashlib
+    rows, n_cols = ext_mont.shape[0], ext_mont.shape[1]
+    canon = O.f_from_mont(curve, 1, np.ascontiguousarray(ext_mont.reshape(-1, 4))).reshape(rows, n_cols, 4)
+    out = []
+    for j in range(n_cols):
+        h = hashlib.new(hash_name)
+        h.update(rows.to_bytes(8, "little"))
+        h.update(np.ascontiguousarray(canon[:, j, :]).tobytes())      # little-endian u64 limbs = LE bytes
+        out.append(h.digest())
+    return out
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("rows", [1, 2, 3, 7, 8, 64])
+def test_column_hash_stepped_vs_hashlib(curve, rows):
+    n_cols = 5
+    ext = O.f_to_mont(curve, 1, O.gen_scalars(curve, 300 + rows, rows * n_cols)).reshape(rows, n_cols, 4)
+    for hid, name in ((0, "sha256"), (1, "blake2s")):
+        out = np.zeros((n_cols, 8), dtype=np.uint32)
+        emu().emu_column_hash(O.CURVES[curve], p32(np.ascontiguousarray(ext).view(np.uint32)), rows, n_cols, hid, p32(out))
+        want = _column_digests_hashlib(curve, ext, name)
+        assert [out[j].tobytes() for j in range(n_cols)] == want, (curve, rows, name)

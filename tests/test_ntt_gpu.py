@@ -78,3 +78,45 @@ def test_ntt_2_17_linearity_and_dc(ctx):
     assert va[0] == sum(ai) % fr
     want = O.ntt_batch(curve, mat[:1], lg)
     assert (got[0] == want[0]).all()
+
+
+def _hashlib_columns(curve, ext_mont, name):
+    import hashlib
+    rows, n_cols = ext_mont.shape[0], ext_mont.shape[1]
+    canon = O.f_from_mont(curve, 1, np.ascontiguousarray(ext_mont.reshape(-1, 4))).reshape(rows, n_cols, 4)
+    out = np.zeros((n_cols, 32), dtype=np.uint8)
+    for j in range(n_cols):
+        h = hashlib.new(name)
+        h.update(rows.to_bytes(8, "little"))
+        h.update(np.ascontiguousarray(canon[:, j, :]).tobytes())
+        out[j] = np.frombuffer(h.digest(), dtype=np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("name", ["sha256", "blake2s"])
+def test_column_hash_vs_hashlib(ctx, curve, name):
+    """linear_codes/mod.rs:256-263 with FieldToBytesColHasher (bench-templates/src/lib.rs:309-338):
+    the GPU digests equal Python hashlib's over the ark-serialize bytes of every column."""
+    for rows, n_cols in ((1, 3), (8, 64), (33, 200)):
+        ext = O.f_to_mont(curve, 1, O.gen_scalars(curve, rows * 1000 + n_cols, rows * n_cols)).reshape(rows, n_cols, 4)
+        got = ctx.column_hash(curve, np.ascontiguousarray(ext), name)
+        assert (got == _hashlib_columns(curve, ext, name)).all(), (rows, n_cols)
+
+
+def test_ligero_commit_device_resident_encode_then_hash(ctx):
+    """compute_matrices + column hashing chained on the device (the encoded matrix never visits the
+    host): 2^16 coefficients -> 32 x 2048 -> 32 NTTs of 2^13 -> 8192 Blake2s leaves."""
+    import torch
+    curve = "bls12_381"
+    n_rows, n_cols, _ = O.ligero_dims(255, 1 << 16)
+    assert (n_rows, n_cols) == (32, 2048)
+    co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0500, n_rows * n_cols))
+    x = torch.from_numpy(co.view(np.int64)).cuda()
+    ext = torch.empty((n_rows * 8192, 4), dtype=torch.int64, device="cuda")
+    leaves = torch.empty((8192, 32), dtype=torch.uint8, device="cuda")
+    ctx.ntt_batch(curve, x.data_ptr(), 13, out=ext.data_ptr(), rows=n_rows, in_cols=n_cols)
+    ctx.column_hash(curve, ext.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=n_rows, n_cols=8192)
+    want_ext = O.ntt_batch(curve, co.reshape(n_rows, n_cols, 4), 13)
+    want = _hashlib_columns(curve, want_ext[:, :64], "blake2s")
+    assert (leaves[:64].cpu().numpy() == want).all()
