@@ -84,6 +84,7 @@ void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uin
 #include "poly.hpp"
 #include "ipa.hpp"
 #include "hash.hpp"
+#include "glv.hpp"
 #include <map>
 #include <memory>
 
@@ -593,9 +594,13 @@ static void fr_powers_t(pc::HipBackend& be, const uint32_t* z, size_t n, uint32_
 }
 template <class C>
 static void ec_fold_t(pc::HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
-  pc::EcFoldBody<C> body; body.key = key; body.half = (uint32_t)half;
+  typedef typename pc::GlvOf<C>::T G;
   pc::Fd<typename C::FrP> u = pc::Fd<typename C::FrP>::load(u_mont).from_mont();
-  body.naf.from_scalar(u.l);
+  uint64_t k[4]; memcpy(k, u.l, 32);
+  pc::GlvSplit sp = pc::glv_decompose<G>(k);
+  pc::EcFoldGlvBody<C> body; body.key = key; body.half = (uint32_t)half;
+  body.n1.from_scalar(sp.k1); body.n2.from_scalar(sp.k2); body.neg1 = sp.neg1; body.neg2 = sp.neg2;
+  for (int i = 0; i < C::FqP::N; i++) body.beta[i] = G::BETA_MONT[i];
   be.launch(body, half, 64); be.sync();
 }
 }  // extern "C++"

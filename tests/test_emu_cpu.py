@@ -228,3 +228,26 @@ def test_column_hash_stepped_vs_hashlib(curve, rows):
         emu().emu_column_hash(O.CURVES[curve], p32(np.ascontiguousarray(ext).view(np.uint32)), rows, n_cols, hid, p32(out))
         want = _column_digests_hashlib(curve, ext, name)
         assert [out[j].tobytes() for j in range(n_cols)] == want, (curve, rows, name)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_glv_split_and_fold_stepped(curve):
+    """GLV: k = (+-k1) + (+-k2)*lambda mod r with short k1, k2 (csrc/glv.hpp glv_decompose), and the
+    Shamir/NAF ladder of the IPA key fold (EcFoldGlvBody) against Python big ints."""
+    fr = R.CURVES[curve]["fr"]
+    r = R.FIELDS[fr]["p"]
+    lam = np.zeros(4, dtype=np.uint64)
+    emu().emu_glv_lambda(O.CURVES[curve], O.p64(lam))
+    lam = O.limbs_to_ints(lam.reshape(1, 4))[0]
+    assert (lam * lam + lam + 1) % r == 0
+    half = 3
+    pts = R.gen_bases(curve, 2 * half)
+    for k in [0, 1, 2, r - 1, r - 2, lam, (lam + 1) % r, (1 << 200) + 12345] + R.gen_scalars(fr, 31, 8):
+        key = O.points_to_array(curve, pts)
+        split = np.zeros(12, dtype=np.uint32)
+        kc = O.ints_to_limbs([k], 4)[0]
+        emu().emu_glv_fold(O.CURVES[curve], p32(key.view(np.uint32)), C.c_size_t(half), O.p64(kc), p32(split))
+        k1 = sum(int(split[i]) << (32 * i) for i in range(5)) * (-1 if split[10] else 1)
+        k2 = sum(int(split[5 + i]) << (32 * i) for i in range(5)) * (-1 if split[11] else 1)
+        assert (k1 + k2 * lam - k) % r == 0 and abs(k1).bit_length() <= 130 and abs(k2).bit_length() <= 130
+        assert O.array_to_points(curve, key[:half]) == [R.ec_add(curve, pts[i], R.ec_mul(curve, k, pts[half + i])) for i in range(half)]
