@@ -6,23 +6,30 @@
 // result after into_affine() whatever the internal schedule.
 //
 // Pipeline (all on one HIP stream, no host round trip until the final download):
-//   1. digits+histogram  one thread per scalar: (optional Montgomery->canonical), signed
-//                        radix-2^c digits, one histogram atomic per non-zero digit
-//   2. exclusive scan    bucket offsets (CSR row pointers)
-//   3. scatter           digits recomputed (cheaper than storing W*n keys), entry =
-//                        base index | sign<<31 written at an atomically claimed slot
+//   1-3. bucket sort     signed radix-2^c digits of every scalar (optional Montgomery->canonical
+//                        fused) -> entries (base index | sign<<31) grouped by (window, bucket) plus
+//                        CSR offsets.  HIP: two-level LDS radix sort (msm_sort.hpp).  Reference
+//                        version kept below (histogram atomics / scan / cursor scatter): it is what
+//                        the CPU stepping tests run and what PC_HIP_SORT=atomic selects.
 //   4. accumulate        the flat, bucket-sorted entry array is cut into equal chunks of T
 //                        entries, one chunk per lane: every lane executes exactly T mixed
 //                        additions (no load imbalance whatever the scalar distribution).
 //                        Runs that lie wholly inside a chunk are written to their bucket;
-//                        the (at most two) runs cut by a chunk edge go to a partial list.
+//                        the (at most two) runs cut by a chunk edge go to a partial list --
+//                        on HIP after neighbouring lanes merged the two halves of a cut run
+//                        (k_accumulate, msm_coop.hpp), which finishes almost every bucket.
 //   5. seg-reduce        the partial list (sorted by bucket by construction) is reduced
 //                        level by level with the same chunk rule until every bucket is whole
-//   6. bucket reduce     sum_j (j+1) B_j per window by grouped running sums, recursively:
-//                        Red(X) = sum(Tw) + K * Red(S);  plain sums ride along as a fan-in-K
-//                        tree; leaves one point per (window, level)
-//   7. host tail         <= W*levels points are downloaded and folded with Horner
-//                        (255 dependent doublings: one CPU core beats one GPU lane 40x here)
+//   6. bucket reduce     sum_j (j+1) B_j per window, recursively Red(X) = sum(Tw) + K * Red(S):
+//                        wide levels by lane-serial running sums (fan-in 4), small levels as
+//                        workgroup-cooperative "bits" levels (fan-in up to 256 in log2 K dependent
+//                        additions); older partial sums ride along as plain fan-in-K trees
+//   7. host tail         the last level's <= W * (#arrays) points are downloaded (pinned, async) and
+//                        folded by one descending Horner chain (255 dependent doublings: one CPU
+//                        core beats one GPU lane 40x here) + one inversion to affine
+// The window width c is chosen per call from the call's n (plan_geometry); a plan is sized for
+// every n <= n_max.  enqueue() queues one MSM, finish() waits for it: several plans (pipelines)
+// per SRS overlap the latency-bound steps 5-7 of one MSM with step 4 of the next.
 //
 // The kernel bodies are functors templated on nothing but the curve; the orchestration is a
 // template over a Backend that provides launch/alloc/scan.  The product instantiates it
