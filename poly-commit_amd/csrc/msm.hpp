@@ -39,6 +39,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <algorithm>
+#include <stdexcept>
 #include <vector>
 #include "ec.hpp"
 #include "host_tail.hpp"
@@ -447,8 +448,15 @@ class MsmPlan {
     buckets_ = (uint32_t*)be_.alloc(NBmax * Pt::WORDS * 4);
     scalars_ = (uint32_t*)be_.alloc((n_max ? n_max : 1) * (size_t)FrP::N * 4);
     // partial levels
+    // chunk length is max(16, M / target_lanes) per call (or the fixed cfg.T): at most this many lanes
     size_t lanes0 = ceil_div_u32(Mmax, min_T_);
+    if (!cfg_.T) {
+      // T = clamp(floor(M / target_lanes), 16, 4096)  =>  lanes = ceil(M / T) <= max(17/16 target_lanes + 2, M / 4096 + 1)
+      size_t bound = std::max<size_t>((size_t)cfg_.target_lanes * 17 / 16 + 2, Mmax / 4096 + 1);
+      if (lanes0 > bound) lanes0 = bound;
+    }
     size_t slots = 2 * lanes0;
+    part_slots_ = slots;
     for (int i = 0; i < 2; i++) {
       pk_[i] = (uint32_t*)be_.alloc(slots * 4);
       pp_[i] = (uint32_t*)be_.alloc(slots * (size_t)Pt::WORDS * 4);
@@ -494,6 +502,7 @@ class MsmPlan {
     be_.template sort_entries<C>(g, scalars_dev, hist_, offsets_, cursor_, entries_);
 
     size_t lanes = ceil_div_u32(Mmax, T);
+    if (2 * lanes > part_slots_) throw std::runtime_error("MsmPlan: partial list undersized");
     { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
     be_.mark();   // 4: accumulate
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
@@ -588,6 +597,7 @@ class MsmPlan {
   size_t n_max_;
   MsmGeom g_;
   uint32_t min_T_;
+  size_t part_slots_ = 0;
   uint32_t *hist_, *offsets_, *cursor_, *entries_, *buckets_, *scalars_, *red_;
   uint32_t* pk_[2]; uint32_t* pp_[2];
   uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32]; uint32_t lvl_bits_[32]; uint32_t lvl_narr_[32];
