@@ -441,6 +441,8 @@ class MsmPlan {
       res_max = std::max<size_t>(res_max, (size_t)g_.W * (n_levels_ ? lvl_narr_[n_levels_ - 1] : 1));
       if (n >= n_max) break;
     }
+    hist_ = offsets_ = cursor_ = entries_ = buckets_ = scalars_ = red_ = nullptr; pk_[0] = pk_[1] = pp_[0] = pp_[1] = nullptr;
+    try {
     hist_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
     offsets_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
     cursor_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
@@ -464,12 +466,16 @@ class MsmPlan {
     }
     red_ = (uint32_t*)be_.alloc(red_max * (size_t)Pt::WORDS * 4);
     result_host_ = (uint32_t*)be_.alloc_host(res_max * Pt::WORDS * 4);
+    } catch (...) { release(); throw; }   // a failed hipMalloc must not leak the earlier buffers
     plan_geometry(n_max);
   }
-  ~MsmPlan() {
+  ~MsmPlan() { release(); }
+  void release() {
     void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_};
     for (void* p : ps) be_.free(p);
     be_.free_host(result_host_);
+    hist_ = offsets_ = cursor_ = entries_ = buckets_ = scalars_ = red_ = nullptr; pk_[0] = pk_[1] = pp_[0] = pp_[1] = nullptr;
+    result_host_ = nullptr;
   }
 
   const MsmGeom& geom() const { return g_; }

@@ -14,13 +14,13 @@
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
-  void free(void* p) { ::free(p); }
+  void free(void* p) { if (p) ::free(p); }
   void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
   void mark() {}
   void record_done() {}
   void wait_done() {}
   void* alloc_host(size_t b) { return calloc(1, b ? b : 1); }
-  void free_host(void* p) { ::free(p); }
+  void free_host(void* p) { if (p) ::free(p); }
   void copy_d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
   void sync() {}
   void copy_d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); }
