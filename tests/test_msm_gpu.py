@@ -217,3 +217,35 @@ def test_msm_2_22_known_answer_and_parity(ctx):
     s = O.gen_scalars(curve, 77, n)
     assert (srs.msm(s)[0] == O.msm_pippenger(curve, bases, s, 64, 1)).all()
     srs.free()
+
+
+def test_rust_affine_layout_and_threads(ctx):
+    """(i) SRS handed over in arkworks' in-memory Affine layout {x, y, infinity: bool} (104-byte stride for
+    BLS12-381), infinity flag honoured; (ii) one ctx shared by several host threads (the reference calls
+    the MSM from rayon workers, hyrax/mod.rs:233-242): calls are serialised, results unaffected."""
+    import ctypes as C
+    import threading
+    curve = "bls12_381"
+    n = 3000
+    packed = O.gen_bases(curve, n)
+    rust = np.zeros((n, 13), dtype=np.uint64)          # 104 bytes: x(48) y(48) flag(1) + padding
+    rust[:, :12] = packed
+    rust[5, :12] = 0xDEADBEEF                          # garbage coordinates, but flagged as the identity
+    rust[5, 12] = 1
+    want_bases = packed.copy()
+    want_bases[5] = 0
+    srs = ctx.upload_srs(curve, rust, n=n, stride_bytes=104)
+    scal = [O.gen_scalars(curve, 900 + k, n) for k in range(6)]
+    want = [O.msm_pippenger(curve, want_bases, s, 8, 1) for s in scal]
+    got = [None] * len(scal)
+
+    def work(k):
+        got[k] = srs.msm(scal[k])[0]
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(scal))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(len(scal)):
+        assert (got[k] == want[k]).all()
+    srs.free()
