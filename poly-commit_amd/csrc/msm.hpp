@@ -63,7 +63,8 @@ struct MsmGeom {
   uint32_t base_off;   // offset of this call's first base inside the resident SRS
   uint32_t from_mont;  // scalars arrive as Montgomery residues
   uint32_t T;          // level-0 chunk length
-  uint32_t T2;         // level>=1 chunk length
+  uint32_t T2;         // chunk length of seg-reduce level 1
+  uint32_t T2b;        // chunk length of the deeper (sparser) seg-reduce levels
 };
 
 PC_HD uint32_t msm_num_windows(uint32_t bits, uint32_t c) { return bits / c + 1; }
@@ -147,11 +148,11 @@ PC_HD uint32_t find_bucket(const uint32_t* offs, uint32_t nb, uint32_t v) {
 
 // Slot range [lo, hi] that the partials of bucket `key` occupy at reduction level `level`
 // (level 1 = output of the accumulate kernel).  See the header comment, step 5.
-PC_HD void partial_slot_range(const uint32_t* offs, uint32_t key, uint32_t T, uint32_t T2, uint32_t level,
+PC_HD void partial_slot_range(const uint32_t* offs, uint32_t key, uint32_t T, uint32_t T2, uint32_t T2b, uint32_t level,
                               uint32_t& lo, uint32_t& hi) {
   lo = 2 * (offs[key] / T);
   hi = 2 * ((offs[key + 1] - 1) / T);
-  for (uint32_t l = 2; l <= level; l++) { lo = 2 * (lo / T2); hi = 2 * (hi / T2); }
+  for (uint32_t l = 2; l <= level; l++) { const uint32_t d = (l == 2) ? T2 : T2b; lo = 2 * (lo / d); hi = 2 * (hi / d); }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -228,15 +229,16 @@ struct SegReduceBody {
   uint32_t* buckets;
   uint32_t* out_keys; uint32_t* out_pts;   // 2 slots per lane
   PC_HD void flush(const Pt& acc, uint32_t key, uint32_t cs, uint32_t ce, uint32_t u, bool first, uint32_t& k0, uint32_t& k1) const {
-    uint32_t lo, hi; partial_slot_range(offsets, key, g.T, g.T2, level, lo, hi);
+    uint32_t lo, hi; partial_slot_range(offsets, key, g.T, g.T2, g.T2b, level, lo, hi);
     if (lo >= cs && hi < ce) { acc.store(buckets + (size_t)key * Pt::WORDS); return; }
     uint32_t slot = first ? 2 * u : 2 * u + 1;
     acc.store(out_pts + (size_t)slot * Pt::WORDS);
     if (first) k0 = key; else k1 = key;
   }
   PC_HD void operator()(uint32_t u) const {
-    const uint32_t cs = u * g.T2;
-    const uint32_t ce = (n_in - cs > g.T2) ? cs + g.T2 : n_in;
+    const uint32_t T2l = level == 1 ? g.T2 : g.T2b;
+    const uint32_t cs = u * T2l;
+    const uint32_t ce = (n_in - cs > T2l) ? cs + T2l : n_in;
     uint32_t k0 = KEY_INVALID, k1 = KEY_INVALID;
     uint32_t cur = KEY_INVALID; bool first = true;
     Pt acc = Pt::infinity();
@@ -352,7 +354,8 @@ template <class C, class Backend>
 void seg_reduce_tail_serial(Backend& be, const MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp,
                             int cur, const uint32_t* offsets, uint32_t* buckets) {
   for (;;) {
-    uint32_t lanes2 = (slots + g.T2 - 1) / g.T2;
+    const uint32_t T2l = level == 1 ? g.T2 : g.T2b;
+    uint32_t lanes2 = (slots + T2l - 1) / T2l;
     SegReduceBody<C> b{g, level, slots, pk[cur], pp[cur], offsets, buckets, pk[cur ^ 1], pp[cur ^ 1]};
     be.launch(b, lanes2);
     if (lanes2 == 1) break;
@@ -381,7 +384,8 @@ void sort_entries_atomic(Backend& be, const MsmGeom& g, const uint32_t* scalars_
 struct MsmConfig {
   uint32_t c = 0;            // 0 = choose from n
   uint32_t T = 0;            // 0 = choose from n*W
-  uint32_t T2 = 8;
+  uint32_t T2 = 4;           // seg-reduce level 1 chunk: short chains beat fewer launches (measured 4 < 8 < 64)
+  uint32_t T2b = 4;          // deeper levels
   uint32_t K0 = 4;           // bucket-reduce group size, level 0 (wide: keep the chain short)
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
@@ -425,6 +429,7 @@ class MsmPlan {
 
   MsmPlan(Backend& be, size_t n_max, const MsmConfig& cfg) : be_(be), cfg_(cfg), n_max_(n_max) {
     if (cfg_.T2 < 4) cfg_.T2 = 4;       // each level must shrink the list: 2*ceil(s/T2) < s
+    if (cfg_.T2b < 4) cfg_.T2b = 4;
     if (cfg_.K0 < 2) cfg_.K0 = 2;
     if (cfg_.K1 < 2) cfg_.K1 = 2;
     min_T_ = cfg_.T ? cfg_.T : 16;
@@ -501,7 +506,7 @@ class MsmPlan {
     uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / cfg_.target_lanes);
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
-    g.T = T; g.T2 = cfg_.T2;
+    g.T = T; g.T2 = cfg_.T2; g.T2b = cfg_.T2b;
 
     be_.memset(buckets_, 0, (size_t)g.NB * Pt::WORDS * 4);
     // steps 1-3: entries grouped by bucket + CSR offsets (backend chooses the sort)
@@ -513,7 +518,7 @@ class MsmPlan {
     be_.mark();   // 4: accumulate
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
-      size_t lanes2 = ceil_div_u32(slots, g.T2);
+      size_t lanes2 = ceil_div_u32(slots, level == 1 ? g.T2 : g.T2b);
       if (lanes2 <= (cfg_.seg_tail_lanes ? cfg_.seg_tail_lanes : 1u)) {   // lanes2 == 1 always ends the walk
         // the remaining levels are tiny: one workgroup walks them all in a single launch
         be_.template seg_reduce_tail<C>(g, level, (uint32_t)slots, pk_, pp_, cur, offsets_, buckets_);
@@ -558,7 +563,7 @@ class MsmPlan {
   void plan_geometry(size_t n) {
     uint32_t c = cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
     g_.c = c; g_.W = msm_num_windows(FrP::BITS, c); g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
-    g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2;
+    g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b;
     uint32_t m = g_.nb_win; n_levels_ = 0;
     uint32_t kbits = 0; arr_exp_.clear();
     while (m > 1) {

@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(256) k_seg_reduce_tail(MsmGeom g, uint32_t lev
                                                          uint32_t* buckets) {
   uint32_t* pk[2] = {pk0, pk1}; uint32_t* pp[2] = {pp0, pp1};
   for (;;) {
-    const uint32_t lanes2 = (slots + g.T2 - 1) / g.T2;
+    const uint32_t T2l = level == 1 ? g.T2 : g.T2b;
+    const uint32_t lanes2 = (slots + T2l - 1) / T2l;
     SegReduceBody<C> b{g, level, slots, pk[cur], pp[cur], offsets, buckets, pk[cur ^ 1], pp[cur ^ 1]};
     for (uint32_t u = threadIdx.x; u < lanes2; u += blockDim.x) b(u);
     if (lanes2 == 1) break;

@@ -323,6 +323,7 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
     srs->cfg = ctx->msm_cfg;
     if (const char* e = getenv("PC_HIP_SEG_TAIL")) srs->cfg.seg_tail_lanes = (uint32_t)atoi(e);   // tuning experiments
     if (const char* e = getenv("PC_HIP_T2")) srs->cfg.T2 = (uint32_t)atoi(e);
+    if (const char* e = getenv("PC_HIP_T2B")) srs->cfg.T2b = (uint32_t)atoi(e);
     srs_lane(srs, 0);   // allocate the first pipeline now so that OOM surfaces at upload
     return (int)PC_OK;
   });

@@ -63,7 +63,7 @@ template <class C>
 static void run(const uint32_t* bases, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int T, int T2, int K0,
                 int from_mont, uint32_t* out) {
   CpuStepBackend be;
-  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) cfg.T2 = T2; if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; cfg.seg_tail_lanes = (T2 == 5) ? 1 : 3; }
+  pc::MsmConfig cfg; cfg.c = c; cfg.T = T; if (T2) { cfg.T2 = T2; cfg.T2b = T2 == 4 ? 6 : T2; } if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; cfg.seg_tail_lanes = (T2 == 5) ? 1 : 3; }
   pc::MsmPlan<C, CpuStepBackend> plan(be, n, cfg);
   plan.run(bases, base_off, scalars, n, from_mont != 0, out);
 }
