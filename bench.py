@@ -89,7 +89,7 @@ def bench_ntt(args):
     y = torch.empty((rows << log_n, 4), dtype=torch.int64, device="cuda")
     # the step after the encoding in LinearCodePCS::commit (linear_codes/mod.rs:256-263): column digests
     leaves = torch.empty((1 << log_n, 32), dtype=torch.uint8, device="cuda")
-    hash_ms = None
+    hash_ms = merkle_ms = None
     if world == 1:
         ctx.column_hash(curve, y.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=rows, n_cols=1 << log_n)
         torch.cuda.synchronize()
@@ -98,6 +98,15 @@ def bench_ntt(args):
             ctx.column_hash(curve, y.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=rows, n_cols=1 << log_n)
         torch.cuda.synchronize()
         hash_ms = (time.perf_counter() - t0) / 3 * 1e3
+        # ... and the Merkle tree over them (create_merkle_tree, linear_codes/mod.rs:506-521)
+        nodes = torch.empty(((1 << log_n) - 1, 32), dtype=torch.uint8, device="cuda")
+        ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=1 << log_n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=1 << log_n)
+        torch.cuda.synchronize()
+        merkle_ms = (time.perf_counter() - t0) / 3 * 1e3
     torch.cuda.synchronize()
     ph = np.zeros(2)
     for _ in range(args.warmup):
@@ -130,7 +139,8 @@ def bench_ntt(args):
             "config": {"workload": f"{n_rows} x {n_cols} matrix, {n_rows} forward NTTs of size 2^{log_n} (BASELINE configs[4])",
                        "parallelism": "1 GPU" if world == 1 else f"rows sharded over {world} GPUs, no collective"},
             "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
-            "column_hash_blake2s_ms": hash_ms,   # not part of `value`: the next step of the commit, device-resident
+            "column_hash_blake2s_ms": hash_ms,   # not part of `value`: the next steps of the commit, device-resident
+            "merkle_tree_sha256_ms": merkle_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
                          "kernel": "k_ntt_pass_a + k_ntt_pass_b (one batched NTT = both)",

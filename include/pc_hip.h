@@ -122,10 +122,31 @@ int pc_hip_last_ntt_phases_ms(const pc_ctx* ctx, float out[2]);
  * FieldToBytesColHasher<F, D> (bench-templates/src/lib.rs:309-338):
  *   out[j] = D( to_bytes!(column j) ),  to_bytes! = u64 LE length || 32-byte LE canonical residues,
  * D = SHA-256 or BLAKE2s-256.  ext_mat: rows x n_cols (row-major, Montgomery) -- the output of
- * pc_hip_ntt_batch, which therefore never has to leave HBM; out_digests: n_cols x 32 bytes.  The
- * Merkle tree over the digests (131072 leaves at 2^24 coefficients) stays with the caller. */
+ * pc_hip_ntt_batch, which therefore never has to leave HBM; out_digests: n_cols x 32 bytes
+ * (feed them to pc_hip_merkle_tree without leaving the device). */
 int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_mem where_in, size_t rows,
                        size_t n_cols, pc_hash hash, void* out_digests, pc_mem where_out);
+
+/* Merkle tree over the column digests: create_merkle_tree, poly-commit/src/linear_codes/
+ * mod.rs:506-521 (called at :270-274) -> ark_crypto_primitives MerkleTree::new, for the Config
+ * the reference's tests and benches instantiate (linear_codes/univariate_ligero/tests.rs:21-37):
+ * identity leaf hash, byte-digest two-to-one hash `hash`, ByteDigestConverter.  The n_leaves
+ * 32-byte digests (the output of pc_hip_column_hash, still in HBM) are padded with empty leaves
+ * to 2^h >= 2 leaves (mod.rs:517-518); the bottom level hashes conv(left) || conv(right) with
+ * conv = raw digest bytes (len_prefix = 0) or the ark-serialize image of the Vec<u8> digest,
+ * u64 LE length || bytes (len_prefix = 1, what ByteDigestConverter produces); upper levels hash
+ * left || right.  out_nodes: (2^h - 1) x 32 bytes in heap order -- root first, children of node i
+ * at 2i+1 and 2i+2 -- the layout of MerkleTree::non_leaf_nodes, from which the caller reads the
+ * root (commitment, mod.rs:277) and authentication paths (col_tree.generate_proof, mod.rs:555-557). */
+int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_mem where_in, size_t n_leaves,
+                       int len_prefix, void* out_nodes, pc_mem where_out);
+
+/* out[i] = sum_j xi[j] * polys[j][i] for i < n_out (coefficients past lens[j] are zero): the
+ * random linear combination MarlinKZG10::open forms before the one witness division,
+ * poly-commit/src/marlin/marlin_pc/mod.rs:281-287 (and :291-301 for the shifted polynomials).
+ * polys: k pointers, all host or all device (where_in); xi_host: k Fr (Montgomery). */
+int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, pc_mem where_in, const size_t* lens,
+                      size_t k, const void* xi_host, void* out, pc_mem where_out, size_t n_out);
 
 /* Witness polynomial q = p / (x - z): KZG10::compute_witness_polynomial,
  * poly-commit/src/kzg10/mod.rs:217-240.  coeffs: n Fr (Montgomery); z: one Fr (Montgomery,

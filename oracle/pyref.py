@@ -15,6 +15,8 @@ Reference anchors (relative to /root/reference):
                              test_reed_solomon :303-331 (natural order, arkworks omega)
   * Ligero dimensions        poly-commit/src/linear_codes/ligero.rs:118-128,
                              poly-commit/src/linear_codes/utils.rs:156-184
+  * column digests / Merkle  poly-commit/src/linear_codes/mod.rs:256-275, 506-521
+  * open's linear combination poly-commit/src/marlin/marlin_pc/mod.rs:281-287
 The field/curve arithmetic itself lives in crates.io ark-ff/ark-ec/ark-poly 0.5 (not in
 /root/reference); it is restated from the published definitions of the curves.
 """
@@ -357,3 +359,77 @@ def ipa_rounds(curve, comm_key, coeffs, z_point, h_prime, challenges):
             key[i] = ec_add(curve, key[i], ec_mul(curve, u, key[h + i]))
         n = h
     return l_vec, r_vec, key[0], cs[0]
+
+
+def column_digest(field, column_canonical, hash_name):
+    """FieldToBytesColHasher<F, D>::evaluate (bench-templates/src/lib.rs:327-337): D over
+    to_bytes!(column) = u64 LE length || 32-byte LE canonical residues."""
+    import hashlib
+    h = hashlib.new(hash_name)
+    h.update(len(column_canonical).to_bytes(8, "little"))
+    for v in column_canonical:
+        h.update(int(v).to_bytes(32, "little"))
+    return h.digest()
+
+
+def merkle_tree(leaf_digests, hash_name="sha256", len_prefix=True):
+    """create_merkle_tree (poly-commit/src/linear_codes/mod.rs:506-521) for the Config of
+    linear_codes/univariate_ligero/tests.rs:21-37 (identity leaf hash, byte-digest two-to-one
+    hash, ByteDigestConverter).  The arithmetic lives in ark-crypto-primitives 0.5 (absent from
+    /root/reference; restated from its published behaviour): leaves padded with empty byte strings
+    to a power of two >= 2; bottom level D(conv(l) || conv(r)) with conv = ark-serialize of the
+    Vec<u8> digest (u64 LE length || bytes) when len_prefix, raw bytes otherwise; upper levels
+    D(left || right).  Returns the inner nodes in heap order (root first)."""
+    import hashlib
+    n = len(leaf_digests)
+    assert n >= 1
+    h = max(1, (n - 1).bit_length())
+    leaves = list(leaf_digests) + [b""] * ((1 << h) - n)
+    conv = (lambda b: len(b).to_bytes(8, "little") + b) if len_prefix else (lambda b: b)
+    level = [hashlib.new(hash_name, conv(leaves[2 * i]) + conv(leaves[2 * i + 1])).digest() for i in range(1 << (h - 1))]
+    levels = [level]
+    while len(level) > 1:
+        level = [hashlib.new(hash_name, level[2 * i] + level[2 * i + 1]).digest() for i in range(len(level) // 2)]
+        levels.append(level)
+    nodes = []
+    for lv in reversed(levels):
+        nodes.extend(lv)
+    return nodes
+
+
+def merkle_path(nodes, leaf_digests, index):
+    """Authentication path of leaf `index` read out of the heap-ordered inner nodes (what
+    MerkleTree::generate_proof returns, linear_codes/mod.rs:555-557): the sibling leaf digest,
+    then the sibling inner node at every level from the bottom up to just below the root."""
+    n_inner = len(nodes)
+    sib = index ^ 1
+    leaf_sibling = leaf_digests[sib] if sib < len(leaf_digests) else b""
+    node = (n_inner + index + 1) // 2 - 1      # parent of the leaf: leaves continue the heap numbering at n_inner
+    path = []
+    while node > 0:
+        path.append(nodes[node + 1 if node % 2 == 1 else node - 1])
+        node = (node - 1) // 2
+    return leaf_sibling, path
+
+
+def merkle_verify(root, leaf, index, leaf_sibling, path, hash_name="sha256", len_prefix=True):
+    import hashlib
+    conv = (lambda b: len(b).to_bytes(8, "little") + b) if len_prefix else (lambda b: b)
+    l, r = (leaf, leaf_sibling) if index % 2 == 0 else (leaf_sibling, leaf)
+    cur = hashlib.new(hash_name, conv(l) + conv(r)).digest()
+    index //= 2
+    for s in path:
+        cur = hashlib.new(hash_name, (cur + s) if index % 2 == 0 else (s + cur)).digest()
+        index //= 2
+    return cur == root
+
+
+def fr_lincomb(field, polys, xi):
+    """p = sum_j xi_j p_j: MarlinKZG10::open, marlin/marlin_pc/mod.rs:281-287."""
+    p = FIELDS[field]["p"]
+    n = max((len(q) for q in polys), default=0)
+    out = [0] * n
+    for c, q in zip(xi, polys):
+        for i, v in enumerate(q):
+            out[i] = (out[i] + c * v) % p
+    return out

@@ -72,6 +72,8 @@ def load_library():
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
     lib.pc_hip_column_hash.argtypes = [vp, ip, vp, ip, sz, sz, ip, vp, ip]
+    lib.pc_hip_merkle_tree.argtypes = [vp, ip, vp, ip, sz, ip, vp, ip]
+    lib.pc_hip_fr_lincomb.argtypes = [vp, ip, C.POINTER(vp), ip, C.POINTER(sz), sz, vp, vp, ip, sz]
     lib.pc_hip_fr_fold.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_dot.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
@@ -157,6 +159,43 @@ class Context:
         pout, wout = _ptr(out)
         hid = {"sha256": 0, "blake2s": 1}[hash_name]
         self.check(self.lib.pc_hip_column_hash(self.h, CURVES[curve], pin, win, rows, n_cols, hid, pout, wout))
+        return out
+
+    def merkle_tree(self, digests, hash_name="sha256", len_prefix=True, out=None, n_leaves=None):
+        """Inner nodes of the Merkle tree over 32-byte leaf digests (create_merkle_tree,
+        linear_codes/mod.rs:506-521), heap order, root at row 0: (2^h - 1, 32) uint8 for host input;
+        device pointers (n_leaves given, out = device pointer) stay on the device."""
+        pin, win = _ptr(digests)
+        if n_leaves is None:
+            n_leaves = digests.shape[0]
+        h = max(1, (n_leaves - 1).bit_length())
+        if out is None:
+            assert win == PC_MEM_HOST
+            out = np.zeros(((1 << h) - 1, 32), dtype=np.uint8)
+        pout, wout = _ptr(out)
+        hid = {"sha256": 0, "blake2s": 1}[hash_name]
+        self.check(self.lib.pc_hip_merkle_tree(self.h, hid, pin, win, n_leaves, 1 if len_prefix else 0, pout, wout))
+        return out
+
+    def fr_lincomb(self, curve, polys, xi, n_out=None, out=None, lens=None):
+        """sum_j xi[j] * polys[j] (MarlinKZG10::open's combination, marlin_pc/mod.rs:281-287).
+        polys: list of (len_j, 4) uint64 host arrays, or device pointers with `lens`; xi: (k, 4)."""
+        k = len(polys)
+        ptrs = [_ptr(p) for p in polys]
+        where = ptrs[0][1] if k else PC_MEM_HOST
+        assert all(w == where for _, w in ptrs)
+        if lens is None:
+            lens = [p.shape[0] for p in polys]
+        if n_out is None:
+            n_out = max(lens) if k else 0
+        if out is None:
+            assert where == PC_MEM_HOST
+            out = np.zeros((n_out, 4), dtype=np.uint64)
+        pout, wout = _ptr(out)
+        arr = (C.c_void_p * max(k, 1))(*[p for p, _ in ptrs])
+        larr = (C.c_size_t * max(k, 1))(*lens)
+        xi = np.ascontiguousarray(xi, dtype=np.uint64)
+        self.check(self.lib.pc_hip_fr_lincomb(self.h, CURVES[curve], arr, where, larr, k, xi.ctypes.data, pout, wout, n_out))
         return out
 
     def last_ntt_phases_ms(self):

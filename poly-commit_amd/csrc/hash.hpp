@@ -121,4 +121,37 @@ struct ColumnHashBody {
   }
 };
 
+// Merkle tree over the column digests: step 2b of LinearCodePCS::commit,
+// create_merkle_tree (poly-commit/src/linear_codes/mod.rs:506-521) ->
+// ark_crypto_primitives::merkle_tree::MerkleTree::new with the Config the reference's tests and
+// benches use (linear_codes/univariate_ligero/tests.rs:21-37): LeafHash = LeafIdentityHasher
+// (the 32-byte column digest IS the leaf digest), TwoToOneHash = a byte digest D,
+// LeafInnerDigestConverter = ByteDigestConverter.  The leaf list is padded with empty leaves to a
+// power of two (mod.rs:517-518).  One level per launch, one lane per parent:
+//   bottom level: parent = D( conv(leaf 2i) || conv(leaf 2i+1) ), conv = the leaf digest either
+//                 raw or ark-serialized as Vec<u8> (u64 LE length || bytes) -- `len_prefix`;
+//                 a padding leaf is the empty byte string;
+//   upper levels: parent = D( left 32 bytes || right 32 bytes ).
+// Nodes are written in heap order (root at 0, children of i at 2i+1 / 2i+2), the layout of
+// MerkleTree::non_leaf_nodes, so the caller reads authentication paths straight out of it.
+template <class D>
+struct MerkleLevelBody {
+  const uint32_t* child;   // bottom: n_real leaf digests x 8 words; upper: the child level inside `nodes`
+  uint32_t* parent;        // this level inside `nodes`
+  uint32_t n_real;         // bottom level only: leaves that exist (the rest are padding)
+  uint32_t bottom, len_prefix;
+  PC_HD void push_leaf(D& d, uint32_t k) const {
+    const bool real = k < n_real;
+    if (len_prefix) { d.push_le32(real ? 32u : 0u); d.push_le32(0); }
+    if (real) { PC_UNROLL for (int w = 0; w < 8; w++) d.push_le32(child[(size_t)k * 8 + w]); }
+  }
+  PC_HD void operator()(uint32_t i) const {
+    D d; d.init();
+    if (bottom) { push_leaf(d, 2 * i); push_leaf(d, 2 * i + 1); }
+    else { PC_UNROLL for (int w = 0; w < 16; w++) d.push_le32(child[(size_t)i * 16 + w]); }
+    uint32_t dig[8]; d.finish(dig);
+    PC_UNROLL for (int w = 0; w < 8; w++) parent[(size_t)i * 8 + w] = dig[w];
+  }
+};
+
 }  // namespace pc

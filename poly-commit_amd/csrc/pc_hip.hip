@@ -640,6 +640,85 @@ int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t 
     return (int)PC_OK;
   });
 }
+extern "C++" {
+template <class FrP>
+static void fr_lincomb_t(pc::HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out) {
+  pc::FrLinCombBody<FrP> b{(const uint64_t*)addr, (const uint32_t*)lens, (const uint32_t*)xi, (uint32_t)k, (uint32_t*)out};
+  be.launch(b, n_out, 256);
+}
+}
+int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_mem where_in, size_t n_leaves,
+                       int len_prefix, void* out_nodes, pc_mem where_out) {
+  if (!ctx || ((int)hash != PC_HASH_SHA256 && (int)hash != PC_HASH_BLAKE2S) || !n_leaves || !leaf_digests || !out_nodes)
+    return PC_ERR_INVALID_ARG;
+  if (n_leaves > (1ull << 31)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    unsigned h = 1; while (((size_t)1 << h) < n_leaves) h++;      // padded leaf count 2^h >= 2
+    const size_t n_nodes = ((size_t)1 << h) - 1;
+    Staged sin(ctx->be, leaf_digests, where_in, n_leaves * 32, true);
+    Staged sout(ctx->be, out_nodes, where_out, n_nodes * 32, false);
+    uint32_t* nodes = (uint32_t*)sout.dev;
+    ctx->be.n_ev = 0; ctx->be.mark();
+    for (int d = (int)h - 1; d >= 0; d--) {
+      const bool bottom = d == (int)h - 1;
+      const size_t cnt = (size_t)1 << d;
+      const uint32_t* child = bottom ? (const uint32_t*)sin.dev : nodes + (((size_t)2 << d) - 1) * 8;
+      uint32_t* parent = nodes + (cnt - 1) * 8;
+      if (hash == PC_HASH_SHA256) {
+        pc::MerkleLevelBody<pc::Sha256> b{child, parent, (uint32_t)n_leaves, bottom ? 1u : 0u, len_prefix ? 1u : 0u};
+        ctx->be.launch(b, cnt, 64);
+      } else {
+        pc::MerkleLevelBody<pc::Blake2s256> b{child, parent, (uint32_t)n_leaves, bottom ? 1u : 0u, len_prefix ? 1u : 0u};
+        ctx->be.launch(b, cnt, 64);
+      }
+    }
+    ctx->be.mark();
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out_nodes, sout.dev, n_nodes * 32); else ctx->be.sync();
+    ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
+    if (ctx->be.timing && ctx->be.n_ev >= 2) (void)hipEventElapsedTime(&ctx->ntt_phases[0], ctx->be.ev[0], ctx->be.ev[1]);
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, pc_mem where_in, const size_t* lens,
+                      size_t k, const void* xi_host, void* out, pc_mem where_out, size_t n_out) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || (k && (!polys || !lens || !xi_host)) || (n_out && !out))
+    return PC_ERR_INVALID_ARG;
+  if (n_out >= (1ull << 32) || k >= (1ull << 20)) return PC_ERR_TOO_LARGE;
+  size_t total = 0;
+  for (size_t j = 0; j < k; j++) {
+    if (lens[j] >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+    if (lens[j] && !polys[j]) return PC_ERR_INVALID_ARG;
+    total += lens[j];
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (!n_out) return (int)PC_OK;
+    // host polynomials are staged back to back in one device buffer
+    Staged stage(ctx->be, nullptr, PC_MEM_HOST, where_in == PC_MEM_HOST ? total * 32 : 0, false);
+    std::vector<uint64_t> addr(k ? k : 1, 0); std::vector<uint32_t> len32(k ? k : 1, 0);
+    size_t off = 0;
+    for (size_t j = 0; j < k; j++) {
+      len32[j] = (uint32_t)lens[j];
+      if (where_in == PC_MEM_HOST) {
+        if (lens[j]) ctx->be.copy_h2d((char*)stage.dev + off * 32, polys[j], lens[j] * 32);
+        addr[j] = (uint64_t)(uintptr_t)((char*)stage.dev + off * 32); off += lens[j];
+      } else addr[j] = (uint64_t)(uintptr_t)polys[j];
+    }
+    Staged daddr(ctx->be, addr.data(), PC_MEM_HOST, addr.size() * 8, true);
+    Staged dlen(ctx->be, len32.data(), PC_MEM_HOST, len32.size() * 4, true);
+    Staged dxi(ctx->be, xi_host, PC_MEM_HOST, (k ? k : 1) * 32, k != 0);
+    Staged sout(ctx->be, out, where_out, n_out * 32, false);
+    ctx->be.n_ev = 0; ctx->be.mark();
+    FIELD_DISPATCH(field_of, fr_lincomb_t<FrP>(ctx->be, daddr.dev, dlen.dev, dxi.dev, k, sout.dev, n_out));
+    ctx->be.mark();
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n_out * 32); else ctx->be.sync();
+    ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
+    if (ctx->be.timing && ctx->be.n_ev >= 2) (void)hipEventElapsedTime(&ctx->ntt_phases[0], ctx->be.ev[0], ctx->be.ev[1]);
+    return (int)PC_OK;
+  });
+}
 int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) {
   if (!ctx || !srs || srs->ctx != ctx || !u_host || 2 * n_half > srs->n) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

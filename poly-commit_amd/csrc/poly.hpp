@@ -107,4 +107,28 @@ void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t
   div_scan<FrP>(be, p + FrP::N, n - 1, z_host, nullptr, q, G, G0);
 }
 
+// p = sum_j xi_j * p_j, coefficient-wise: the combination MarlinKZG10::open forms before the
+// single witness division (marlin/marlin_pc/mod.rs:281-287, `p += (challenge_j, polynomial)`),
+// and the shifted twin for degree-bounded polynomials (:291-301).  Polynomials may have
+// different lengths (missing high coefficients are zero).  One lane per output coefficient:
+// consecutive lanes read consecutive coefficients of the same polynomial (coalesced), the
+// xi_j and the pointer table are wave-uniform loads.  64 x 2^20 Fr: 2 GiB read, 32 MiB written.
+template <class FrP>
+struct FrLinCombBody {
+  typedef Fd<FrP> F;
+  const uint64_t* polys;   // k device addresses
+  const uint32_t* lens;    // k lengths
+  const uint32_t* xi;      // k Fr, Montgomery
+  uint32_t k; uint32_t* out;
+  PC_HD void operator()(uint32_t i) const {
+    F acc = F::zero();
+    for (uint32_t j = 0; j < k; j++) {
+      if (i >= lens[j]) continue;
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(polys[j]);
+      acc = acc.add(F::load(xi + (size_t)j * FrP::N).mul(F::load(p + (size_t)i * FrP::N)));
+    }
+    acc.store(out + (size_t)i * FrP::N);
+  }
+};
+
 }  // namespace pc

@@ -136,3 +136,26 @@ def test_sharded_engine_world1_matches_oracle(ctx):
     rc2, want_w = O.kzg_open(curve, powers, coeffs, z)
     assert (comm == want_c).all() and (proof == want_w).all()
     eng.srs.free()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254", "pallas"])
+def test_fr_lincomb_matches_bigint(ctx, curve):
+    """MarlinKZG10::open's p = sum_j xi_j p_j (marlin_pc/mod.rs:281-287), ragged lengths, host and
+    device-resident inputs; followed by the witness division it feeds (:307-312)."""
+    import torch
+    lens = [1000, 1, 517, 1000, 64, 0]
+    polys_i = [R.gen_scalars(curve + "_fr", 0x5EED0700 + j, n) for j, n in enumerate(lens)]
+    xi_i = R.gen_scalars(curve + "_fr", 0x5EED0777, len(lens))
+    want = R.fr_lincomb(curve + "_fr", polys_i, xi_i)
+    polys = [O.fr_mont_array(curve, p) if len(p) else np.zeros((0, 4), dtype=np.uint64) for p in polys_i]
+    xi = O.fr_mont_array(curve, xi_i)
+    got = ctx.fr_lincomb(curve, polys, xi)
+    assert O.fr_from_mont_array(curve, got) == want
+    # device-resident polynomials and output; truncated output length
+    dev = [torch.from_numpy(p.view(np.int64)).cuda() if len(p) else torch.zeros((1, 4), dtype=torch.int64, device="cuda") for p in polys]
+    out = torch.empty((600, 4), dtype=torch.int64, device="cuda")
+    ctx.fr_lincomb(curve, [d.data_ptr() for d in dev], xi, n_out=600, out=out.data_ptr(), lens=lens)
+    assert O.fr_from_mont_array(curve, out.cpu().numpy().view(np.uint64)) == want[:600]
+    # k = 0 gives the zero polynomial
+    z = ctx.fr_lincomb(curve, [], np.zeros((0, 4), dtype=np.uint64), n_out=5)
+    assert not z.any()

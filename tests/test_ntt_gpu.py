@@ -120,3 +120,43 @@ def test_ligero_commit_device_resident_encode_then_hash(ctx):
     want_ext = O.ntt_batch(curve, co.reshape(n_rows, n_cols, 4), 13)
     want = _hashlib_columns(curve, want_ext[:, :64], "blake2s")
     assert (leaves[:64].cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("name", ["sha256", "blake2s"])
+@pytest.mark.parametrize("len_prefix", [True, False])
+def test_merkle_tree_vs_hashlib(ctx, name, len_prefix):
+    """create_merkle_tree (linear_codes/mod.rs:506-521): inner nodes in heap order equal the
+    hashlib restatement, for power-of-two and padded leaf counts; every leaf's path verifies."""
+    import hashlib
+    for n in (1, 2, 3, 8, 13, 64, 1000, 4096):
+        leaves = [hashlib.blake2s(n.to_bytes(4, "little") + i.to_bytes(4, "little")).digest() for i in range(n)]
+        arr = np.frombuffer(b"".join(leaves), dtype=np.uint8).reshape(n, 32).copy()
+        got = ctx.merkle_tree(arr, name, len_prefix)
+        want = R.merkle_tree(leaves, name, len_prefix)
+        assert got.shape[0] == len(want)
+        assert got.tobytes() == b"".join(want), (n, name, len_prefix)
+        nodes = [got[i].tobytes() for i in range(got.shape[0])]
+        for i in {0, n // 2, n - 1}:
+            sib, path = R.merkle_path(nodes, leaves, i)
+            assert R.merkle_verify(nodes[0], leaves[i], i, sib, path, name, len_prefix)
+
+
+def test_ligero_commit_root_device_resident(ctx):
+    """LinearCodePCS::commit steps 1-3 (linear_codes/mod.rs:250-277) chained in HBM: encode,
+    column digests, Merkle tree; only the 32-byte root (and the node array for later paths) is read
+    back.  2^16 coefficients -> 32 x 2048 -> 8192 leaves."""
+    import torch
+    curve = "bls12_381"
+    n_rows, n_cols, _ = O.ligero_dims(255, 1 << 16)
+    co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0501, n_rows * n_cols))
+    x = torch.from_numpy(co.view(np.int64)).cuda()
+    ext = torch.empty((n_rows * 8192, 4), dtype=torch.int64, device="cuda")
+    leaves = torch.empty((8192, 32), dtype=torch.uint8, device="cuda")
+    nodes = torch.empty((8191, 32), dtype=torch.uint8, device="cuda")
+    ctx.ntt_batch(curve, x.data_ptr(), 13, out=ext.data_ptr(), rows=n_rows, in_cols=n_cols)
+    ctx.column_hash(curve, ext.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=n_rows, n_cols=8192)
+    ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=8192)
+    want_ext = O.ntt_batch(curve, co.reshape(n_rows, n_cols, 4), 13)
+    want_leaves = _hashlib_columns(curve, want_ext, "blake2s")
+    want = R.merkle_tree([want_leaves[j].tobytes() for j in range(8192)], "sha256", True)
+    assert nodes.cpu().numpy().tobytes() == b"".join(want)
