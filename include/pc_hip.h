@@ -141,10 +141,27 @@ int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_m
 int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_mem where_in, size_t n_leaves,
                        int len_prefix, void* out_nodes, pc_mem where_out);
 
+/* LinearCodePCS::commit steps 1-3 for one polynomial in one call, nothing but the results leaving
+ * HBM (poly-commit/src/linear_codes/mod.rs:248-277): encode the rows x in_cols coefficient matrix
+ * (pc_hip_ntt_batch), digest the 2^log_n columns (pc_hip_column_hash, col_hash), build the Merkle
+ * tree (pc_hip_merkle_tree, tree_hash / len_prefix).  nodes_out_host: (2^h - 1) x 32 bytes, h =
+ * max(1, log_n), root first -- the commitment is nodes[0] plus the metadata the caller already has
+ * (mod.rs:280-287).  leaves_out_host (2^log_n x 32 bytes) and ext_out (rows x 2^log_n Fr, host or
+ * device per where_ext) are what LinCodePCCommitmentState keeps for open (mod.rs:264-268); either
+ * may be NULL. */
+int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
+                         unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
+                         pc_mem where_ext, void* leaves_out_host, void* nodes_out_host);
+/* Kernel-only milliseconds of the last pc_hip_ligero_commit (timing on): [NTT pass A, NTT pass B,
+ * column digests, Merkle tree]. */
+int pc_hip_last_ligero_phases_ms(const pc_ctx* ctx, float out[4]);
+
 /* out[i] = sum_j xi[j] * polys[j][i] for i < n_out (coefficients past lens[j] are zero): the
  * random linear combination MarlinKZG10::open forms before the one witness division,
  * poly-commit/src/marlin/marlin_pc/mod.rs:281-287 (and :291-301 for the shifted polynomials).
- * polys: k pointers, all host or all device (where_in); xi_host: k Fr (Montgomery). */
+ * polys: k pointers, all host or all device (where_in); xi_host: k Fr (Montgomery).  The same
+ * call is Ligero's row combination v = b^T * mat in open (Matrix::row_mul, poly-commit/src/utils.rs:120-147,
+ * as used by generate_proof, linear_codes/mod.rs:539) with the rows as the polynomials. */
 int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, pc_mem where_in, const size_t* lens,
                       size_t k, const void* xi_host, void* out, pc_mem where_out, size_t n_out);
 

@@ -73,6 +73,8 @@ def load_library():
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
     lib.pc_hip_column_hash.argtypes = [vp, ip, vp, ip, sz, sz, ip, vp, ip]
     lib.pc_hip_merkle_tree.argtypes = [vp, ip, vp, ip, sz, ip, vp, ip]
+    lib.pc_hip_ligero_commit.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, ip, ip, ip, vp, ip, vp, vp]
+    lib.pc_hip_last_ligero_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_fr_lincomb.argtypes = [vp, ip, C.POINTER(vp), ip, C.POINTER(sz), sz, vp, vp, ip, sz]
     lib.pc_hip_fr_fold.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_dot.argtypes = [vp, ip, vp, vp, sz, vp]
@@ -197,6 +199,28 @@ class Context:
         xi = np.ascontiguousarray(xi, dtype=np.uint64)
         self.check(self.lib.pc_hip_fr_lincomb(self.h, CURVES[curve], arr, where, larr, k, xi.ctypes.data, pout, wout, n_out))
         return out
+
+    def ligero_commit(self, curve, mat, log_n, col_hash="blake2s", tree_hash="sha256", len_prefix=True,
+                      rows=None, in_cols=None, ext_out=None, want_leaves=True):
+        """LinearCodePCS::commit steps 1-3 (linear_codes/mod.rs:248-277) in one call: returns
+        (nodes (2^h - 1, 32) uint8 with the root at row 0, leaves (2^log_n, 32) uint8 or None)."""
+        pin, win = _ptr(mat)
+        if rows is None:
+            rows, in_cols = mat.shape[0], mat.shape[1]
+        hid = {"sha256": 0, "blake2s": 1}
+        n = 1 << log_n
+        nodes = np.zeros(((1 << max(1, log_n)) - 1, 32), dtype=np.uint8)
+        leaves = np.zeros((n, 32), dtype=np.uint8) if want_leaves else None
+        pext, wext = _ptr(ext_out) if ext_out is not None else (None, PC_MEM_HOST)
+        self.check(self.lib.pc_hip_ligero_commit(self.h, CURVES[curve], pin, win, rows, in_cols, log_n, hid[col_hash],
+                                                 hid[tree_hash], 1 if len_prefix else 0, pext, wext,
+                                                 leaves.ctypes.data if want_leaves else None, nodes.ctypes.data))
+        return nodes, leaves
+
+    def last_ligero_phases_ms(self):
+        out = (C.c_float * 4)()
+        self.check(self.lib.pc_hip_last_ligero_phases_ms(self.h, out))
+        return list(out)
 
     def last_ntt_phases_ms(self):
         out = (C.c_float * 2)()

@@ -139,9 +139,10 @@ struct NttRunnerT : NttRunner {
 struct pc_ctx {
   std::map<std::pair<int, unsigned>, std::unique_ptr<NttRunner>> ntt_plans;
   float ntt_phases[2] = {0, 0};
+  float ligero_phases[4] = {0, 0, 0, 0};
   int device = 0;
   pc::HipBackend be;
-  std::mutex mu;
+  std::recursive_mutex mu;   // recursive: the fused entry points call the single-step ones
   std::string last_error;
   pc::MsmConfig msm_cfg;
   float phases[8] = {0};
@@ -282,7 +283,7 @@ const char* pc_hip_last_error(const pc_ctx* ctx) { return ctx ? ctx->last_error.
 
 int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk) {
   if (!ctx || window_bits == 1 || window_bits > 24) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   ctx->msm_cfg.c = window_bits; ctx->msm_cfg.T = chunk;
   return PC_OK;
 }
@@ -295,7 +296,7 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
   if (stride_bytes < pb) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 31)) return PC_ERR_TOO_LARGE;
   if (where == PC_MEM_DEVICE && stride_bytes != pb) return PC_ERR_UNSUPPORTED;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   *out = nullptr;
   pc_srs* srs = new (std::nothrow) pc_srs();
   if (!srs) return PC_ERR_OOM;
@@ -352,7 +353,7 @@ int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void*
                pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
   pc_srs* srs = const_cast<pc_srs*>(srs_c);
   if (!ctx || !srs || !out_xy || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     pc_job job;
     int rc = enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, &job, false);
@@ -366,7 +367,7 @@ int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const
                      pc_mem where, size_t n, void* out_xy, int* out_is_infinity, pc_job** out_job) {
   pc_srs* srs = const_cast<pc_srs*>(srs_c);
   if (!ctx || !srs || !out_xy || !out_job || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   *out_job = nullptr;
   pc_job* job = new (std::nothrow) pc_job();
   if (!job) return PC_ERR_OOM;
@@ -378,7 +379,7 @@ int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const
 
 int pc_hip_job_wait(pc_ctx* ctx, pc_job* job) {
   if (!ctx || !job) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   int rc = job->status;
   if (!job->done) rc = guarded(ctx, [&]() { complete_job(ctx, job); return job->status; });
   delete job;
@@ -390,7 +391,7 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
                      int* out_is_infinity) {
   pc_srs* srs = const_cast<pc_srs*>(srs_c);
   if (!ctx || !srs || !out_xy || srs->ctx != ctx || (n_polys && (!scalars || !n))) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     // software pipeline over the lanes: polynomial k+1 accumulates while k's tail drains
     std::vector<pc_job> jobs(n_polys);
@@ -430,7 +431,7 @@ int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem wher
   const unsigned max_lg = field_of == PC_CURVE_BN254 ? 28 : 32;
   if (log_n > max_lg || log_n > 27) return PC_ERR_TOO_LARGE;
   if (in_cols > ((size_t)1 << log_n)) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (rows == 0) return (int)PC_OK;
     auto key = std::make_pair((int)field_of, log_n);
@@ -469,7 +470,7 @@ int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_
                          const void* carry_in_host, void* out, pc_mem where_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && (!coeffs || !out))) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (n == 0) return (int)PC_OK;
     Staged sin(ctx->be, coeffs, where_in, n * 32, true);
@@ -509,7 +510,7 @@ int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_m
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || ((int)hash != PC_HASH_SHA256 && (int)hash != PC_HASH_BLAKE2S) ||
       (rows && n_cols && (!ext_mat || !out_digests))) return PC_ERR_INVALID_ARG;
   if (rows >= (1ull << 32) || n_cols >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (!n_cols) return (int)PC_OK;
     Staged sin(ctx->be, ext_mat, where_in, rows * n_cols * 32, true);
@@ -537,7 +538,7 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
                         void* out, pc_mem where_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && !coeffs) || (n > 1 && !out)) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (n <= 1) return (int)PC_OK;
     Staged sin(ctx->be, coeffs, where_in, n * 32, true);
@@ -616,7 +617,7 @@ static void ec_fold_t(pc::HipBackend& be, uint32_t* key, size_t half, const uint
 int pc_hip_fr_fold(pc_ctx* ctx, pc_curve field_of, void* lo_dev, const void* hi_dev, size_t n_half, const void* s_host) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !s_host || (n_half && (!lo_dev || !hi_dev))) return PC_ERR_INVALID_ARG;
   if (n_half >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (n_half) FIELD_DISPATCH(field_of, fr_fold_t<FrP>(ctx->be, (uint32_t*)lo_dev, (const uint32_t*)hi_dev, n_half, (const uint32_t*)s_host));
     return (int)PC_OK;
@@ -625,7 +626,7 @@ int pc_hip_fr_fold(pc_ctx* ctx, pc_curve field_of, void* lo_dev, const void* hi_
 int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void* b_dev, size_t n, void* out_host) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !out_host || (n && (!a_dev || !b_dev))) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     FIELD_DISPATCH(field_of, fr_dot_t<FrP>(ctx->be, (const uint32_t*)a_dev, (const uint32_t*)b_dev, n, (uint32_t*)out_host));
     return (int)PC_OK;
@@ -634,12 +635,56 @@ int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void*
 int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t n, void* out_dev) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && !out_dev)) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (n) FIELD_DISPATCH(field_of, fr_powers_t<FrP>(ctx->be, (const uint32_t*)z_host, n, (uint32_t*)out_dev));
     return (int)PC_OK;
   });
 }
+int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
+                         unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
+                         pc_mem where_ext, void* leaves_out_host, void* nodes_out_host) {
+  if (!ctx || !rows || !in_cols || !mat || !nodes_out_host || log_n > 27 || in_cols > ((size_t)1 << log_n))
+    return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  const size_t N = (size_t)1 << log_n;
+  void* ext = nullptr; void* leaves = nullptr; void* nodes = nullptr;
+  const bool own_ext = !(ext_out && where_ext == PC_MEM_DEVICE);
+  int rc = guarded(ctx, [&]() {
+    ext = own_ext ? ctx->be.alloc(rows * N * 32) : ext_out;
+    leaves = ctx->be.alloc(N * 32);
+    nodes = ctx->be.alloc((N > 1 ? N : 2) * 32);
+    return (int)PC_OK;
+  });
+  float ph[4] = {0, 0, 0, 0};
+  if (rc == PC_OK) rc = pc_hip_ntt_batch(ctx, field_of, mat, where_in, rows, in_cols, log_n, ext, PC_MEM_DEVICE);
+  if (rc == PC_OK) { ph[0] = ctx->ntt_phases[0]; ph[1] = ctx->ntt_phases[1]; }
+  if (rc == PC_OK) rc = pc_hip_column_hash(ctx, field_of, ext, PC_MEM_DEVICE, rows, N, col_hash, leaves, PC_MEM_DEVICE);
+  if (rc == PC_OK) ph[2] = ctx->ntt_phases[0];
+  if (rc == PC_OK) rc = pc_hip_merkle_tree(ctx, tree_hash, leaves, PC_MEM_DEVICE, N, len_prefix, nodes, PC_MEM_DEVICE);
+  if (rc == PC_OK) ph[3] = ctx->ntt_phases[0];
+  if (rc == PC_OK) rc = guarded(ctx, [&]() {
+    unsigned h = 1; while (((size_t)1 << h) < N) h++;
+    ctx->be.copy_d2h(nodes_out_host, nodes, (((size_t)1 << h) - 1) * 32);
+    if (leaves_out_host) ctx->be.copy_d2h(leaves_out_host, leaves, N * 32);
+    if (ext_out && where_ext == PC_MEM_HOST) ctx->be.copy_d2h(ext_out, ext, rows * N * 32);
+    return (int)PC_OK;
+  });
+  (void)guarded(ctx, [&]() {
+    if (own_ext && ext) ctx->be.free(ext);
+    if (leaves) ctx->be.free(leaves);
+    if (nodes) ctx->be.free(nodes);
+    return (int)PC_OK;
+  });
+  memcpy(ctx->ligero_phases, ph, sizeof ph);
+  return rc;
+}
+int pc_hip_last_ligero_phases_ms(const pc_ctx* ctx, float out[4]) {
+  if (!ctx || !out) return PC_ERR_INVALID_ARG;
+  memcpy(out, ctx->ligero_phases, sizeof ctx->ligero_phases);
+  return PC_OK;
+}
+
 extern "C++" {
 template <class FrP>
 static void fr_lincomb_t(pc::HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out) {
@@ -652,7 +697,7 @@ int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_m
   if (!ctx || ((int)hash != PC_HASH_SHA256 && (int)hash != PC_HASH_BLAKE2S) || !n_leaves || !leaf_digests || !out_nodes)
     return PC_ERR_INVALID_ARG;
   if (n_leaves > (1ull << 31)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     unsigned h = 1; while (((size_t)1 << h) < n_leaves) h++;      // padded leaf count 2^h >= 2
     const size_t n_nodes = ((size_t)1 << h) - 1;
@@ -692,7 +737,7 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
     if (lens[j] && !polys[j]) return PC_ERR_INVALID_ARG;
     total += lens[j];
   }
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (!n_out) return (int)PC_OK;
     // host polynomials are staged back to back in one device buffer
@@ -721,7 +766,7 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
 }
 int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) {
   if (!ctx || !srs || srs->ctx != ctx || !u_host || 2 * n_half > srs->n) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     for (int i = 0; i < PC_MSM_LANES; i++)      // queued MSMs still read the old key
       if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
@@ -774,7 +819,7 @@ int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_ho
                                 void* out_points_dev) {
   if (!ctx || (int)curve < 0 || (int)curve > 2 || !g_xy_host || (n && (!scalars_dev || !out_points_dev))) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (!n) return (int)PC_OK;
     switch (curve) {
@@ -787,7 +832,7 @@ int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_ho
 }
 int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, void* out_xy) {
   if (!ctx || !srs || srs->ctx != ctx || offset + count > srs->n || (count && !out_xy)) return PC_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (count) ctx->be.copy_d2h(out_xy, srs->bases + offset * (size_t)srs->aw, count * (size_t)srs->aw * 4);
     return (int)PC_OK;

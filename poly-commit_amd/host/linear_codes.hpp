@@ -4,6 +4,8 @@
 //   LigeroPCParams::compute_dimensions  linear_codes/ligero.rs:118-128
 //   reed_solomon                        linear_codes/utils.rs:112-127
 //   LinearEncode::compute_matrices      linear_codes/mod.rs:118-138
+//   LinearCodePCS::commit               linear_codes/mod.rs:234-297 (steps 1-4, one polynomial at a time)
+//   generate_proof step 1 (row_mul)     linear_codes/mod.rs:539, poly-commit/src/utils.rs:120-147
 // Matrix<F> is the reference's dense row-major matrix (utils.rs:49-147) flattened.
 #pragma once
 #include <math.h>
@@ -62,6 +64,68 @@ struct LinearEncode {
     coeffs.resize(dims.first * dims.second, FrT<E>::zero());
     mat.n = dims.first; mat.m = dims.second; mat.entries = coeffs;
     return encode_rows(ctx, mat, param.rho_inv, ext_mat);
+  }
+};
+
+// Metadata / LinCodePCCommitment / LinCodePCCommitmentState (linear_codes/data_structures.rs:84-125);
+// the state additionally keeps the inner Merkle nodes so that open does not rebuild the tree
+// (the reference rebuilds it from `leaves` in open, mod.rs:329-336)
+struct Metadata { size_t n_rows = 0, n_cols = 0, n_ext_cols = 0; };
+struct LinCodePCCommitment { Metadata metadata; uint8_t root[32] = {0}; };
+template <class E>
+struct LinCodePCCommitmentState {
+  Matrix<E> mat, ext_mat;
+  std::vector<uint8_t> leaves;     // n_ext_cols x 32: column digests
+  std::vector<uint8_t> nodes;      // inner Merkle nodes, heap order, root first (MerkleTree::non_leaf_nodes)
+};
+
+template <class E>
+struct LinearCodePCS {
+  pc_hash col_hash = PC_HASH_BLAKE2S;      // FieldToBytesColHasher<F, Blake2s256>
+  pc_hash tree_hash = PC_HASH_SHA256;      // TwoToOneHash = Sha256
+  bool len_prefix = true;                  // ByteDigestConverter
+  // commit to one polynomial: matrix -> encode -> column digests -> Merkle tree, chained on the device
+  Error commit(pc_ctx* ctx, const DensePolynomial<E>& polynomial, const LigeroPCParams& param, LinCodePCCommitment& com,
+               LinCodePCCommitmentState<E>& state, bool keep_ext_mat = true) const {
+    std::vector<FrT<E>> coeffs = polynomial.coeffs;
+    auto dims = param.compute_dimensions<E>(coeffs.size());
+    coeffs.resize(dims.first * dims.second, FrT<E>::zero());
+    state.mat.n = dims.first; state.mat.m = dims.second; state.mat.entries = coeffs;
+    size_t size = 1; unsigned lg = 0; while (size < dims.second * param.rho_inv) { size <<= 1; lg++; }
+    state.ext_mat.n = dims.first; state.ext_mat.m = size;
+    if (keep_ext_mat) state.ext_mat.entries.assign(dims.first * size, FrT<E>::zero()); else state.ext_mat.entries.clear();
+    state.leaves.assign(size * 32, 0);
+    const size_t n_nodes = (size > 1 ? size : 2) - 1;
+    state.nodes.assign(n_nodes * 32, 0);
+    int rc = pc_hip_ligero_commit(ctx, E::ID, state.mat.entries.data(), PC_MEM_HOST, dims.first, dims.second, lg, col_hash,
+                                  tree_hash, len_prefix ? 1 : 0, keep_ext_mat ? state.ext_mat.entries.data() : nullptr,
+                                  PC_MEM_HOST, state.leaves.data(), state.nodes.data());
+    if (rc != PC_OK) { Error e; e.kind = Error::Backend; e.msg = pc_hip_strerror(rc); return e; }
+    com.metadata.n_rows = dims.first; com.metadata.n_cols = dims.second; com.metadata.n_ext_cols = size;
+    memcpy(com.root, state.nodes.data(), 32);
+    return Error();
+  }
+  // v = b^T * mat (generate_proof step 1)
+  static Error row_mul(pc_ctx* ctx, const Matrix<E>& mat, const std::vector<FrT<E>>& b, std::vector<FrT<E>>& v) {
+    if (b.size() != mat.n) { Error e; e.kind = Error::Backend; e.msg = "Invalid row multiplication: vector length differs from the number of rows"; return e; }
+    std::vector<const void*> rows(mat.n); std::vector<size_t> lens(mat.n, mat.m);
+    for (size_t r = 0; r < mat.n; r++) rows[r] = mat.entries.data() + r * mat.m;
+    v.assign(mat.m, FrT<E>::zero());
+    int rc = pc_hip_fr_lincomb(ctx, E::ID, rows.data(), PC_MEM_HOST, lens.data(), mat.n, b.data(), v.data(), PC_MEM_HOST, mat.m);
+    if (rc != PC_OK) { Error e; e.kind = Error::Backend; e.msg = pc_hip_strerror(rc); return e; }
+    return Error();
+  }
+  // Merkle authentication path of column `index` out of the commitment state (col_tree.generate_proof,
+  // mod.rs:555-557): the sibling leaf digest, then the sibling inner nodes from the bottom up.
+  static void merkle_path(const LinCodePCCommitmentState<E>& st, size_t index, uint8_t leaf_sibling[32],
+                          std::vector<uint8_t>& path) {
+    const size_t n_inner = st.nodes.size() / 32;
+    memcpy(leaf_sibling, st.leaves.data() + (index ^ 1) * 32, 32);
+    path.clear();
+    for (size_t node = (n_inner + index + 1) / 2 - 1; node > 0; node = (node - 1) / 2) {
+      const size_t sib = (node & 1) ? node + 1 : node - 1;
+      path.insert(path.end(), st.nodes.begin() + sib * 32, st.nodes.begin() + (sib + 1) * 32);
+    }
   }
 };
 

@@ -192,7 +192,44 @@ static void run(pc_ctx* ctx, const char* name) {
       CHECK(row.evaluate(w * w * w) == ext.at(r, 3));
     }
   }
-  printf("%s: ligero reed_solomon/compute_matrices, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
+  // ---- LinearCodePCS::commit (linear_codes/mod.rs:234-297): fused device chain == the single steps ----
+  {
+    LigeroPCParams param;
+    LinearCodePCS<E> pcs;
+    DensePolynomial<E> pol = rand_poly<E>(4999, rng);
+    LinCodePCCommitment com; LinCodePCCommitmentState<E> st;
+    CHECK(!pcs.commit(ctx, pol, param, com, st));
+    CHECK(com.metadata.n_rows == st.mat.n && com.metadata.n_cols == st.mat.m && com.metadata.n_ext_cols == st.ext_mat.m);
+    Matrix<E> mat2, ext2;
+    CHECK(!LinearEncode<E>::compute_matrices(ctx, pol, param, mat2, ext2));
+    CHECK(ext2.entries.size() == st.ext_mat.entries.size());
+    CHECK(memcmp(ext2.entries.data(), st.ext_mat.entries.data(), ext2.entries.size() * sizeof(FrT<E>)) == 0);
+    std::vector<uint8_t> leaves(ext2.m * 32), nodes((ext2.m - 1) * 32);
+    CHECK(pc_hip_column_hash(ctx, E::ID, ext2.entries.data(), PC_MEM_HOST, ext2.n, ext2.m, PC_HASH_BLAKE2S, leaves.data(), PC_MEM_HOST) == PC_OK);
+    CHECK(pc_hip_merkle_tree(ctx, PC_HASH_SHA256, leaves.data(), PC_MEM_HOST, ext2.m, 1, nodes.data(), PC_MEM_HOST) == PC_OK);
+    CHECK(leaves == st.leaves && nodes == st.nodes && memcmp(com.root, nodes.data(), 32) == 0);
+    // the commitment without the encoded matrix coming back is the same commitment
+    LinCodePCCommitment com2; LinCodePCCommitmentState<E> st2;
+    CHECK(!pcs.commit(ctx, pol, param, com2, st2, false));
+    CHECK(memcmp(com.root, com2.root, 32) == 0 && st2.ext_mat.entries.empty());
+    // generate_proof step 1: v = b^T * mat, checked against the host field arithmetic
+    std::vector<FrT<E>> b(st.mat.n), v;
+    for (auto& x : b) x = rng.next_fr();
+    CHECK(!LinearCodePCS<E>::row_mul(ctx, st.mat, b, v));
+    for (size_t c = 0; c < st.mat.m; c += 7) {
+      FrT<E> acc = FrT<E>::zero();
+      for (size_t r = 0; r < st.mat.n; r++) acc = acc + b[r] * st.mat.at(r, c);
+      CHECK(acc == v[c]);
+    }
+    b.pop_back();
+    CHECK(LinearCodePCS<E>::row_mul(ctx, st.mat, b, v).kind == Error::Backend);
+    // authentication path shape: log2(n_ext_cols) - 1 inner siblings
+    uint8_t sib[32]; std::vector<uint8_t> path;
+    LinearCodePCS<E>::merkle_path(st, 5, sib, path);
+    CHECK(path.size() == (ark_log2(st.ext_mat.m) - 1) * 32 && memcmp(sib, st.leaves.data() + 4 * 32, 32) == 0);
+    CHECK(memcmp(path.data() + path.size() - 32, st.nodes.data() + 2 * 32, 32) == 0);   // leaf 5 is in the left half: last sibling is node 2
+  }
+  printf("%s: ligero reed_solomon/compute_matrices/commit/row_mul, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
 }
 
 int main() {

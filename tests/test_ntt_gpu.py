@@ -160,3 +160,29 @@ def test_ligero_commit_root_device_resident(ctx):
     want_leaves = _hashlib_columns(curve, want_ext, "blake2s")
     want = R.merkle_tree([want_leaves[j].tobytes() for j in range(8192)], "sha256", True)
     assert nodes.cpu().numpy().tobytes() == b"".join(want)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_ligero_commit_fused_vs_restatement(ctx, curve):
+    """pc_hip_ligero_commit == encode (oracle NTT) + hashlib column digests + hashlib Merkle tree,
+    for a ragged polynomial length (zero-padded matrix, linear_codes/mod.rs:123-129)."""
+    poly_len = 3000
+    n_rows, n_cols, _ = O.ligero_dims(255 if curve != "bn254" else 254, poly_len)
+    co = np.zeros((n_rows * n_cols, 4), dtype=np.uint64)
+    co[:poly_len] = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0502, poly_len))
+    log_n = (n_cols * 4 - 1).bit_length()
+    ext = np.zeros((n_rows, 1 << log_n, 4), dtype=np.uint64)
+    nodes, leaves = ctx.ligero_commit(curve, co.reshape(n_rows, n_cols, 4), log_n, ext_out=ext)
+    want_ext = O.ntt_batch(curve, co.reshape(n_rows, n_cols, 4), log_n)
+    assert (ext == want_ext).all()
+    want_leaves = _hashlib_columns(curve, want_ext, "blake2s")
+    assert (leaves == want_leaves).all()
+    want = R.merkle_tree([want_leaves[j].tobytes() for j in range(1 << log_n)], "sha256", True)
+    assert nodes.tobytes() == b"".join(want)
+    # root only (no leaves / ext coming back) is the same root
+    nodes2, none = ctx.ligero_commit(curve, co.reshape(n_rows, n_cols, 4), log_n, want_leaves=False)
+    assert none is None and (nodes2[0] == nodes[0]).all()
+    # ... and with the sha256 column hasher / raw-digest converter the tree changes as restated
+    nodes3, leaves3 = ctx.ligero_commit(curve, co.reshape(n_rows, n_cols, 4), log_n, col_hash="sha256", tree_hash="blake2s", len_prefix=False)
+    wl = _hashlib_columns(curve, want_ext, "sha256")
+    assert nodes3.tobytes() == b"".join(R.merkle_tree([wl[j].tobytes() for j in range(1 << log_n)], "blake2s", False))
