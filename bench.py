@@ -175,6 +175,8 @@ def bench_batch(args):
     ctx.set_timing(True)
     bases = O.gen_bases(curve, n)                  # synthetic chunk (every rank the same points: throughput only)
     srs = ctx.upload_srs(curve, bases)
+    if args.precompute:
+        srs.precompute()
     polys = [torch.from_numpy(O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0100 + j, n)).view(np.int64)).cuda()
              for j in range(args.polys)]
     ptrs, lens = [p.data_ptr() for p in polys], [n] * args.polys
@@ -236,6 +238,9 @@ def main():
                     help="kzg (default, BASELINE configs[1]), ntt (configs[4]: Ligero 2^24 coefficients) or "
                          "batch (configs[2]: 64 x MarlinKZG10<Bn254> commits, SRS sharded over the GPUs)")
     ap.add_argument("--polys", type=int, default=64)
+    ap.add_argument("--precompute", type=int, default=1,
+                    help="1 (default): build the SRS window table in HBM once after the upload "
+                         "(pc_hip_srs_precompute; part of SRS residency, outside the timed region); 0: table-free MSM")
     args = ap.parse_args()
     if args.workload == "ntt":
         return bench_ntt(args)
@@ -272,7 +277,7 @@ def main():
     eng = sharded.HipEngine(ctx, curve)
     job = sharded.ShardedKzg(eng, curve, rank, world, dist)
     bases = O.gen_bases(curve, n + 1)       # +1: the open of shard r > 0 reaches one base back
-    job.load_srs_chunk(bases)
+    job.load_srs_chunk(bases, precompute=bool(args.precompute))
     coeffs_h = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0001 + rank, n))
     coeffs = torch.from_numpy(coeffs_h.view(np.int64)).cuda()
     z_mont = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x2EE7, 1))[0]
@@ -342,7 +347,7 @@ def main():
             "config": {"workload": f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{args.log_degree} per GPU, "
                                    f"SRS resident, hiding off (BASELINE configs[1])",
                        "curve": curve, "log_degree": args.log_degree, "pairs_per_step": pairs_per_step,
-                       "inflight": depth,
+                       "inflight": depth, "srs_window_table": bool(args.precompute),
                        "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients sharded in {world} contiguous chunks, "
                                                                  f"all_gather of partial points"},
             "commit_open_per_s": args.steps / dt if world == 1 else None,

@@ -62,6 +62,14 @@ const char* pc_hip_last_error(const pc_ctx* ctx);
 int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, size_t stride_bytes,
                       pc_mem where, pc_srs** out);
 void pc_hip_srs_free(pc_srs* srs);
+/* Optional, once per committer key (same place as the upload, i.e. `trim`): build the window
+ * table T[w][i] = 2^(c w) * bases[i] in HBM, (bits/c + 1) x the size of the SRS.  MSMs of at least
+ * min_pairs pairs (0 = a quarter of the SRS) against this SRS then run with one bucket set shared
+ * by all windows: fewer, wider windows, no window fold -- same results, bit for bit.  window_bits
+ * 0 = choose from the SRS length.  Shorter MSMs keep the table-free path.  pc_hip_ec_fold drops
+ * the table (the key changes).  Nothing in the reference corresponds to it: ark-ec's
+ * VariableBaseMSM has no fixed-base state. */
+int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs);
 size_t pc_hip_srs_len(const pc_srs* srs);
 /* Device pointer of the packed (x||y) resident bases, for callers that build on it. */
 void* pc_hip_srs_device_ptr(const pc_srs* srs);

@@ -55,6 +55,7 @@ def load_library():
     lib.pc_hip_last_error.restype = C.c_char_p
     lib.pc_hip_srs_upload.argtypes = [vp, ip, vp, sz, sz, ip, C.POINTER(vp)]
     lib.pc_hip_srs_free.argtypes = [vp]
+    lib.pc_hip_srs_precompute.argtypes = [vp, vp, C.c_uint, sz]
     lib.pc_hip_srs_free.restype = None
     lib.pc_hip_srs_len.argtypes = [vp]
     lib.pc_hip_srs_len.restype = sz
@@ -292,6 +293,11 @@ class Srs:
         h = C.c_void_p()
         ctx.check(ctx.lib.pc_hip_srs_upload(ctx.h, CURVES[curve], p, n, stride_bytes, where, C.byref(h)))
         self.h, self.n = h, n
+
+    def precompute(self, window_bits=0, min_pairs=0):
+        """Build the window table of this SRS in HBM (pc_hip_srs_precompute)."""
+        self.ctx.check(self.ctx.lib.pc_hip_srs_precompute(self.ctx.h, self.h, window_bits, min_pairs))
+        return self
 
     def free(self):
         if self.h:

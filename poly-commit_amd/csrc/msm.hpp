@@ -57,7 +57,7 @@ static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 struct MsmGeom {
   uint32_t n;          // pairs in this call
   uint32_t c;          // window bits
-  uint32_t W;          // number of windows (digits per scalar)
+  uint32_t W;          // bucket sets: one per window, or 1 when the windows share buckets (table mode)
   uint32_t nb_win;     // buckets per window = 2^(c-1)
   uint32_t NB;         // total buckets = W * nb_win
   uint32_t base_off;   // offset of this call's first base inside the resident SRS
@@ -65,6 +65,12 @@ struct MsmGeom {
   uint32_t T;          // level-0 chunk length
   uint32_t T2;         // chunk length of seg-reduce level 1
   uint32_t T2b;        // chunk length of the deeper (sparser) seg-reduce levels
+  uint32_t Wd;         // signed digits per scalar = bits / c + 1
+  uint32_t tbl_stride; // 0: classic (digit w goes to bucket set w and adds base i);  else the bases are a
+                       // precomputed table T[w][i] = 2^(c w) P_i of `tbl_stride` points per window: digit w
+                       // adds T[w][i] into the ONE shared bucket set (W == 1)
+  PC_HD uint32_t key_window(uint32_t w) const { return tbl_stride ? 0u : w; }
+  PC_HD uint32_t base_index(uint32_t w, uint32_t i) const { return tbl_stride ? w * tbl_stride + base_off + i : base_off + i; }
 };
 
 PC_HD uint32_t msm_num_windows(uint32_t bits, uint32_t c) { return bits / c + 1; }
@@ -101,11 +107,11 @@ struct DigitsHistBody {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
     uint32_t carry = 0;
     const uint32_t half = 1u << (g.c - 1);
-    for (uint32_t w = 0; w < g.W; w++) {
+    for (uint32_t w = 0; w < g.Wd; w++) {
       uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
-      if (mag) atomic_inc_u32(hist + (size_t)w * g.nb_win + (mag - 1));
+      if (mag) atomic_inc_u32(hist + (size_t)g.key_window(w) * g.nb_win + (mag - 1));
     }
   }
 };
@@ -124,13 +130,13 @@ struct ScatterBody {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
     uint32_t carry = 0;
     const uint32_t half = 1u << (g.c - 1);
-    for (uint32_t w = 0; w < g.W; w++) {
+    for (uint32_t w = 0; w < g.Wd; w++) {
       uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
       if (mag) {
-        uint32_t pos = atomic_inc_u32(cursor + (size_t)w * g.nb_win + (mag - 1));
-        entries[pos] = (g.base_off + i) | (carry << 31);
+        uint32_t pos = atomic_inc_u32(cursor + (size_t)g.key_window(w) * g.nb_win + (mag - 1));
+        entries[pos] = g.base_index(w, i) | (carry << 31);
       }
     }
   }
@@ -379,6 +385,40 @@ void sort_entries_atomic(Backend& be, const MsmGeom& g, const uint32_t* scalars_
 }
 
 // ---------------------------------------------------------------------------------------
+// Window table of a resident SRS: table[w][i] = 2^(c w) P_i for w < Wd (affine, (0,0) = infinity).
+// With it digit w of scalar i adds table[w][i] into ONE bucket set shared by all windows:
+//   sum_i k_i P_i = sum_{w,i} d_{w,i} (2^(c w) P_i) = sum_b b * B[b],
+// so the bucket count no longer multiplies with the window count and c can grow (c = 20 at
+// n = 2^20: 13 digits per scalar instead of 16, the same 2^19 buckets in total, no window fold).
+// Built once per SRS (like the upload, outside any commit/open): one lane per base walks the
+// doubling chain in Jacobian coordinates and normalises once per window.
+// ---------------------------------------------------------------------------------------
+template <class C>
+struct WindowTableBody {
+  static constexpr int AW = 2 * Fd<typename C::FqP>::N;
+  const uint32_t* bases; uint32_t n, c, Wd; uint32_t* table;
+  PC_HD void operator()(uint32_t i) const {
+    AffD<C> p = AffD<C>::load(bases + (size_t)i * AW);
+    p.store(table + (size_t)i * AW);
+    JacD<C> acc = JacD<C>::infinity(); acc.add_affine(p);
+    for (uint32_t w = 1; w < Wd; w++) {
+      for (uint32_t k = 0; k < c; k++) acc = acc.dbl();
+      acc.to_affine().store(table + ((size_t)w * n + i) * AW);
+    }
+  }
+};
+
+// window width for the table mode: n * (bits/c + 1) mixed adds against ~3 * 2^(c-1) reduction adds
+inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255) {
+  uint32_t best = 8; double best_cost = 1e300;
+  for (uint32_t c = 8; c <= 23; c++) {
+    double cost = (double)n * (scalar_bits / c + 1) + 3.0 * (double)((size_t)1 << (c - 1));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------
 // Orchestration
 // ---------------------------------------------------------------------------------------
 struct MsmConfig {
@@ -386,11 +426,22 @@ struct MsmConfig {
   uint32_t T = 0;            // 0 = choose from n*W
   uint32_t T2 = 4;           // seg-reduce level 1 chunk: short chains beat fewer launches (measured 4 < 8 < 64)
   uint32_t T2b = 4;          // deeper levels
-  uint32_t K0 = 4;           // bucket-reduce group size, level 0 (wide: keep the chain short)
+  uint32_t K0 = 8;           // bucket-reduce group size of the wide levels (serial chains; measured 8 < 4 << 16)
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
   uint32_t seg_tail_lanes = 256;         // seg-reduce levels with at most this many lanes run inside one launch
   uint32_t coop_max_points = 1u << 17;   // levels with more points than this use the serial fan-in K0
+  // Precomputed window table of a resident SRS (pc_hip_srs_precompute): calls of at least tbl_min_n
+  // pairs run with window width tbl_c against tbl[w][i] = 2^(tbl_c w) P_i and ONE shared bucket set.
+  const uint32_t* tbl = nullptr;
+  uint32_t tbl_c = 0, tbl_stride = 0;
+  size_t tbl_min_n = 0;
+  // The shared bucket set is denser where the short top digit lands (56 instead of 24 entries per
+  // bucket at n = 2^20, c = 20): chunks of M / 2^18 = 52 entries would cut those buckets twice, which
+  // the in-workgroup neighbour merge cannot repair (seg-reduce 0.37 -> 0.76 ms).  One round of 512
+  // workgroups (chunks of 104) keeps every bucket within two chunks at the same accumulate time.
+  uint32_t tbl_target_lanes = 1u << 17;
+  uint32_t tbl_K0 = 8;                  // first reduction level of the 2^(c-1)-bucket set (measured 8 < 4 << 16)
 };
 
 PC_HD uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -439,7 +490,7 @@ class MsmPlan {
     for (size_t n = 1;; n = (n * 2 < n_max) ? n * 2 : n_max) {
       plan_geometry(n);
       NBmax = std::max<size_t>(NBmax, g_.NB);
-      Mmax = std::max<size_t>(Mmax, n * (size_t)g_.W);
+      Mmax = std::max<size_t>(Mmax, n * (size_t)g_.Wd);
       size_t total = 0;
       for (uint32_t l = 0; l < n_levels_; l++) total += (size_t)(1 + lvl_narr_[l]) * g_.W * lvl_m_[l];
       red_max = std::max(red_max, total);
@@ -459,7 +510,8 @@ class MsmPlan {
     size_t lanes0 = ceil_div_u32(Mmax, min_T_);
     if (!cfg_.T) {
       // T = clamp(floor(M / target_lanes), 16, 4096)  =>  lanes = ceil(M / T) <= max(17/16 target_lanes + 2, M / 4096 + 1)
-      size_t bound = std::max<size_t>((size_t)cfg_.target_lanes * 17 / 16 + 2, Mmax / 4096 + 1);
+      const size_t tl = std::max(cfg_.target_lanes, cfg_.tbl ? cfg_.tbl_target_lanes : 0u);
+      size_t bound = std::max<size_t>(tl * 17 / 16 + 2, Mmax / 4096 + 1);
       if (lanes0 > bound) lanes0 = bound;
     }
     size_t slots = 2 * lanes0;
@@ -502,8 +554,8 @@ class MsmPlan {
     plan_geometry(n);
     MsmGeom g = g_;
     g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
-    const size_t Mmax = n * g.W;
-    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / cfg_.target_lanes);
+    const size_t Mmax = n * g.Wd;
+    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / (g.tbl_stride ? cfg_.tbl_target_lanes : cfg_.target_lanes));
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
     g.T = T; g.T2 = cfg_.T2; g.T2b = cfg_.T2b;
@@ -514,7 +566,7 @@ class MsmPlan {
 
     size_t lanes = ceil_div_u32(Mmax, T);
     if (2 * lanes > part_slots_) throw std::runtime_error("MsmPlan: partial list undersized");
-    { AccumulateBody<C> b{g, bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
+    { AccumulateBody<C> b{g, g.tbl_stride ? cfg_.tbl : bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
     be_.mark();   // 4: accumulate
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
@@ -561,15 +613,17 @@ class MsmPlan {
  private:
   // window width, bucket counts and the reduction-level plan for a call of n pairs
   void plan_geometry(size_t n) {
-    uint32_t c = cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
-    g_.c = c; g_.W = msm_num_windows(FrP::BITS, c); g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
+    const bool tbl = cfg_.tbl && cfg_.tbl_c && n >= cfg_.tbl_min_n;
+    uint32_t c = tbl ? cfg_.tbl_c : cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
+    g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u;
+    g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b;
     uint32_t m = g_.nb_win; n_levels_ = 0;
     uint32_t kbits = 0; arr_exp_.clear();
     while (m > 1) {
       // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
       // points the chain length is all that matters: workgroup-cooperative "bits" levels (K1).
-      uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? cfg_.K0 : cfg_.K1; if (K > m) K = m;
+      uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? (tbl ? cfg_.tbl_K0 : cfg_.K0) : cfg_.K1; if (K > m) K = m;
       uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
       const bool bits = K >= 16;
       const uint32_t woff = n_levels_ == 0 ? 1u : 0u;

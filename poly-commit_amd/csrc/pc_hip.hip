@@ -23,7 +23,7 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)
   const size_t gw = (size_t)sg.nblocks * sg.NC, nb1 = (size_t)sg.NC + 1;
   const size_t rec_off = ((gw + 2 * nb1) * 4 + 15) & ~(size_t)15;
-  const size_t need = rec_off + (size_t)g.n * g.W * 8;
+  const size_t need = rec_off + (size_t)g.n * g.Wd * 8;
   if (need > sort_ws_bytes) {
     if (sort_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0; }
     PC_HIP_CHECK(hipMalloc(&sort_ws, need)); sort_ws_bytes = need;
@@ -156,6 +156,7 @@ struct pc_srs {
   pc_curve curve = PC_CURVE_BLS12_381;
   size_t n = 0;
   uint32_t* bases = nullptr;     // packed x||y
+  uint32_t* table = nullptr;     // precomputed window table (pc_hip_srs_precompute), or null
   int aw = 0;                    // words per affine point
   pc::MsmConfig cfg;
   MsmLane* lanes[PC_MSM_LANES] = {nullptr, nullptr, nullptr};
@@ -234,6 +235,14 @@ static int enqueue_job(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void*
   L->runner->enqueue(srs->bases, (uint32_t)base_offset, scalars, where, n, form == PC_SCALARS_MONTGOMERY);
   L->inflight = job;
   return PC_OK;
+}
+
+// Forget the window table of an SRS (and the pipelines sized for it).  No job may be in flight.
+static void drop_table(pc_srs* srs) {
+  if (!srs->table) return;
+  for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
+  (void)hipFree(srs->table); srs->table = nullptr;
+  srs->cfg.tbl = nullptr; srs->cfg.tbl_c = 0; srs->cfg.tbl_stride = 0; srs->cfg.tbl_min_n = 0;
 }
 
 extern "C" {
@@ -325,6 +334,9 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
     if (const char* e = getenv("PC_HIP_SEG_TAIL")) srs->cfg.seg_tail_lanes = (uint32_t)atoi(e);   // tuning experiments
     if (const char* e = getenv("PC_HIP_T2")) srs->cfg.T2 = (uint32_t)atoi(e);
     if (const char* e = getenv("PC_HIP_T2B")) srs->cfg.T2b = (uint32_t)atoi(e);
+    if (const char* e = getenv("PC_HIP_K0")) srs->cfg.K0 = (uint32_t)atoi(e);
+    if (const char* e = getenv("PC_HIP_TBL_K0")) srs->cfg.tbl_K0 = (uint32_t)atoi(e);
+    if (const char* e = getenv("PC_HIP_TBL_LANES")) srs->cfg.tbl_target_lanes = (uint32_t)atoi(e);
     srs_lane(srs, 0);   // allocate the first pipeline now so that OOM surfaces at upload
     return (int)PC_OK;
   });
@@ -344,7 +356,38 @@ void pc_hip_srs_free(pc_srs* srs) {
     delete srs->lanes[i];
   }
   if (srs->bases) (void)hipFree(srs->bases);
+  if (srs->table) (void)hipFree(srs->table);
   delete srs;
+}
+int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {
+  if (!ctx || !srs || srs->ctx != ctx || window_bits == 1 || window_bits > 23) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    for (int i = 0; i < PC_MSM_LANES; i++)
+      if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
+    drop_table(srs);
+    if (!srs->n) return (int)PC_OK;
+    const uint32_t bits = srs->curve == PC_CURVE_BN254 ? 254u : 255u;
+    const uint32_t c = window_bits ? window_bits : pc::msm_choose_table_c(srs->n, bits);
+    const uint32_t Wd = pc::msm_num_windows(bits, c);
+    if ((uint64_t)Wd * srs->n >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;     // entry = 31-bit table index + sign
+    const size_t bytes = (size_t)Wd * srs->n * srs->aw * 4;
+    uint32_t* table = (uint32_t*)ctx->be.alloc(bytes);
+    try {
+      switch (srs->curve) {
+        case PC_CURVE_BLS12_381: { pc::WindowTableBody<pc_curve_bls12_381> b{srs->bases, (uint32_t)srs->n, c, Wd, table}; ctx->be.launch(b, srs->n, 64); } break;
+        case PC_CURVE_BN254: { pc::WindowTableBody<pc_curve_bn254> b{srs->bases, (uint32_t)srs->n, c, Wd, table}; ctx->be.launch(b, srs->n, 64); } break;
+        default: { pc::WindowTableBody<pc_curve_pallas> b{srs->bases, (uint32_t)srs->n, c, Wd, table}; ctx->be.launch(b, srs->n, 64); } break;
+      }
+      ctx->be.sync();
+    } catch (...) { ctx->be.free(table); throw; }
+    for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
+    srs->table = table;
+    srs->cfg.tbl = table; srs->cfg.tbl_c = c; srs->cfg.tbl_stride = (uint32_t)srs->n;
+    srs->cfg.tbl_min_n = min_pairs ? min_pairs : (srs->n + 3) / 4;
+    srs_lane(srs, 0);
+    return (int)PC_OK;
+  });
 }
 size_t pc_hip_srs_len(const pc_srs* srs) { return srs ? srs->n : 0; }
 void* pc_hip_srs_device_ptr(const pc_srs* srs) { return srs ? srs->bases : nullptr; }
@@ -771,6 +814,7 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) 
     for (int i = 0; i < PC_MSM_LANES; i++)      // queued MSMs still read the old key
       if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
     if (!n_half) return (int)PC_OK;
+    drop_table(srs);                            // the key changes: its window table is stale
     switch (srs->curve) {
       case PC_CURVE_BLS12_381: ec_fold_t<pc_curve_bls12_381>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
       case PC_CURVE_BN254: ec_fold_t<pc_curve_bn254>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;

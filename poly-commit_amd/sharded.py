@@ -43,8 +43,10 @@ class HipEngine:
         self._scratch = None
         self.phases = []
 
-    def load_srs(self, bases):
+    def load_srs(self, bases, precompute=False):
         self.srs = self.ctx.upload_srs(self.curve, np.ascontiguousarray(bases))
+        if precompute:          # window table in HBM (pc_hip_srs_precompute): once per key, like the upload
+            self.srs.precompute()
 
     def _ptr(self, buf, elem_off=0):
         if isinstance(buf, np.ndarray):
@@ -95,8 +97,8 @@ class ShardedKzg:
 
     # bases: n+1 affine points; bases[0] = the power just below this chunk (unused on rank 0),
     # bases[1 + j] = power r*n + j.
-    def load_srs_chunk(self, bases):
-        self.e.load_srs(bases)
+    def load_srs_chunk(self, bases, **kw):
+        self.e.load_srs(bases, **kw)
 
     def set_point(self, z_mont):
         self.z = np.ascontiguousarray(z_mont, dtype=np.uint64)

@@ -77,6 +77,30 @@ extern "C" void emu_msm(int curve, const uint32_t* bases, const uint32_t* scalar
   }
 }
 
+// table mode (pc_hip_srs_precompute): window table built by the same body the GPU runs, then the
+// plan with one shared bucket set.  n_srs bases, MSM over [base_off, base_off + n).
+template <class C>
+static void run_table(const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int K0,
+                      int from_mont, uint32_t* out) {
+  CpuStepBackend be;
+  constexpr int AW = 2 * pc::Fd<typename C::FqP>::N;
+  const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, (uint32_t)c);
+  std::vector<uint32_t> table((size_t)Wd * n_srs * AW);
+  { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data()}; be.launch(b, n_srs); }
+  pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_min_n = 1;
+  if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3; }
+  pc::MsmPlan<C, CpuStepBackend> plan(be, n_srs, cfg);
+  plan.run(bases, base_off, scalars, n, from_mont != 0, out);
+}
+extern "C" void emu_msm_table(int curve, const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off,
+                              int c, int K0, int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: run_table<pc_curve_bls12_381>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out); break;
+    case 1: run_table<pc_curve_bn254>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out); break;
+    case 2: run_table<pc_curve_pallas>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out); break;
+  }
+}
+
 // field / curve unit hooks (32-bit limb code vs the 64-bit limb oracle)
 template <class P> static void fop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   typedef pc::Fd<P> F; F x = F::load(a), y = F::load(b), r;

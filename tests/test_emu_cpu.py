@@ -133,6 +133,34 @@ def test_msm_stepped_offset_and_montgomery():
     assert (run_msm(curve, b, mont, 0, 0, 0, 0, from_mont=1) == O.msm_naive(curve, b, s)).all()
 
 
+def run_msm_table(curve, b, s, c, K0=0, base_off=0, from_mont=0):
+    out = np.zeros(2 * O.fq_limbs(curve), dtype=np.uint64)
+    emu().emu_msm_table(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(len(b)), p32(s.view(np.uint32)), C.c_size_t(len(s)),
+                        base_off, c, K0, from_mont, p32(out.view(np.uint32)))
+    return out
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_window_table_mode_stepped(curve):
+    """pc_hip_srs_precompute: table[w][i] = 2^(c w) P_i, all digits into one shared bucket set --
+    same point as the table-free MSM, incl. a base offset (powers_of_g[lz..]), infinity and
+    repeated bases, all-(r-1) scalars (carry into the top digit) and Montgomery input."""
+    n = 150
+    r = R.FIELDS[curve + "_fr"]["p"]
+    b = O.gen_bases(curve, n)
+    b[5] = 0
+    b[11] = b[10]
+    s = O.gen_scalars(curve, 17, n)
+    want = O.msm_naive(curve, b, s)
+    for c, K0 in ((4, 2), (7, 0), (9, 16), (12, 4), (16, 0)):
+        assert (run_msm_table(curve, b, s, c, K0) == want).all(), (c, K0)
+    top = O.ints_to_limbs([r - 1] * n, 4)
+    assert (run_msm_table(curve, b, top, 8) == O.msm_naive(curve, b, top)).all()
+    assert (run_msm_table(curve, b, np.ascontiguousarray(s[:100]), 6, 2, base_off=50) == O.msm_naive(curve, b[50:], s[:100])).all()
+    assert (run_msm_table(curve, b, O.f_to_mont(curve, 1, s), 10, 0, from_mont=1) == want).all()
+    assert not run_msm_table(curve, b, np.zeros((n, 4), dtype=np.uint64), 5).any()
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_division_scan_stepped(curve):
     for n in (1, 2, 3, 64, 65, 130, 1000):

@@ -249,3 +249,69 @@ def test_rust_affine_layout_and_threads(ctx):
     for k in range(len(scal)):
         assert (got[k] == want[k]).all()
     srs.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_window_table_small(ctx, curve):
+    """pc_hip_srs_precompute: MSMs against the window table (one shared bucket set) return the
+    same points as the table-free path and the oracle -- several window widths, base offsets,
+    truncation, Montgomery scalars, infinity / repeated bases, short calls below min_pairs."""
+    n = 3000
+    bases = O.gen_bases(curve, n)
+    bases[7] = 0
+    bases[21] = bases[20]
+    s = O.gen_scalars(curve, 0x7AB1E, n)
+    want = O.msm_pippenger(curve, bases, s, 8, 1)
+    srs = ctx.upload_srs(curve, bases)
+    assert (srs.msm(s)[0] == want).all()
+    r = R.FIELDS[curve + "_fr"]["p"]
+    top = O.ints_to_limbs([r - 1] * n, 4)
+    for c in (0, 5, 9, 12, 16):
+        srs.precompute(window_bits=c, min_pairs=1)
+        assert (srs.msm(s)[0] == want).all(), c
+        assert (srs.msm(O.f_to_mont(curve, 1, s), montgomery=True)[0] == want).all(), c
+        assert (srs.msm(np.ascontiguousarray(s[:1000]), base_offset=500)[0] == O.msm_pippenger(curve, bases[500:], s[:1000], 8, 1)).all(), c
+        assert (srs.msm(top)[0] == O.msm_pippenger(curve, bases, top, 8, 1)).all(), c
+        got, inf = srs.msm(np.zeros((n, 4), dtype=np.uint64))
+        assert inf and not got.any()
+    # default threshold: calls shorter than a quarter of the SRS take the table-free path
+    srs.precompute()
+    assert (srs.msm(np.ascontiguousarray(s[:100]))[0] == O.msm_pippenger(curve, bases, s[:100], 8, 1)).all()
+    assert (srs.msm(s)[0] == want).all()
+    jobs = [srs.msm_async(s) for _ in range(4)]
+    assert all((j.wait()[0] == want).all() for j in jobs)
+    srs.free()
+
+
+def test_msm_window_table_2_20_and_fold_invalidation(ctx):
+    """Table mode at the bench size (auto c = 20, 13 digits) against the table-free result and the
+    closed form; pc_hip_ec_fold drops the table (the key changed) and later MSMs use the new key."""
+    import poly_commit_amd as pc
+    curve = "bls12_381"
+    n = (1 << 20) + 1
+    fr = R.FIELDS["bls12_381_fr"]["p"]
+    bases = O.gen_bases(curve, n)
+    s = O.gen_scalars(curve, 0x5EED0001, n)
+    srs = ctx.upload_srs(curve, bases)
+    plain, _ = srs.msm(s)
+    srs.precompute()
+    assert (srs.msm(s)[0] == plain).all()
+    ones = np.ascontiguousarray(O.ints_to_limbs([1], 4).repeat(n, axis=0))
+    assert (srs.msm(ones)[0] == pc.point_mul(curve, bases[0], O.fr_mont_array(curve, [n * (n + 1) // 2 % fr])[0])).all()
+    q = np.ascontiguousarray(s[: n - 1])
+    assert (srs.msm(q)[0] == O.msm_pippenger(curve, bases, q, 16, 1)).all()          # open-side length, same table
+    srs.free()
+    # fold: key' = lo + u * hi (ipa_pc/mod.rs:699-707) on a small key with a table
+    curve = "pallas"
+    m = 2048
+    kb = O.gen_bases(curve, m)
+    srs = ctx.upload_srs(curve, kb)
+    srs.precompute(min_pairs=1)
+    t = O.gen_scalars(curve, 9, m)
+    assert (srs.msm(t)[0] == O.msm_pippenger(curve, kb, t, 8, 1)).all()
+    u = O.f_to_mont(curve, 1, O.gen_scalars(curve, 10, 1))[0]
+    srs.ec_fold(m // 2, u)
+    folded = srs.read(0, m // 2)
+    t2 = np.ascontiguousarray(t[: m // 2])
+    assert (srs.msm(t2)[0] == O.msm_pippenger(curve, folded, t2, 8, 1)).all()
+    srs.free()
