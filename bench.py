@@ -348,6 +348,7 @@ def main():
                                    f"SRS resident, hiding off (BASELINE configs[1])",
                        "curve": curve, "log_degree": args.log_degree, "pairs_per_step": pairs_per_step,
                        "inflight": depth, "srs_window_table": bool(args.precompute),
+                       "srs_window_table_build_ms": eng.precompute_ms,    # once per key, outside the timed region
                        "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients sharded in {world} contiguous chunks, "
                                                                  f"all_gather of partial points"},
             "commit_open_per_s": args.steps / dt if world == 1 else None,

@@ -385,7 +385,8 @@ int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t
     srs->table = table;
     srs->cfg.tbl = table; srs->cfg.tbl_c = c; srs->cfg.tbl_stride = (uint32_t)srs->n;
     srs->cfg.tbl_min_n = min_pairs ? min_pairs : (srs->n + 3) / 4;
-    srs_lane(srs, 0);
+    try { srs_lane(srs, 0); }                     // workspace for the table geometry; on failure fall back
+    catch (...) { drop_table(srs); srs_lane(srs, 0); throw; }
     return (int)PC_OK;
   });
 }

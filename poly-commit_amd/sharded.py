@@ -45,8 +45,12 @@ class HipEngine:
 
     def load_srs(self, bases, precompute=False):
         self.srs = self.ctx.upload_srs(self.curve, np.ascontiguousarray(bases))
+        self.precompute_ms = None
         if precompute:          # window table in HBM (pc_hip_srs_precompute): once per key, like the upload
+            import time
+            t0 = time.perf_counter()
             self.srs.precompute()
+            self.precompute_ms = (time.perf_counter() - t0) * 1e3
 
     def _ptr(self, buf, elem_off=0):
         if isinstance(buf, np.ndarray):

@@ -5,6 +5,10 @@ timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -1
 timeout -k 10 600 python bench.py > gpurun_out/run_bench_n1.json 2>/dev/null
 timeout -k 10 600 python bench.py --inflight 0 --no-cpu-baseline > gpurun_out/run_bench_n1_inflight0.json 2>/dev/null
+timeout -k 10 600 python bench.py --precompute 0 --no-cpu-baseline > gpurun_out/run_bench_n1_notable.json 2>/dev/null
+timeout -k 10 600 python bench.py --precompute 0 --inflight 0 --no-cpu-baseline > gpurun_out/run_bench_n1_notable_inflight0.json 2>/dev/null
+timeout -k 10 300 python bench.py --log-degree 22 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/run_bench_2p22.json 2>/dev/null
+timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/run_lincomb.json
 timeout -k 10 600 python bench.py --workload ntt --steps 5 --warmup 1 > gpurun_out/run_bench_ntt.json 2>/dev/null
 timeout -k 10 600 python bench.py --workload batch --steps 2 --warmup 1 > gpurun_out/run_bench_batch.json 2>/dev/null
 timeout -k 10 300 python bench.py --log-degree 24 --steps 3 --warmup 1 > gpurun_out/run_bench_2p24.json 2>/dev/null
