@@ -106,6 +106,7 @@ struct HipBackend {
   void destroy() {
     if (scan_tmp) (void)hipFree(scan_tmp);
     if (sort_ws) (void)hipFree(sort_ws);
+    if (work_ws) (void)hipFree(work_ws);
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
     if (done) (void)hipEventDestroy(done);
     if (stream) (void)hipStreamDestroy(stream);
@@ -114,6 +115,15 @@ struct HipBackend {
 
   void* alloc(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 4)); return p; }
   void free(void* p) { if (p) (void)hipFree(p); }
+  // Grow-only scratch for the short kernels of one call (division scan levels): hipMalloc/hipFree per
+  // call would synchronise the whole device and drain the MSM pipelines running on other streams.
+  void* workspace(size_t bytes) {
+    if (bytes > work_ws_bytes) {
+      if (work_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(work_ws); work_ws = nullptr; work_ws_bytes = 0; }
+      PC_HIP_CHECK(hipMalloc(&work_ws, bytes)); work_ws_bytes = bytes;
+    }
+    return work_ws;
+  }
   void memset(void* p, int v, size_t bytes) { PC_HIP_CHECK(hipMemsetAsync(p, v, bytes, stream)); }
   void copy_d2d(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
   void copy_h2d(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream)); }
@@ -148,6 +158,7 @@ struct HipBackend {
   void sort_entries(const struct MsmGeom& g, const uint32_t* scalars, uint32_t* hist, uint32_t* offsets, uint32_t* cursor,
                     uint32_t* entries);
   void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
+  void* work_ws = nullptr; size_t work_ws_bytes = 0;
   int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
 
   // bucket accumulation with the neighbour merge of cut runs (msm_coop.hpp)

@@ -237,6 +237,12 @@ static int enqueue_job(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void*
   return PC_OK;
 }
 
+// fan-in of the upper levels of the division scan (tuning hook)
+static uint32_t scan_fan() {
+  static const uint32_t g = []() { const char* e = getenv("PC_HIP_SCAN_G"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2 ? v : 16); }();
+  return g;
+}
+
 // Forget the window table of an SRS (and the pipelines sized for it).  No job may be in flight.
 static void drop_table(pc_srs* srs) {
   if (!srs->table) return;
@@ -521,9 +527,9 @@ int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_
     Staged sout(ctx->be, out, where_out, n * 32, false);
     const uint32_t* z = (const uint32_t*)z_host; const uint32_t* cin = (const uint32_t*)carry_in_host;
     switch (field_of) {
-      case PC_CURVE_BLS12_381: pc::div_scan<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev); break;
-      case PC_CURVE_BN254: pc::div_scan<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev); break;
-      default: pc::div_scan<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev); break;
+      case PC_CURVE_BLS12_381: pc::div_scan<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan()); break;
+      case PC_CURVE_BN254: pc::div_scan<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan()); break;
+      default: pc::div_scan<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan()); break;
     }
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n * 32);
     return (int)PC_OK;
@@ -589,9 +595,9 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
     Staged sout(ctx->be, out, where_out, (n - 1) * 32, false);
     const uint32_t* z = (const uint32_t*)z_host;
     switch (field_of) {
-      case PC_CURVE_BLS12_381: pc::witness_polynomial<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
-      case PC_CURVE_BN254: pc::witness_polynomial<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
-      default: pc::witness_polynomial<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev); break;
+      case PC_CURVE_BLS12_381: pc::witness_polynomial<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan()); break;
+      case PC_CURVE_BN254: pc::witness_polynomial<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan()); break;
+      default: pc::witness_polynomial<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan()); break;
     }
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, (n - 1) * 32);
     return (int)PC_OK;

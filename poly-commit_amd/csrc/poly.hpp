@@ -52,7 +52,7 @@ struct ScanDownBody {
 // carry_in_host: one Montgomery Fr on the host, or null.  x / out are device pointers.
 template <class FrP, class Backend>
 void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* z_host, const uint32_t* carry_in_host,
-              uint32_t* out, uint32_t G = 64, uint32_t G0 = 8) {
+              uint32_t* out, uint32_t G = 16, uint32_t G0 = 8) {
   typedef Fd<FrP> F;
   if (count_in == 0) return;
   // A carry-in c is the same as one more (virtual) coefficient on top: acc = c + z*0 = c.
@@ -60,7 +60,8 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
   F z = F::load(z_host);
   // Level 0 touches every coefficient: short chunks (G0 = 8 -> 256 contiguous bytes per lane,
   // count0/8 lanes) keep it bandwidth-bound instead of latency-bound; upper levels are tiny and
-  // use fan-in G.
+  // latency-bound: fan-in G = 16 keeps every serial chain short (74 instead of 168 dependent
+  // steps per sweep at 2^20).
   std::vector<uint32_t> counts, fan; std::vector<F> factors;
   counts.push_back(count0); factors.push_back(z);
   do {
@@ -72,7 +73,7 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
   } while (counts.back() > 1);
   const size_t L = counts.size() - 1;                       // number of up-sweeps
   size_t total = 0; for (size_t k = 1; k <= L; k++) total += counts[k];
-  uint32_t* buf = (uint32_t*)be.alloc((2 * total + 2) * (size_t)FrP::N * 4);
+  uint32_t* buf = (uint32_t*)be.workspace((2 * total + 2) * (size_t)FrP::N * 4);   // cached: no per-call hipMalloc/hipFree
   std::vector<uint32_t*> B(L + 1), Cc(L + 1);
   uint32_t* cur = buf;
   for (size_t k = 1; k <= L; k++) { B[k] = cur; cur += (size_t)counts[k] * FrP::N; }
@@ -96,12 +97,11 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
     }
   }
   be.sync();
-  be.free(buf);
 }
 
 // q (n-1 elements) = p (n elements) / (x - z): q[i-1] = value after element i, i = n-1 .. 1.
 template <class FrP, class Backend>
-void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t G = 64,
+void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t G = 16,
                         uint32_t G0 = 8) {
   if (n <= 1) return;
   div_scan<FrP>(be, p + FrP::N, n - 1, z_host, nullptr, q, G, G0);

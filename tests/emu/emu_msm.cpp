@@ -15,6 +15,8 @@
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
   void free(void* p) { if (p) ::free(p); }
+  std::vector<uint8_t> ws;
+  void* workspace(size_t bytes) { if (ws.size() < bytes) ws.assign(bytes, 0); return ws.data(); }
   void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
   void mark() {}
   void record_done() {}
