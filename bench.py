@@ -292,6 +292,8 @@ def main():
         # commit and open of one polynomial; up to `depth` results stay in flight so that the
         # latency-bound tail of one MSM overlaps the bucket accumulation of the next
         pending.append(job.commit_async(coeffs, n))
+        if depth == 0:                       # strictly blocking calls: the commitment is back before the open starts
+            pending.popleft().result()
         pending.append(job.open_async(coeffs, n))
         while len(pending) > depth:
             pending.popleft().result()

@@ -16,6 +16,7 @@ timeout -k 10 200 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_o
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/run_prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --inflight 0 > $R/gpurun_out/run_prof.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/run_prof_notable -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --inflight 0 --precompute 0 > $R/gpurun_out/run_prof_notable.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/run_pmc_fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 0 > $R/gpurun_out/run_pmc_fetch.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/run_pmc_write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 0 > $R/gpurun_out/run_pmc_write.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/run_prof_ntt -o bench -- python $R/bench.py --workload ntt --steps 3 --warmup 1 > $R/gpurun_out/run_prof_ntt.log 2>&1
