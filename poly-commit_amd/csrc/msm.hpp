@@ -69,6 +69,7 @@ struct MsmGeom {
   uint32_t tbl_stride; // 0: classic (digit w goes to bucket set w and adds base i);  else the bases are a
                        // precomputed table T[w][i] = 2^(c w) P_i of `tbl_stride` points per window: digit w
                        // adds T[w][i] into the ONE shared bucket set (W == 1)
+  uint32_t pt_stride;  // words between consecutive points of the array the accumulate kernel gathers from
   PC_HD uint32_t key_window(uint32_t w) const { return tbl_stride ? 0u : w; }
   PC_HD uint32_t base_index(uint32_t w, uint32_t i) const { return tbl_stride ? w * tbl_stride + base_off + i : base_off + i; }
 };
@@ -196,11 +197,11 @@ struct AccumulateBody {
       Pt acc = Pt::infinity();
       bool first = true;
       uint32_t val = entries[s];
-      AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * AW);
+      AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * g.pt_stride);
       for (uint32_t p = s; p < e; p++) {
         // prefetch the next entry's base while this one is being added
         uint32_t nval = val; AffD<C> npt = pt;
-        if (p + 1 < e) { nval = entries[p + 1]; npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * AW); }
+        if (p + 1 < e) { nval = entries[p + 1]; npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride); }
         if (p == boundary) {
           flush(acc, k, s, e, t, first, k0, k1);
           first = false; acc = Pt::infinity();
@@ -397,13 +398,14 @@ template <class C>
 struct WindowTableBody {
   static constexpr int AW = 2 * Fd<typename C::FqP>::N;
   const uint32_t* bases; uint32_t n, c, Wd; uint32_t* table;
+  uint32_t stride;           // words per table entry (>= AW; 32 = one 128-byte line per 96-byte point)
   PC_HD void operator()(uint32_t i) const {
     AffD<C> p = AffD<C>::load(bases + (size_t)i * AW);
-    p.store(table + (size_t)i * AW);
+    p.store(table + (size_t)i * stride);
     JacD<C> acc = JacD<C>::infinity(); acc.add_affine(p);
     for (uint32_t w = 1; w < Wd; w++) {
       for (uint32_t k = 0; k < c; k++) acc = acc.dbl();
-      acc.to_affine().store(table + ((size_t)w * n + i) * AW);
+      acc.to_affine().store(table + ((size_t)w * n + i) * stride);
     }
   }
 };
@@ -435,6 +437,7 @@ struct MsmConfig {
   // pairs run with window width tbl_c against tbl[w][i] = 2^(tbl_c w) P_i and ONE shared bucket set.
   const uint32_t* tbl = nullptr;
   uint32_t tbl_c = 0, tbl_stride = 0;
+  uint32_t tbl_pt_stride = 0;            // words per table entry
   size_t tbl_min_n = 0;
   // The shared bucket set is denser where the short top digit lands (56 instead of 24 entries per
   // bucket at n = 2^20, c = 20): chunks of M / 2^18 = 52 entries would cut those buckets twice, which
@@ -617,6 +620,7 @@ class MsmPlan {
     uint32_t c = tbl ? cfg_.tbl_c : cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
     g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u;
     g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
+    g_.pt_stride = tbl ? cfg_.tbl_pt_stride : (uint32_t)AW;
     g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b;
     uint32_t m = g_.nb_win; n_levels_ = 0;
     uint32_t kbits = 0; arr_exp_.clear();

@@ -377,19 +377,23 @@ int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t
     const uint32_t c = window_bits ? window_bits : pc::msm_choose_table_c(srs->n, bits);
     const uint32_t Wd = pc::msm_num_windows(bits, c);
     if ((uint64_t)Wd * srs->n >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;     // entry = 31-bit table index + sign
-    const size_t bytes = (size_t)Wd * srs->n * srs->aw * 4;
+    // 96-byte points (BLS12-381) are padded to one 128-byte line each: a gather then touches one
+    // DRAM line instead of 1.5 on average (the table no longer fits the 256 MB MALL)
+    uint32_t pt_stride = (uint32_t)srs->aw;
+    if (const char* e = getenv("PC_HIP_TBL_PAD")) { if (atoi(e) && srs->aw == 24) pt_stride = 32; }
+    const size_t bytes = (size_t)Wd * srs->n * pt_stride * 4;
     uint32_t* table = (uint32_t*)ctx->be.alloc(bytes);
     try {
       switch (srs->curve) {
-        case PC_CURVE_BLS12_381: { pc::WindowTableBody<pc_curve_bls12_381> b{srs->bases, (uint32_t)srs->n, c, Wd, table}; ctx->be.launch(b, srs->n, 64); } break;
-        case PC_CURVE_BN254: { pc::WindowTableBody<pc_curve_bn254> b{srs->bases, (uint32_t)srs->n, c, Wd, table}; ctx->be.launch(b, srs->n, 64); } break;
-        default: { pc::WindowTableBody<pc_curve_pallas> b{srs->bases, (uint32_t)srs->n, c, Wd, table}; ctx->be.launch(b, srs->n, 64); } break;
+        case PC_CURVE_BLS12_381: { pc::WindowTableBody<pc_curve_bls12_381> b{srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride}; ctx->be.launch(b, srs->n, 64); } break;
+        case PC_CURVE_BN254: { pc::WindowTableBody<pc_curve_bn254> b{srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride}; ctx->be.launch(b, srs->n, 64); } break;
+        default: { pc::WindowTableBody<pc_curve_pallas> b{srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride}; ctx->be.launch(b, srs->n, 64); } break;
       }
       ctx->be.sync();
     } catch (...) { ctx->be.free(table); throw; }
     for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
     srs->table = table;
-    srs->cfg.tbl = table; srs->cfg.tbl_c = c; srs->cfg.tbl_stride = (uint32_t)srs->n;
+    srs->cfg.tbl = table; srs->cfg.tbl_c = c; srs->cfg.tbl_stride = (uint32_t)srs->n; srs->cfg.tbl_pt_stride = pt_stride;
     srs->cfg.tbl_min_n = min_pairs ? min_pairs : (srs->n + 3) / 4;
     try { srs_lane(srs, 0); }                     // workspace for the table geometry; on failure fall back
     catch (...) { drop_table(srs); srs_lane(srs, 0); throw; }

@@ -87,9 +87,10 @@ static void run_table(const uint32_t* bases, size_t n_srs, const uint32_t* scala
   CpuStepBackend be;
   constexpr int AW = 2 * pc::Fd<typename C::FqP>::N;
   const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, (uint32_t)c);
-  std::vector<uint32_t> table((size_t)Wd * n_srs * AW);
-  { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data()}; be.launch(b, n_srs); }
-  pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_min_n = 1;
+  const uint32_t stride = AW + 8;             // padded entries, as the 128-byte-aligned BLS12-381 table
+  std::vector<uint32_t> table((size_t)Wd * n_srs * stride);
+  { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data(), stride}; be.launch(b, n_srs); }
+  pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_pt_stride = stride; cfg.tbl_min_n = 1;
   if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3; }
   pc::MsmPlan<C, CpuStepBackend> plan(be, n_srs, cfg);
   plan.run(bases, base_off, scalars, n, from_mont != 0, out);
