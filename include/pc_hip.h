@@ -109,6 +109,18 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
 
 
+/* Many short MSMs over the SAME bases in one pass:
+ *   out[k] = sum_{j < m} scalars[k][j] * bases[base_offset + j],   k < n_msms,
+ * scalars = n_msms x m elements, contiguous.  This is HyraxPC::commit's "one multi-commitment per
+ * row" (poly-commit/src/hyrax/mod.rs:233-242: pedersen_commit(&ck.com_key, row) per matrix row,
+ * :86-93, inside a par_iter) -- sqrt(n) MSMs of sqrt(n) pairs, each far below the latency floor of
+ * a stand-alone launch sequence (~1 ms).  The m bases get a small window table (built on the first
+ * call, cached per (base_offset, m, n_msms)); MSM k owns bucket set k of one shared sort /
+ * accumulate / reduce pipeline; results are folded per MSM on the device and normalised with one
+ * inversion.  out_xy: n_msms affine points; out_is_infinity: n_msms flags or NULL. */
+int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form, pc_mem where,
+                    size_t m, size_t n_msms, void* out_xy, int* out_is_infinity);
+
 /* Enable/disable hipEvent phase timing on this ctx (off by default). */
 int pc_hip_set_timing(pc_ctx* ctx, int on);
 

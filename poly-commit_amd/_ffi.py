@@ -64,6 +64,7 @@ def load_library():
     lib.pc_hip_msm.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip)]
     lib.pc_hip_msm_batch.argtypes = [vp, vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), sz, ip, ip, vp,
                                      C.POINTER(ip)]
+    lib.pc_hip_msm_many.argtypes = [vp, vp, sz, vp, ip, ip, sz, sz, vp, C.POINTER(ip)]
     lib.pc_hip_msm_async.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip), C.POINTER(vp)]
     lib.pc_hip_job_wait.argtypes = [vp, vp]
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
@@ -315,6 +316,20 @@ class Srs:
                                                PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
                                                where, n, C.c_void_p(out.ctypes.data), C.byref(inf)))
         return out, bool(inf.value)
+
+    def msm_many(self, scalars, m=None, n_msms=None, base_offset=0, montgomery=False):
+        """n_msms MSMs of m pairs over bases[base_offset : base_offset + m] (pc_hip_msm_many; Hyrax's
+        one commitment per matrix row).  scalars: (n_msms, m, 4) uint64 host array or a device pointer.
+        Returns ((n_msms, 2*Fq limbs) uint64 affine points, (n_msms,) infinity flags)."""
+        p, where = _ptr(scalars)
+        if m is None:
+            n_msms, m = scalars.shape[0], scalars.shape[1]
+        out = np.zeros((n_msms, 2 * FQ_BYTES[self.curve] // 8), dtype=np.uint64)
+        inf = (C.c_int * max(n_msms, 1))()
+        self.ctx.check(self.ctx.lib.pc_hip_msm_many(self.ctx.h, self.h, base_offset, p,
+                                                    PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL, where, m, n_msms,
+                                                    C.c_void_p(out.ctypes.data), inf))
+        return out, np.array(list(inf)[:n_msms], dtype=bool)
 
     def msm_batch(self, scalar_ptrs, lens, base_offsets=None, montgomery=True):
         """pc_hip_msm_batch over device pointers: k scalar vectors against this SRS -> (k, 2*Fq) points."""

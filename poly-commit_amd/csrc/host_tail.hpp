@@ -130,5 +130,29 @@ void horner_to_affine(std::vector<WeightedPoint>& items, uint32_t* out_affine) {
   acc.store_affine(out_affine);
 }
 
+// count XYZZ points -> count affine points (x||y Montgomery, (0,0) = infinity) with ONE field
+// inversion (Montgomery's trick over the products ZZ*ZZZ).
+template <class C>
+void batch_to_affine(const uint32_t* xyzz, size_t count, uint32_t* out_affine) {
+  typedef Xyzz64<C> P; typedef typename P::Fq Fq;
+  constexpr int FW = P::FW;
+  std::vector<Fq> prefix(count);
+  Fq run = Fq::one();
+  for (size_t i = 0; i < count; i++) {
+    P p = P::load(xyzz + i * 4 * FW);
+    prefix[i] = run;
+    if (!p.is_inf()) run = run.mul(p.ZZ.mul(p.ZZZ));
+  }
+  Fq inv = run.inv();
+  for (size_t i = count; i-- > 0;) {
+    P p = P::load(xyzz + i * 4 * FW);
+    uint32_t* o = out_affine + i * 2 * FW;
+    if (p.is_inf()) { memset(o, 0, 2 * FW * 4); continue; }
+    Fq t = inv.mul(prefix[i]);                 // 1 / (ZZ * ZZZ) of point i
+    inv = inv.mul(p.ZZ.mul(p.ZZZ));
+    p.X.mul(t.mul(p.ZZZ)).store(o); p.Y.mul(t.mul(p.ZZ)).store(o + FW);
+  }
+}
+
 }  // namespace host64
 }  // namespace pc

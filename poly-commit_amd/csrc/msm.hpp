@@ -70,8 +70,12 @@ struct MsmGeom {
                        // precomputed table T[w][i] = 2^(c w) P_i of `tbl_stride` points per window: digit w
                        // adds T[w][i] into the ONE shared bucket set (W == 1)
   uint32_t pt_stride;  // words between consecutive points of the array the accumulate kernel gathers from
-  PC_HD uint32_t key_window(uint32_t w) const { return tbl_stride ? 0u : w; }
-  PC_HD uint32_t base_index(uint32_t w, uint32_t i) const { return tbl_stride ? w * tbl_stride + base_off + i : base_off + i; }
+  uint32_t m_sub;      // 0: one MSM.  else the n scalars are n / m_sub independent MSMs of m_sub pairs over the SAME
+                       // bases (table mode only): sub-MSM s owns bucket set s, scalar i adds table[w][i mod m_sub]
+  PC_HD uint32_t key_window(uint32_t w, uint32_t sub) const { return m_sub ? sub : tbl_stride ? 0u : w; }
+  PC_HD uint32_t base_index(uint32_t w, uint32_t j) const { return tbl_stride ? w * tbl_stride + base_off + j : base_off + j; }
+  // scalar i -> (sub-MSM, position inside it)
+  PC_HD void split(uint32_t i, uint32_t& sub, uint32_t& j) const { if (m_sub) { sub = i / m_sub; j = i - sub * m_sub; } else { sub = 0; j = i; } }
 };
 
 PC_HD uint32_t msm_num_windows(uint32_t bits, uint32_t c) { return bits / c + 1; }
@@ -106,13 +110,13 @@ struct DigitsHistBody {
   uint32_t* hist;            // NB counters (zeroed)
   PC_HD void operator()(uint32_t i) const {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
-    uint32_t carry = 0;
+    uint32_t carry = 0, sub, j; g.split(i, sub, j);
     const uint32_t half = 1u << (g.c - 1);
     for (uint32_t w = 0; w < g.Wd; w++) {
       uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
-      if (mag) atomic_inc_u32(hist + (size_t)g.key_window(w) * g.nb_win + (mag - 1));
+      if (mag) atomic_inc_u32(hist + (size_t)g.key_window(w, sub) * g.nb_win + (mag - 1));
     }
   }
 };
@@ -129,15 +133,15 @@ struct ScatterBody {
   uint32_t* entries;         // M = offsets[NB] slots
   PC_HD void operator()(uint32_t i) const {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
-    uint32_t carry = 0;
+    uint32_t carry = 0, sub, j; g.split(i, sub, j);
     const uint32_t half = 1u << (g.c - 1);
     for (uint32_t w = 0; w < g.Wd; w++) {
       uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
       if (mag) {
-        uint32_t pos = atomic_inc_u32(cursor + (size_t)g.key_window(w) * g.nb_win + (mag - 1));
-        entries[pos] = g.base_index(w, i) | (carry << 31);
+        uint32_t pos = atomic_inc_u32(cursor + (size_t)g.key_window(w, sub) * g.nb_win + (mag - 1));
+        entries[pos] = g.base_index(w, j) | (carry << 31);
       }
     }
   }
@@ -420,6 +424,30 @@ inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255) {
   return best;
 }
 
+// Many-MSM mode: after the bucket reduction every sub-MSM s holds `narr` partial sums P_a[s] with
+// weights 2^exp[a] (no window fold: the table put all windows into one bucket set).  One lane per
+// sub-MSM folds them with a short Horner chain (<= c doublings) -- B results, B lanes, one launch.
+// `order` lists the arrays by descending exponent.
+template <class C>
+struct SubFoldBody {
+  typedef XyzzD<C> Pt;
+  const uint32_t* arrays;    // narr arrays of W points each (array a at arrays + a * W * Pt::WORDS)
+  uint32_t W, narr;
+  uint32_t exp[32], order[32];
+  uint32_t* out;             // W XYZZ points
+  PC_HD void operator()(uint32_t s) const {
+    Pt acc = Pt::infinity();
+    uint32_t cur = narr ? exp[order[0]] : 0;
+    for (uint32_t t = 0; t < narr; t++) {
+      const uint32_t a = order[t];
+      for (; cur > exp[a]; cur--) acc = acc.dbl();
+      acc.add(Pt::load(arrays + ((size_t)a * W + s) * Pt::WORDS));
+    }
+    for (; cur > 0; cur--) acc = acc.dbl();
+    acc.store(out + (size_t)s * Pt::WORDS);
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 // Orchestration
 // ---------------------------------------------------------------------------------------
@@ -481,7 +509,10 @@ class MsmPlan {
   typedef typename C::FrP FrP;
   static constexpr int AW = 2 * Fd<typename C::FqP>::N;
 
-  MsmPlan(Backend& be, size_t n_max, const MsmConfig& cfg) : be_(be), cfg_(cfg), n_max_(n_max) {
+  // subs == 0: one MSM of up to n_max pairs per call.  subs == B > 0: every call is B independent MSMs of
+  // n_max / B pairs over the same bases (cfg.tbl must hold their window table); see enqueue().
+  MsmPlan(Backend& be, size_t n_max, const MsmConfig& cfg, uint32_t subs = 0) : be_(be), cfg_(cfg), n_max_(n_max), subs_(subs) {
+    if (subs_ && (!cfg_.tbl || !cfg_.tbl_c || n_max % subs_)) throw std::runtime_error("MsmPlan: many-MSM mode needs a window table");
     if (cfg_.T2 < 4) cfg_.T2 = 4;       // each level must shrink the list: 2*ceil(s/T2) < s
     if (cfg_.T2b < 4) cfg_.T2b = 4;
     if (cfg_.K0 < 2) cfg_.K0 = 2;
@@ -490,7 +521,7 @@ class MsmPlan {
     // The window width is chosen per call from the call's n (a resident SRS serves MSMs of many
     // lengths: KZG opens, IPA halving rounds).  Size every buffer for the worst call n <= n_max.
     size_t NBmax = 1, Mmax = 1, red_max = 1, res_max = 1;
-    for (size_t n = 1;; n = (n * 2 < n_max) ? n * 2 : n_max) {
+    for (size_t n = subs_ ? n_max : 1;; n = (n * 2 < n_max) ? n * 2 : n_max) {
       plan_geometry(n);
       NBmax = std::max<size_t>(NBmax, g_.NB);
       Mmax = std::max<size_t>(Mmax, n * (size_t)g_.Wd);
@@ -524,8 +555,9 @@ class MsmPlan {
       pp_[i] = (uint32_t*)be_.alloc(slots * (size_t)Pt::WORDS * 4);
       slots = 2 * (size_t)ceil_div_u32(slots, cfg_.T2);
     }
-    red_ = (uint32_t*)be_.alloc(red_max * (size_t)Pt::WORDS * 4);
-    result_host_ = (uint32_t*)be_.alloc_host(res_max * Pt::WORDS * 4);
+    red_ = (uint32_t*)be_.alloc((red_max + subs_) * (size_t)Pt::WORDS * 4);       // + the folded sub-MSM results
+    result_host_ = (uint32_t*)be_.alloc_host(std::max<size_t>(res_max, subs_) * Pt::WORDS * 4);
+    red_points_ = red_max;
     } catch (...) { release(); throw; }   // a failed hipMalloc must not leak the earlier buffers
     plan_geometry(n_max);
   }
@@ -557,6 +589,7 @@ class MsmPlan {
     plan_geometry(n);
     MsmGeom g = g_;
     g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
+    g.m_sub = subs_ ? (uint32_t)(n / subs_) : 0u;
     const size_t Mmax = n * g.Wd;
     uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / (g.tbl_stride ? cfg_.tbl_target_lanes : cfg_.target_lanes));
     if (T < min_T_) T = min_T_;
@@ -601,13 +634,31 @@ class MsmPlan {
     }
     be_.mark();   // 6: bucket reduction
     // download: the last level holds W points per array, S first
-    if (n_levels_ == 0) be_.copy_d2h_async(result_host_, buckets_, (size_t)g.W * Pt::WORDS * 4);
+    if (subs_) {
+      // many-MSM mode: fold each sub-MSM's few weighted sums on the device, download one XYZZ point each
+      SubFoldBody<C> f;
+      f.arrays = n_levels_ ? prev_base + (size_t)g.W * Pt::WORDS : buckets_;
+      f.W = g.W; f.narr = n_levels_ ? (uint32_t)arr_exp_.size() : 1u;
+      if (f.narr > 32) throw std::runtime_error("MsmPlan: too many reduction arrays");
+      for (uint32_t a = 0; a < f.narr; a++) { f.exp[a] = n_levels_ ? arr_exp_[a] : 0u; f.order[a] = a; }
+      std::stable_sort(f.order, f.order + f.narr, [&](uint32_t x, uint32_t y) { return f.exp[x] > f.exp[y]; });
+      f.out = red_ + red_points_ * Pt::WORDS;
+      be_.launch(f, g.W);
+      be_.copy_d2h_async(result_host_, f.out, (size_t)g.W * Pt::WORDS * 4);
+    }
+    else if (n_levels_ == 0) be_.copy_d2h_async(result_host_, buckets_, (size_t)g.W * Pt::WORDS * 4);
     else be_.copy_d2h_async(result_host_, prev_base + (size_t)g.W * Pt::WORDS, (size_t)g.W * lvl_narr_[n_levels_ - 1] * Pt::WORDS * 4);
     be_.record_done();
   }
 
   // Wait for the queued MSM and fold its partial sums on the host (Horner) into one affine point.
   void finish(uint32_t* out_host) {
+    if (subs_) {      // subs_ affine points: batch-normalise the folded XYZZ results (one inversion in all)
+      if (pending_empty_) { for (size_t i = 0; i < (size_t)subs_ * AW; i++) out_host[i] = 0; return; }
+      be_.wait_done();
+      host64::batch_to_affine<C>(result_host_, subs_, out_host);
+      return;
+    }
     if (pending_empty_) { for (int i = 0; i < AW; i++) out_host[i] = 0; return; }
     be_.wait_done();
     host_tail(out_host);
@@ -616,9 +667,9 @@ class MsmPlan {
  private:
   // window width, bucket counts and the reduction-level plan for a call of n pairs
   void plan_geometry(size_t n) {
-    const bool tbl = cfg_.tbl && cfg_.tbl_c && n >= cfg_.tbl_min_n;
+    const bool tbl = subs_ || (cfg_.tbl && cfg_.tbl_c && n >= cfg_.tbl_min_n);
     uint32_t c = tbl ? cfg_.tbl_c : cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
-    g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u;
+    g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = subs_ ? subs_ : tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u; g_.m_sub = 0;
     g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.pt_stride = tbl ? cfg_.tbl_pt_stride : (uint32_t)AW;
     g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b;
@@ -664,6 +715,8 @@ class MsmPlan {
   Backend& be_;
   MsmConfig cfg_;
   size_t n_max_;
+  uint32_t subs_ = 0;
+  size_t red_points_ = 0;
   MsmGeom g_;
   uint32_t min_T_;
   size_t part_slots_ = 0;

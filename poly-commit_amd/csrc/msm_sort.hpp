@@ -20,7 +20,7 @@
 namespace pc {
 
 struct SortGeom {
-  uint32_t n, c, W, nb_win, NB, base_off, from_mont, Wd, tbl_stride;
+  uint32_t n, c, W, nb_win, NB, base_off, from_mont, Wd, tbl_stride, m_sub;
   uint32_t fine_bits, cb, ncw /* coarse bins per window */, NC /* total coarse bins */, S /* scalars per block */, nblocks;
   uint32_t top_w, top_fine_bits;   // the last window only uses 2^(tb-1) buckets: it gets its own (smaller) fine width
 };
@@ -28,7 +28,7 @@ struct SortGeom {
 inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   SortGeom s;
   s.n = g.n; s.c = g.c; s.W = g.W; s.nb_win = g.nb_win; s.NB = g.NB; s.base_off = g.base_off; s.from_mont = g.from_mont;
-  s.Wd = g.Wd; s.tbl_stride = g.tbl_stride;
+  s.Wd = g.Wd; s.tbl_stride = g.tbl_stride; s.m_sub = g.m_sub;
   uint32_t bbits = g.c - 1;                               // bucket bits per window
   uint32_t cb_max = 0; while ((2u << cb_max) * g.W <= 32768u) cb_max++;
   uint32_t cb = bbits > 8 ? bbits - 8 : 0;
@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
   const uint32_t half = 1u << (sg.c - 1);
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, sg.from_mont);
-    uint32_t carry = 0;
+    uint32_t carry = 0, sub = 0, j = i;
+    if (sg.m_sub) { sub = i / sg.m_sub; j = i - sub * sg.m_sub; }      // many-MSM mode: bucket set `sub`
     for (uint32_t w = 0; w < sg.Wd; w++) {
       uint32_t raw = sd.bits_at(w * sg.c, sg.c) + carry;
       carry = raw > half;
@@ -73,9 +74,9 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
         const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
         uint32_t b = mag - 1, cbin = b >> fb;
         if (cbin >= sg.ncw) cbin = sg.ncw - 1;           // (top window, magnitude 2^(tb-1): one past its range)
-        uint32_t bin = (sg.tbl_stride ? 0u : w * sg.ncw) + cbin;
+        uint32_t bin = (sg.m_sub ? sub * sg.ncw : sg.tbl_stride ? 0u : w * sg.ncw) + cbin;
         uint32_t pos = atomicAdd(&cnt[bin], 1u);
-        const uint32_t base = sg.tbl_stride ? w * sg.tbl_stride + sg.base_off + i : sg.base_off + i;
+        const uint32_t base = sg.tbl_stride ? w * sg.tbl_stride + sg.base_off + j : sg.base_off + j;
         if (SCATTER) records[pos] = make_uint2(base | (carry << 31), b - (cbin << fb));
       }
     }

@@ -19,7 +19,9 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   if (sort_mode < 0) { const char* e = getenv("PC_HIP_SORT"); sort_mode = (e && !strcmp(e, "atomic")) ? 0 : 1; }
   if (sort_mode == 0) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }
   SortGeom sg = make_sort_geom(g, C::FrP::BITS);
-  if (sg.fine_bits > 10) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }   // c > 22
+  if (sg.fine_bits > 10 || sg.NC > 16384) {   // c > 22, or more bucket sets than the LDS histogram holds
+    sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return;
+  }
   // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)
   const size_t gw = (size_t)sg.nblocks * sg.NC, nb1 = (size_t)sg.NC + 1;
   const size_t rec_off = ((gw + 2 * nb1) * 4 + 15) & ~(size_t)15;
@@ -100,7 +102,7 @@ template <class C>
 struct MsmRunnerT : MsmRunner {
   pc::HipBackend& be;
   pc::MsmPlan<C, pc::HipBackend> plan;
-  MsmRunnerT(pc::HipBackend& b, size_t n, const pc::MsmConfig& cfg) : be(b), plan(b, n, cfg) {}
+  MsmRunnerT(pc::HipBackend& b, size_t n, const pc::MsmConfig& cfg, uint32_t subs = 0) : be(b), plan(b, n, cfg, subs) {}
   void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) override {
     const uint32_t* sdev = (const uint32_t*)scalars;
     be.n_ev = 0; be.mark();
@@ -161,6 +163,8 @@ struct pc_srs {
   pc::MsmConfig cfg;
   MsmLane* lanes[PC_MSM_LANES] = {nullptr, nullptr, nullptr};
   int next_lane = 0;
+  // pc_hip_msm_many: window table of bases[base_offset .. base_offset + m) and the pipeline sized for B x m
+  struct Many { size_t base_offset = 0, m = 0, B = 0; uint32_t* table = nullptr; MsmLane* lane = nullptr; } many;
 };
 struct pc_job {
   pc_srs* srs = nullptr; int lane = 0;
@@ -241,6 +245,12 @@ static int enqueue_job(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void*
 static uint32_t scan_fan() {
   static const uint32_t g = []() { const char* e = getenv("PC_HIP_SCAN_G"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2 ? v : 16); }();
   return g;
+}
+
+static void drop_many(pc_srs* srs) {
+  delete srs->many.lane; srs->many.lane = nullptr;
+  if (srs->many.table) (void)hipFree(srs->many.table);
+  srs->many.table = nullptr; srs->many.m = srs->many.B = srs->many.base_offset = 0;
 }
 
 // Forget the window table of an SRS (and the pipelines sized for it).  No job may be in flight.
@@ -363,6 +373,7 @@ void pc_hip_srs_free(pc_srs* srs) {
   }
   if (srs->bases) (void)hipFree(srs->bases);
   if (srs->table) (void)hipFree(srs->table);
+  drop_many(srs);
   delete srs;
 }
 int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {
@@ -455,6 +466,57 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
       if (rc != PC_OK) { for (size_t j = 0; j < k; j++) if (!jobs[j].done) complete_job(ctx, &jobs[j]); return rc; }
     }
     for (size_t k = 0; k < n_polys; k++) if (!jobs[k].done) complete_job(ctx, &jobs[k]);
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form, pc_mem where,
+                    size_t m, size_t n_msms, void* out_xy, int* out_is_infinity) {
+  if (!ctx || !srs || srs->ctx != ctx || !out_xy || (m && n_msms && !scalars)) return PC_ERR_INVALID_ARG;
+  if (base_offset > srs->n || m > srs->n - base_offset) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    const size_t pb = (size_t)srs->aw * 4;
+    if (!n_msms) return (int)PC_OK;
+    if (!m) { memset(out_xy, 0, n_msms * pb); if (out_is_infinity) for (size_t k = 0; k < n_msms; k++) out_is_infinity[k] = 1; return (int)PC_OK; }
+    const uint32_t bits = srs->curve == PC_CURVE_BN254 ? 254u : 255u;
+    const uint32_t c = pc::msm_choose_table_c(m, bits), Wd = pc::msm_num_windows(bits, c);
+    if ((uint64_t)n_msms * m * Wd >= (1ull << 31) || ((uint64_t)n_msms << (c - 1)) >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;
+    pc_srs::Many& M = srs->many;
+    if (!M.lane || M.base_offset != base_offset || M.m != m || M.B != n_msms) {
+      drop_many(srs);
+      uint32_t* table = (uint32_t*)ctx->be.alloc((size_t)Wd * m * pb);
+      MsmLane* L = nullptr;
+      try {
+        const uint32_t* b0 = srs->bases + base_offset * srs->aw;
+        switch (srs->curve) {
+          case PC_CURVE_BLS12_381: { pc::WindowTableBody<pc_curve_bls12_381> b{b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw}; ctx->be.launch(b, m, 64); } break;
+          case PC_CURVE_BN254: { pc::WindowTableBody<pc_curve_bn254> b{b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw}; ctx->be.launch(b, m, 64); } break;
+          default: { pc::WindowTableBody<pc_curve_pallas> b{b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw}; ctx->be.launch(b, m, 64); } break;
+        }
+        ctx->be.sync();
+        pc::MsmConfig cfg = srs->cfg;
+        cfg.c = 0; cfg.T = 0; cfg.tbl = table; cfg.tbl_c = c; cfg.tbl_stride = (uint32_t)m; cfg.tbl_pt_stride = (uint32_t)srs->aw; cfg.tbl_min_n = 0;
+        L = new MsmLane();
+        L->be.init();
+        switch (srs->curve) {
+          case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, n_msms * m, cfg, (uint32_t)n_msms); break;
+          case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, n_msms * m, cfg, (uint32_t)n_msms); break;
+          default: L->runner = new MsmRunnerT<pc_curve_pallas>(L->be, n_msms * m, cfg, (uint32_t)n_msms); break;
+        }
+      } catch (...) { delete L; ctx->be.free(table); throw; }
+      M.table = table; M.lane = L; M.base_offset = base_offset; M.m = m; M.B = n_msms;
+    }
+    MsmLane* L = M.lane;
+    L->be.timing = ctx->be.timing;
+    L->runner->enqueue(srs->bases, 0, scalars, where, n_msms * m, form == PC_SCALARS_MONTGOMERY);
+    L->runner->finish((uint32_t*)out_xy);
+    if (out_is_infinity) {
+      const uint32_t* o = (const uint32_t*)out_xy;
+      for (size_t k = 0; k < n_msms; k++) { uint32_t acc = 0; for (int i = 0; i < srs->aw; i++) acc |= o[k * srs->aw + i]; out_is_infinity[k] = acc == 0; }
+    }
+    for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
+    if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
     return (int)PC_OK;
   });
 }
@@ -825,7 +887,8 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) 
     for (int i = 0; i < PC_MSM_LANES; i++)      // queued MSMs still read the old key
       if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
     if (!n_half) return (int)PC_OK;
-    drop_table(srs);                            // the key changes: its window table is stale
+    drop_table(srs);                            // the key changes: its window tables are stale
+    drop_many(srs);
     switch (srs->curve) {
       case PC_CURVE_BLS12_381: ec_fold_t<pc_curve_bls12_381>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
       case PC_CURVE_BN254: ec_fold_t<pc_curve_bn254>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;

@@ -104,6 +104,28 @@ extern "C" void emu_msm_table(int curve, const uint32_t* bases, size_t n_srs, co
   }
 }
 
+// many-MSM mode (pc_hip_msm_many): B independent MSMs of m pairs over the same m bases.
+template <class C>
+static void run_many(const uint32_t* bases, size_t m, const uint32_t* scalars, size_t B, int c, int K0, int from_mont, uint32_t* out) {
+  CpuStepBackend be;
+  constexpr int AW = 2 * pc::Fd<typename C::FqP>::N;
+  const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, (uint32_t)c);
+  std::vector<uint32_t> table((size_t)Wd * m * AW);
+  { pc::WindowTableBody<C> b{bases, (uint32_t)m, (uint32_t)c, Wd, table.data(), (uint32_t)AW}; be.launch(b, m); }
+  pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)m; cfg.tbl_pt_stride = AW; cfg.tbl_min_n = 1;
+  if (K0) { cfg.tbl_K0 = K0; cfg.K1 = K0 == 2 ? 4 : 16; cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3; }
+  pc::MsmPlan<C, CpuStepBackend> plan(be, B * m, cfg, (uint32_t)B);
+  plan.run(bases, 0, scalars, B * m, from_mont != 0, out);
+}
+extern "C" void emu_msm_many(int curve, const uint32_t* bases, size_t m, const uint32_t* scalars, size_t B, int c, int K0,
+                             int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: run_many<pc_curve_bls12_381>(bases, m, scalars, B, c, K0, from_mont, out); break;
+    case 1: run_many<pc_curve_bn254>(bases, m, scalars, B, c, K0, from_mont, out); break;
+    case 2: run_many<pc_curve_pallas>(bases, m, scalars, B, c, K0, from_mont, out); break;
+  }
+}
+
 // field / curve unit hooks (32-bit limb code vs the 64-bit limb oracle)
 template <class P> static void fop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   typedef pc::Fd<P> F; F x = F::load(a), y = F::load(b), r;

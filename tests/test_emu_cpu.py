@@ -162,6 +162,32 @@ def test_msm_window_table_mode_stepped(curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_msm_many_mode_stepped(curve):
+    """pc_hip_msm_many (Hyrax's one-MSM-per-matrix-row, hyrax/mod.rs:233-242): B MSMs over the same m
+    bases in one pass -- sub-MSM s owns bucket set s of the shared table pipeline; results folded per
+    sub-MSM and batch-normalised.  Rows that are all zero give infinity."""
+    m, B = 40, 7
+    b = O.gen_bases(curve, m)
+    b[3] = b[2]
+    s = O.gen_scalars(curve, 99, B * m).reshape(B, m, 4)
+    s[4] = 0
+    s[5, :, :] = s[5, :1, :]
+    want = np.stack([O.msm_naive(curve, b, np.ascontiguousarray(s[k])) for k in range(B)])
+    assert not want[4].any()
+    for c, K0 in ((4, 2), (6, 0), (8, 4), (11, 0)):
+        out = np.zeros((B, 2 * O.fq_limbs(curve)), dtype=np.uint64)
+        flat = np.ascontiguousarray(s.reshape(B * m, 4))
+        emu().emu_msm_many(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(m), p32(flat.view(np.uint32)), C.c_size_t(B), c, K0, 0,
+                           p32(out.view(np.uint32)))
+        assert (out == want).all(), (c, K0)
+    mont = O.f_to_mont(curve, 1, np.ascontiguousarray(s.reshape(B * m, 4)))
+    out = np.zeros((B, 2 * O.fq_limbs(curve)), dtype=np.uint64)
+    emu().emu_msm_many(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(m), p32(mont.view(np.uint32)), C.c_size_t(B), 5, 0, 1,
+                       p32(out.view(np.uint32)))
+    assert (out == want).all()
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_division_scan_stepped(curve):
     for n in (1, 2, 3, 64, 65, 130, 1000):
         for G in (2, 3, 64):

@@ -315,3 +315,58 @@ def test_msm_window_table_2_20_and_fold_invalidation(ctx):
     t2 = np.ascontiguousarray(t[: m // 2])
     assert (srs.msm(t2)[0] == O.msm_pippenger(curve, folded, t2, 8, 1)).all()
     srs.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_many_small(ctx, curve):
+    """pc_hip_msm_many: B MSMs over the same m bases == B separate oracle MSMs; zero rows give infinity;
+    base offset; Montgomery scalars; a second call reuses the cached table; a different shape rebuilds."""
+    m, B = 200, 37
+    bases = O.gen_bases(curve, m + 50)
+    bases[60] = bases[59]
+    srs = ctx.upload_srs(curve, bases)
+    s = O.gen_scalars(curve, 0x4A11, B * m).reshape(B, m, 4)
+    s[5] = 0
+    s[6, :, :] = s[6, :1, :]
+    r = R.FIELDS[curve + "_fr"]["p"]
+    s[7] = O.ints_to_limbs([r - 1] * m, 4)
+    s = np.ascontiguousarray(s)
+    for off in (0, 50):
+        want = np.stack([O.msm_pippenger(curve, bases[off:off + m], np.ascontiguousarray(s[k]), 4, 1) for k in range(B)])
+        got, inf = srs.msm_many(s, base_offset=off)
+        assert (got == want).all(), off
+        assert inf[5] and inf.sum() == 1
+        got2, _ = srs.msm_many(O.f_to_mont(curve, 1, s.reshape(-1, 4)).reshape(B, m, 4), base_offset=off, montgomery=True)
+        assert (got2 == want).all()
+    # the ordinary MSM entry points are unaffected, and a different shape is served as well
+    assert (srs.msm(np.ascontiguousarray(s[0]))[0] == O.msm_pippenger(curve, bases, np.ascontiguousarray(s[0]), 4, 1)).all()
+    got3, _ = srs.msm_many(np.ascontiguousarray(s[:3, :64]))
+    assert (got3 == np.stack([O.msm_pippenger(curve, bases[:64], np.ascontiguousarray(s[k, :64]), 4, 1) for k in range(3)])).all()
+    got4, _ = srs.msm_many(np.ascontiguousarray(s[:1, :1]))
+    assert (got4[0] == O.msm_pippenger(curve, bases[:1], np.ascontiguousarray(s[0, :1]), 1, 1)).all()
+    srs.free()
+
+
+def test_msm_many_hyrax_shape_1024x1024(ctx):
+    """Hyrax's shape for 2^20 evaluations: 1024 row commitments of 1024 pairs each (hyrax/mod.rs:233-242),
+    one call.  Spot rows against the oracle; the sum of all rows against ONE big MSM with column-summed
+    scalars (linearity) -- a check that involves every row without 1024 oracle MSMs."""
+    import poly_commit_amd as pc
+    curve = "bn254"
+    m = B = 1024
+    fr = R.FIELDS["bn254_fr"]["p"]
+    bases = O.gen_bases(curve, m)
+    srs = ctx.upload_srs(curve, bases)
+    s = O.gen_scalars(curve, 0x4A12, B * m).reshape(B, m, 4)
+    got, inf = srs.msm_many(s)
+    assert not inf.any()
+    for k in (0, 511, 1023):
+        assert (got[k] == O.msm_pippenger(curve, bases, np.ascontiguousarray(s[k]), 8, 1)).all()
+    cols = [0] * m
+    ints = O.limbs_to_ints(s.reshape(-1, 4))
+    for k in range(B):
+        row = ints[k * m:(k + 1) * m]
+        cols = [(a + b) % fr for a, b in zip(cols, row)]
+    want_sum = O.msm_pippenger(curve, bases, O.ints_to_limbs(cols, 4), 8, 1)
+    assert (pc.points_sum(curve, got) == want_sum).all()
+    srs.free()
