@@ -97,6 +97,15 @@ struct HipBackend {
       for (int cu = 0; cu < ncu; cu++)
         if ((cu / 2) % cu_parts == cu_part) mask[cu / 32] |= 1u << (cu % 32);   // pairs of CUs (a WGP-like unit) stay together
       PC_HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data()));
+    } else if (tail_split) {
+      // Two queues per pipeline: sort + accumulate at high priority, the latency-bound reductions at
+      // low priority, so that a bucket accumulation arriving at a busy chip gets the CUs first.
+      int lo = 0, hi = 0;
+      PC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+      PC_HIP_CHECK(hipStreamCreateWithPriority(&tail_stream, hipStreamNonBlocking, lo));
+      PC_HIP_CHECK(hipEventCreateWithFlags(&tail_ev, hipEventDisableTiming));
+      main_stream = stream;
     } else {
       PC_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
@@ -109,6 +118,9 @@ struct HipBackend {
     if (work_ws) (void)hipFree(work_ws);
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
     if (done) (void)hipEventDestroy(done);
+    if (main_stream) stream = main_stream;
+    if (tail_stream) (void)hipStreamDestroy(tail_stream);
+    if (tail_ev) (void)hipEventDestroy(tail_ev);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void mark() { if (timing && n_ev < MAX_EV) PC_HIP_CHECK(hipEventRecord(ev[n_ev++], stream)); }
@@ -135,6 +147,15 @@ struct HipBackend {
   void copy_d2h_async(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); }
   void* alloc_host(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault)); return p; }
   void free_host(void* p) { if (p) (void)hipHostFree(p); }
+  // everything launched between begin_tail() and end_tail() goes to the low-priority queue, ordered
+  // after what was queued before
+  void begin_tail() {
+    if (!tail_stream) return;
+    PC_HIP_CHECK(hipEventRecord(tail_ev, main_stream));
+    PC_HIP_CHECK(hipStreamWaitEvent(tail_stream, tail_ev, 0));
+    stream = tail_stream;
+  }
+  void end_tail() { if (tail_stream) stream = main_stream; }
   void record_done() { PC_HIP_CHECK(hipEventRecord(done, stream)); }
   void wait_done() { PC_HIP_CHECK(hipEventSynchronize(done)); }
 
@@ -160,6 +181,10 @@ struct HipBackend {
   void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
   void* work_ws = nullptr; size_t work_ws_bytes = 0;
   int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
+  // Shared by the pipelines of one SRS: the bucket accumulations of different pipelines run one after
+  // another (each fills every CU by itself; two at once only slow each other), everything else overlaps.
+  hipEvent_t* acc_chain = nullptr; bool* acc_chain_armed = nullptr;
+  bool tail_split = false; hipStream_t main_stream = nullptr, tail_stream = nullptr; hipEvent_t tail_ev = nullptr;
 
   // bucket accumulation with the neighbour merge of cut runs (msm_coop.hpp)
   template <class C>

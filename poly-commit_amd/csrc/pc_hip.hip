@@ -42,7 +42,7 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   hipLaunchKernelGGL((k_sort_pass<C, false>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)nullptr, (uint2*)nullptr);
   PC_HIP_CHECK(hipGetLastError());
   mark();   // 1: digits + coarse histogram
-  hipLaunchKernelGGL(k_sort_binscan, dim3((sg.NC + 1 + 255) / 256), dim3(256), 0, stream, G, sg.nblocks, sg.NC, bintotal);
+  hipLaunchKernelGGL(k_sort_binscan, dim3((sg.NC + 15) / 16), dim3(256), 0, stream, G, sg.nblocks, sg.NC, bintotal);
   PC_HIP_CHECK(hipGetLastError());
   exclusive_scan_u32(bintotal, binbase, nb1);
   mark();   // 2: scans
@@ -56,8 +56,10 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
 template <class C>
 void HipBackend::accumulate(const AccumulateBody<C>& body, size_t lanes) {
   if (lanes == 0) return;
+  if (acc_chain && *acc_chain_armed) PC_HIP_CHECK(hipStreamWaitEvent(stream, *acc_chain, 0));
   hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, body, (uint32_t)lanes);
   PC_HIP_CHECK(hipGetLastError());
+  if (acc_chain) { PC_HIP_CHECK(hipEventRecord(*acc_chain, stream)); *acc_chain_armed = true; }
 }
 
 template <class C>
@@ -163,6 +165,7 @@ struct pc_srs {
   pc::MsmConfig cfg;
   MsmLane* lanes[PC_MSM_LANES] = {nullptr, nullptr, nullptr};
   int next_lane = 0;
+  hipEvent_t acc_chain = nullptr; bool acc_chain_armed = false;     // see HipBackend::acc_chain
   // pc_hip_msm_many: window table of bases[base_offset .. base_offset + m) and the pipeline sized for B x m
   struct Many { size_t base_offset = 0, m = 0, B = 0; uint32_t* table = nullptr; MsmLane* lane = nullptr; } many;
 };
@@ -197,7 +200,15 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
     // CU-partitioned pipelines are opt-in (PC_HIP_SPLIT_CUS=1): on this part a masked stream lost far
     // more throughput than the share of CUs it gave up (accumulate 3.65 ms on 256 CUs, 6.8 ms on 240).
     static const bool split = []() { const char* e = getenv("PC_HIP_SPLIT_CUS"); return e && e[0] == '1'; }();
+    // default on; PC_HIP_TAIL_PRIO=0 puts a pipeline back on one queue (measured 8.5-9.0 -> 7.7 ms/step at 2^20)
+    static const bool tsplit = []() { const char* e = getenv("PC_HIP_TAIL_PRIO"); return !(e && e[0] == '0'); }();
+    L->be.tail_split = tsplit;
     if (i == 0 || !split) L->be.init(); else L->be.init(i - 1, PC_MSM_LANES - 1);
+    static const bool chain = []() { const char* e = getenv("PC_HIP_ACC_CHAIN"); return e && e[0] == '1'; }();
+    if (chain) {
+      if (!srs->acc_chain) PC_HIP_CHECK(hipEventCreateWithFlags(&srs->acc_chain, hipEventDisableTiming));
+      L->be.acc_chain = &srs->acc_chain; L->be.acc_chain_armed = &srs->acc_chain_armed;
+    }
     switch (srs->curve) {
       case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, srs->n, srs->cfg); break;
       case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, srs->n, srs->cfg); break;
@@ -367,6 +378,7 @@ void pc_hip_srs_free(pc_srs* srs) {
   for (int i = 0; i < PC_MSM_LANES; i++) {
     if (srs->lanes[i] && srs->lanes[i]->inflight) {   // abandon: let the stream drain, mark the job failed
       (void)hipStreamSynchronize(srs->lanes[i]->be.stream);
+      if (srs->lanes[i]->be.tail_stream) (void)hipStreamSynchronize(srs->lanes[i]->be.tail_stream);
       srs->lanes[i]->inflight->done = true; srs->lanes[i]->inflight->status = PC_ERR_INVALID_ARG;
     }
     delete srs->lanes[i];
@@ -374,6 +386,7 @@ void pc_hip_srs_free(pc_srs* srs) {
   if (srs->bases) (void)hipFree(srs->bases);
   if (srs->table) (void)hipFree(srs->table);
   drop_many(srs);
+  if (srs->acc_chain) (void)hipEventDestroy(srs->acc_chain);
   delete srs;
 }
 int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {

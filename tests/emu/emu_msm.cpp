@@ -20,6 +20,8 @@ struct CpuStepBackend {
   void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
   void mark() {}
   void record_done() {}
+  void begin_tail() {}
+  void end_tail() {}
   void wait_done() {}
   void* alloc_host(size_t b) { return calloc(1, b ? b : 1); }
   void free_host(void* p) { if (p) ::free(p); }

@@ -370,3 +370,30 @@ def test_msm_many_hyrax_shape_1024x1024(ctx):
     want_sum = O.msm_pippenger(curve, bases, O.ints_to_limbs(cols, 4), 8, 1)
     assert (pc.points_sum(curve, got) == want_sum).all()
     srs.free()
+
+
+def test_msm_many_and_precompute_argument_errors(ctx):
+    """Error convention of the newer entry points: negative status, nothing computed."""
+    import ctypes as C
+    curve = "bn254"
+    bases = O.gen_bases(curve, 64)
+    srs = ctx.upload_srs(curve, bases)
+    s = O.gen_scalars(curve, 3, 64)
+    out = np.zeros((2, 8), dtype=np.uint64)
+    lib = ctx.lib
+    vp = C.c_void_p
+    # bases[base_offset + m) must lie inside the SRS
+    assert lib.pc_hip_msm_many(ctx.h, srs.h, 60, vp(s.ctypes.data), 0, 0, 8, 2, vp(out.ctypes.data), None) == -1
+    assert lib.pc_hip_msm_many(ctx.h, srs.h, 0, None, 0, 0, 8, 2, vp(out.ctypes.data), None) == -1
+    assert lib.pc_hip_msm_many(ctx.h, srs.h, 0, vp(s.ctypes.data), 0, 0, 8, 2, None, None) == -1
+    # too many entries for the 31-bit entry index: PC_ERR_TOO_LARGE, before any allocation
+    assert lib.pc_hip_msm_many(ctx.h, srs.h, 0, vp(s.ctypes.data), 0, 0, 64, 1 << 26, vp(out.ctypes.data), None) == -5
+    # zero MSMs / zero pairs are fine
+    assert lib.pc_hip_msm_many(ctx.h, srs.h, 0, vp(s.ctypes.data), 0, 0, 8, 0, vp(out.ctypes.data), None) == 0
+    inf = (C.c_int * 2)()
+    assert lib.pc_hip_msm_many(ctx.h, srs.h, 0, vp(s.ctypes.data), 0, 0, 0, 2, vp(out.ctypes.data), inf) == 0
+    assert list(inf) == [1, 1] and not out.any()
+    assert lib.pc_hip_srs_precompute(ctx.h, srs.h, 1, 0) == -1
+    assert lib.pc_hip_srs_precompute(ctx.h, srs.h, 24, 0) == -1
+    assert lib.pc_hip_srs_precompute(None, srs.h, 0, 0) == -1
+    srs.free()
