@@ -607,7 +607,7 @@ class MsmPlan {
     // the reductions below are latency-bound: they go to the pipeline's low-priority queue (HIP backend)
     // (only while the reductions are a sizeable share of the MSM: 20-30 % faster steps up to 2^18, 10-15 % at
     // 2^20, but 8 % slower at 2^21 and beyond, where a delayed reduction stalls the caller's pipeline)
-    if (Mmax <= ((size_t)1 << 24)) be_.begin_tail();
+    if (n <= ((size_t)3 << 19)) be_.begin_tail();
     struct TailScope { Backend& b; ~TailScope() { b.end_tail(); } } tail_scope{be_};
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {

@@ -202,7 +202,10 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
     static const bool split = []() { const char* e = getenv("PC_HIP_SPLIT_CUS"); return e && e[0] == '1'; }();
     // default on; PC_HIP_TAIL_PRIO=0 puts a pipeline back on one queue (measured 8.5-9.0 -> 7.7 ms/step at 2^20)
     static const bool tsplit = []() { const char* e = getenv("PC_HIP_TAIL_PRIO"); return !(e && e[0] == '0'); }();
-    L->be.tail_split = tsplit;
+    // (pipelines of a large SRS keep one plain queue: the split only pays up to ~2^20 pairs per call, and
+    // priority-created streams measured 5 % slower at 2^22 even with the split unused)
+    L->be.tail_split = tsplit && srs->n <= ((size_t)3 << 19);
+    { const char* e = getenv("PC_HIP_TAIL_PRIO"); L->be.high_prio = e && e[0] == '2'; }     // 2: main queues at high priority (experiment)
     if (i == 0 || !split) L->be.init(); else L->be.init(i - 1, PC_MSM_LANES - 1);
     static const bool chain = []() { const char* e = getenv("PC_HIP_ACC_CHAIN"); return e && e[0] == '1'; }();
     if (chain) {
@@ -289,6 +292,9 @@ int pc_hip_init(int device_id, pc_ctx** out) {
   pc_ctx* ctx = new (std::nothrow) pc_ctx();
   if (!ctx) return PC_ERR_OOM;
   ctx->device = device_id;
+  // the division scan / folds on the context's stream feed the MSM pipelines: same priority as their main queues
+  // (normal by default; PC_HIP_TAIL_PRIO=2 raises both)
+  { const char* e = getenv("PC_HIP_TAIL_PRIO"); ctx->be.high_prio = e && e[0] == '2'; }
   int rc = guarded(ctx, [&]() { ctx->be.init(); return (int)PC_OK; });
   if (rc != PC_OK) { delete ctx; return rc; }
   *out = ctx;

@@ -19,7 +19,8 @@ ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, log_n))
 srs = ctx.upload_srs(curve, np.ascontiguousarray(key[:n]))
 cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
 torch.cuda.synchronize()
-t = time.perf_counter(); srs.msm(cdev.data_ptr(), n=n, montgomery=True); t_commit = time.perf_counter() - t
+for _ in range(3):      # every pipeline of the SRS exists (streams + workspace are created on first use)
+    srs.msm(cdev.data_ptr(), n=n, montgomery=True)
 t = time.perf_counter(); srs.msm(cdev.data_ptr(), n=n, montgomery=True); t_commit = time.perf_counter() - t
 srs.free()
 it = iter(range(log_n))
