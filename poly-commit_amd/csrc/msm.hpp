@@ -180,8 +180,8 @@ struct AccumulateBody {
   uint32_t* buckets;         // NB x Pt::WORDS (zeroed = infinity)
   uint32_t* pkeys;           // 2 slots per lane
   uint32_t* ppts;            // 2 x Pt::WORDS per lane
-  PC_HD void flush(const Pt& acc, uint32_t k, uint32_t s, uint32_t e, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
-    bool complete = offsets[k] >= s && offsets[k + 1] <= e;
+  // complete: the whole run [offsets[k], offsets[k+1]) lies inside this lane's chunk
+  PC_HD void flush(const Pt& acc, uint32_t k, bool complete, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
     if (complete) { acc.store(buckets + (size_t)k * Pt::WORDS); return; }
     uint32_t slot = first ? 2 * t : 2 * t + 1;
     acc.store(ppts + (size_t)slot * Pt::WORDS);
@@ -197,25 +197,35 @@ struct AccumulateBody {
       const uint32_t s = (uint32_t)s64;
       const uint32_t e = (M - s > g.T) ? s + g.T : M;
       uint32_t k = find_bucket(offsets, g.NB, s);
-      uint32_t boundary = offsets[k + 1];
+      // the run of bucket k is [run_lo, boundary); `next_boundary` = offsets[k + 2] is fetched one bucket
+      // ahead so that a boundary costs no dependent load (it is hit on nearly every iteration by some lane)
+      uint32_t run_lo = offsets[k], boundary = offsets[k + 1];
+      uint32_t next_boundary = (k + 2 <= g.NB) ? offsets[k + 2] : 0xffffffffu;
       Pt acc = Pt::infinity();
       bool first = true;
       uint32_t val = entries[s];
+      uint32_t nval = (s + 1 < e) ? entries[s + 1] : val;
       AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * g.pt_stride);
       for (uint32_t p = s; p < e; p++) {
-        // prefetch the next entry's base while this one is being added
-        uint32_t nval = val; AffD<C> npt = pt;
-        if (p + 1 < e) { nval = entries[p + 1]; npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride); }
+        // Bucket boundary first: its loads of `offsets` must not sit behind this iteration's gathers
+        // (waiting for the youngest load waits for all older ones: that stalled every wave on the
+        // HBM latency of the prefetch it had just issued, on nearly every iteration).
         if (p == boundary) {
-          flush(acc, k, s, e, t, first, k0, k1);
+          flush(acc, k, run_lo >= s, t, first, k0, k1);       // its end, p, is inside the chunk
           first = false; acc = Pt::infinity();
-          do { k++; } while (offsets[k + 1] <= p);
-          boundary = offsets[k + 1];
+          k++; run_lo = p; boundary = next_boundary;
+          while (boundary <= p) { k++; boundary = offsets[k + 1]; }      // empty buckets (rare): all start at p
+          next_boundary = (k + 2 <= g.NB) ? offsets[k + 2] : 0xffffffffu;
         }
+        // Software pipeline, issued right before the long addition: the base of entry p+1 (its index
+        // arrived an iteration ago) and the index of entry p+2.
+        uint32_t nnval = nval; AffD<C> npt = pt;
+        if (p + 1 < e) npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride);
+        if (p + 2 < e) nnval = entries[p + 2];
         acc.add_affine(pt.neg_if(val >> 31));
-        val = nval; pt = npt;
+        val = nval; nval = nnval; pt = npt;
       }
-      flush(acc, k, s, e, t, first, k0, k1);
+      flush(acc, k, run_lo >= s && boundary <= e, t, first, k0, k1);
       last = acc;
     }
   }
