@@ -44,43 +44,43 @@ struct Fd {
   PC_HD bool eq(const Fd& o) const { uint32_t a = 0; PC_UNROLL for (int i = 0; i < N; i++) a |= l[i] ^ o.l[i]; return a == 0; }
 
   // r = a - MOD if a >= MOD else a   (a < 2*MOD, possibly with an extra carry word `hi`)
+  // Carry chains: on the device clang's add/sub-with-carry builtins lower to one v_addc / v_subb per limb
+  // (the portable 64-bit formulation costs ~5 instructions per limb there); the host keeps the portable form.
+#if defined(__HIP_DEVICE_COMPILE__)
+  static __device__ __forceinline__ uint32_t adc(uint32_t a, uint32_t b, uint32_t& c) { unsigned co; uint32_t r = __builtin_addc(a, b, c, &co); c = co; return r; }
+  static __device__ __forceinline__ uint32_t sbb(uint32_t a, uint32_t b, uint32_t& br) { unsigned bo; uint32_t r = __builtin_subc(a, b, br, &bo); br = bo; return r; }
+#else
+  static inline uint32_t adc(uint32_t a, uint32_t b, uint32_t& c) { uint64_t t = (uint64_t)a + b + c; c = (uint32_t)(t >> 32); return (uint32_t)t; }
+  static inline uint32_t sbb(uint32_t a, uint32_t b, uint32_t& br) { uint64_t t = (uint64_t)a - b - br; br = (uint32_t)(t >> 63); return (uint32_t)t; }
+#endif
   static PC_HD void cond_sub(uint32_t* a, uint32_t hi) {
     uint32_t d[N];
-    uint64_t br = 0;
-    PC_UNROLL for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)a[i] - P::MOD[i] - br;
-      d[i] = (uint32_t)t; br = (t >> 63);
-    }
+    uint32_t br = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) d[i] = sbb(a[i], P::MOD[i], br);
     // a >= MOD  <=>  no final borrow, or the carry word absorbs it
     bool ge = (hi != 0) || (br == 0);
     PC_UNROLL for (int i = 0; i < N; i++) a[i] = ge ? d[i] : a[i];
   }
 
   PC_HD Fd add(const Fd& o) const {
-    Fd r; uint64_t c = 0;
-    PC_UNROLL for (int i = 0; i < N; i++) { c += (uint64_t)l[i] + o.l[i]; r.l[i] = (uint32_t)c; c >>= 32; }
-    cond_sub(r.l, (uint32_t)c);   // every modulus here leaves >= 1 spare top bit, so c == 0
+    Fd r; uint32_t c = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = adc(l[i], o.l[i], c);
+    cond_sub(r.l, c);   // every modulus here leaves >= 1 spare top bit, so c == 0
     return r;
   }
   PC_HD Fd sub(const Fd& o) const {
-    Fd r; uint64_t br = 0;
-    PC_UNROLL for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)l[i] - o.l[i] - br;
-      r.l[i] = (uint32_t)t; br = (t >> 63);
-    }
-    uint32_t mask = (uint32_t)0 - (uint32_t)br;   // add MOD back on borrow
-    uint64_t c = 0;
-    PC_UNROLL for (int i = 0; i < N; i++) { c += (uint64_t)r.l[i] + (P::MOD[i] & mask); r.l[i] = (uint32_t)c; c >>= 32; }
+    Fd r; uint32_t br = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = sbb(l[i], o.l[i], br);
+    uint32_t mask = (uint32_t)0 - br;   // add MOD back on borrow
+    uint32_t c = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = adc(r.l[i], P::MOD[i] & mask, c);
     return r;
   }
   PC_HD Fd dbl() const { return add(*this); }
   PC_HD Fd neg() const {
     // MOD - a, or 0 for a == 0
-    Fd r; uint64_t br = 0; uint32_t nz = 0;
-    PC_UNROLL for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)P::MOD[i] - l[i] - br;
-      r.l[i] = (uint32_t)t; br = (t >> 63); nz |= l[i];
-    }
+    Fd r; uint32_t br = 0, nz = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) { r.l[i] = sbb(P::MOD[i], l[i], br); nz |= l[i]; }
     uint32_t mask = nz ? 0xffffffffu : 0u;
     PC_UNROLL for (int i = 0; i < N; i++) r.l[i] &= mask;
     return r;
@@ -97,32 +97,41 @@ struct Fd {
   // Host (tests, the Horner tail): portable CIOS.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PC_MAC1(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-  // k partial products per asm statement (hipcc pads every statement with an s_nop)
-  static __device__ __forceinline__ void mac1(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
-    asm(PC_MAC1("%2", "%3") : "+v"(acc), "+v"(hi) : "v"(x[0]), "v"(y[0]) : "vcc");
+  // first product of a column: the carry word is written, not accumulated (0 + 0 + carry), so it needs
+  // no zero-initialised register
+#define PC_MAC1F(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
+  // k partial products per asm statement (hipcc pads every statement with an s_nop).  FIRST: the
+  // statement opens a column (`hi` is an output only).
+#define PC_MAC_FNS(NAME, M0, HI)                                                                                        \
+  static __device__ __forceinline__ void NAME##1(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
+    asm(M0("%2", "%3") : "+v"(acc), HI(hi) : "v"(x[0]), "v"(y[0]) : "vcc");                                              \
+  }                                                                                                                     \
+  static __device__ __forceinline__ void NAME##2(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
+    asm(M0("%2", "%3") PC_MAC1("%4", "%5")                                                                               \
+        : "+v"(acc), HI(hi) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc");                                       \
+  }                                                                                                                     \
+  static __device__ __forceinline__ void NAME##4(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
+    asm(M0("%2", "%3") PC_MAC1("%4", "%5") PC_MAC1("%6", "%7") PC_MAC1("%8", "%9")                                       \
+        : "+v"(acc), HI(hi)                                                                                              \
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc");               \
+  }                                                                                                                     \
+  static __device__ __forceinline__ void NAME##8(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
+    asm(M0("%2", "%3") PC_MAC1("%4", "%5") PC_MAC1("%6", "%7") PC_MAC1("%8", "%9")                                       \
+        PC_MAC1("%10", "%11") PC_MAC1("%12", "%13") PC_MAC1("%14", "%15") PC_MAC1("%16", "%17")                          \
+        : "+v"(acc), HI(hi)                                                                                              \
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]),                        \
+          "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");               \
   }
-  static __device__ __forceinline__ void mac2(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
-    asm(PC_MAC1("%2", "%3") PC_MAC1("%4", "%5")
-        : "+v"(acc), "+v"(hi) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc");
-  }
-  static __device__ __forceinline__ void mac4(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
-    asm(PC_MAC1("%2", "%3") PC_MAC1("%4", "%5") PC_MAC1("%6", "%7") PC_MAC1("%8", "%9")
-        : "+v"(acc), "+v"(hi)
-        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc");
-  }
-  static __device__ __forceinline__ void mac8(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
-    asm(PC_MAC1("%2", "%3") PC_MAC1("%4", "%5") PC_MAC1("%6", "%7") PC_MAC1("%8", "%9")
-        PC_MAC1("%10", "%11") PC_MAC1("%12", "%13") PC_MAC1("%14", "%15") PC_MAC1("%16", "%17")
-        : "+v"(acc), "+v"(hi)
-        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]),
-          "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");
-  }
-  template <int CNT>
+#define PC_HI_INOUT(h) "+v"(h)
+#define PC_HI_OUT(h) "=&v"(h)
+  PC_MAC_FNS(mac, PC_MAC1, PC_HI_INOUT)
+  PC_MAC_FNS(macf, PC_MAC1F, PC_HI_OUT)
+  template <int CNT, bool FIRST = false>
   static __device__ __forceinline__ void mac_n(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
-    if constexpr (CNT >= 8) { mac8(acc, hi, x, y); mac_n<CNT - 8>(acc, hi, x + 8, y + 8); }
-    else if constexpr (CNT >= 4) { mac4(acc, hi, x, y); mac_n<CNT - 4>(acc, hi, x + 4, y + 4); }
-    else if constexpr (CNT >= 2) { mac2(acc, hi, x, y); mac_n<CNT - 2>(acc, hi, x + 2, y + 2); }
-    else if constexpr (CNT == 1) { mac1(acc, hi, x, y); }
+    if constexpr (CNT >= 8) { if constexpr (FIRST) macf8(acc, hi, x, y); else mac8(acc, hi, x, y); mac_n<CNT - 8>(acc, hi, x + 8, y + 8); }
+    else if constexpr (CNT >= 4) { if constexpr (FIRST) macf4(acc, hi, x, y); else mac4(acc, hi, x, y); mac_n<CNT - 4>(acc, hi, x + 4, y + 4); }
+    else if constexpr (CNT >= 2) { if constexpr (FIRST) macf2(acc, hi, x, y); else mac2(acc, hi, x, y); mac_n<CNT - 2>(acc, hi, x + 2, y + 2); }
+    else if constexpr (CNT == 1) { if constexpr (FIRST) macf1(acc, hi, x, y); else mac1(acc, hi, x, y); }
   }
   // number of non-zero modulus limbs among MOD[lo..hi]
   static constexpr int nz_mod(int lo, int hi_) { int c = 0; for (int i = lo; i <= hi_; i++) c += P::MOD[i] != 0; return c; }
@@ -135,10 +144,10 @@ struct Fd {
     int c = 0;
     PC_UNROLL for (int i = 0; i <= K; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; }
     PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
-    mac_n<CNT>(acc, hi, x, y);
+    mac_n<CNT, true>(acc, hi, x, y);
     m[K] = (uint32_t)acc * P::INV;
     mac1(acc, hi, &m[K], &mod[0]);
-    acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < N) column_lo<K + 1>(o, m, mod, acc, hi);
   }
   template <int K>
@@ -149,9 +158,9 @@ struct Fd {
     int c = 0;
     PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; }
     PC_UNROLL for (int i = K - N + 1; i < N; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
-    mac_n<CNT>(acc, hi, x, y);
+    mac_n<CNT, true>(acc, hi, x, y);
     t[K - N] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) column_hi<K + 1>(o, m, mod, acc, hi, t);
   }
   __device__ __forceinline__ Fd mul(const Fd& o) const {
