@@ -51,6 +51,12 @@ class HipEngine:
             t0 = time.perf_counter()
             self.srs.precompute()
             self.precompute_ms = (time.perf_counter() - t0) * 1e3
+        # The SRS's MSM pipelines (streams + workspace, GBs for a large SRS) are created on first use:
+        # touch all of them now so that no later call pays for it.
+        one = np.zeros((1, 4), dtype=np.uint64)
+        one[0, 0] = 1
+        for _ in range(3):
+            self.srs.msm(one, n=1)
 
     def _ptr(self, buf, elem_off=0):
         if isinstance(buf, np.ndarray):

@@ -7,12 +7,13 @@ timeout -k 10 600 python bench.py > gpurun_out/run_bench_n1.json 2>/dev/null
 timeout -k 10 600 python bench.py --inflight 0 --no-cpu-baseline > gpurun_out/run_bench_n1_inflight0.json 2>/dev/null
 timeout -k 10 600 python bench.py --precompute 0 --no-cpu-baseline > gpurun_out/run_bench_n1_notable.json 2>/dev/null
 timeout -k 10 600 python bench.py --precompute 0 --inflight 0 --no-cpu-baseline > gpurun_out/run_bench_n1_notable_inflight0.json 2>/dev/null
-timeout -k 10 300 python bench.py --log-degree 22 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/run_bench_2p22.json 2>/dev/null
+timeout -k 10 300 python bench.py --log-degree 22 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/run_bench_2p22.json 2>/dev/null
 timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/run_lincomb.json
 timeout -k 10 600 python bench.py --workload ntt --steps 5 --warmup 1 > gpurun_out/run_bench_ntt.json 2>/dev/null
 timeout -k 10 600 python bench.py --workload batch --steps 2 --warmup 1 > gpurun_out/run_bench_batch.json 2>/dev/null
-timeout -k 10 300 python bench.py --log-degree 24 --steps 3 --warmup 1 > gpurun_out/run_bench_2p24.json 2>/dev/null
+timeout -k 10 300 python bench.py --log-degree 24 --steps 3 --warmup 2 > gpurun_out/run_bench_2p24.json 2>/dev/null
 timeout -k 10 200 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_out/run_ipa_2p22.json
+timeout -k 10 120 tools/microbench > gpurun_out/run_microbench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/run_prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --inflight 0 > $R/gpurun_out/run_prof.log 2>&1
