@@ -190,6 +190,12 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
  * host); out: n-1 Fr.  Keeps the quotient in HBM between commit and open. */
 int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n,
                         const void* z_host, void* out, pc_mem where_out);
+/* p(z) for n coefficients (Montgomery; z and the result on the host): Polynomial::evaluate, which
+ * KZG10::open applies to the blinding polynomial (poly-commit/src/kzg10/mod.rs:276) and every
+ * caller to the opened polynomial; for a polynomial sharded over GPUs it is the value each shard
+ * contributes to the division carry of the shards below it (one up-sweep, no output polynomial). */
+int pc_hip_poly_eval(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,
+                     void* out_host);
 /* The same recurrence exposed with a carry, for a polynomial sharded over several GPUs:
  *   acc = carry_in (or 0);  for i = n-1 .. 0:  acc = coeffs[i] + z*acc;  out[i] = acc.
  * out has n elements; on the shard that holds coefficient 0, out[0] = p(z) and out[1..n) is

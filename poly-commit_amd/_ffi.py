@@ -84,6 +84,7 @@ def load_library():
     lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
+    lib.pc_hip_poly_eval.argtypes = [vp, ip, vp, ip, sz, vp, vp]
     lib.pc_hip_poly_div_scan.argtypes = [vp, ip, vp, ip, sz, vp, vp, vp, ip]
     lib.pc_hip_points_sum.argtypes = [ip, vp, sz, vp]
     lib.pc_hip_point_mul.argtypes = [ip, vp, vp, vp]
@@ -241,6 +242,16 @@ class Context:
         z = np.ascontiguousarray(z, dtype=np.uint64)
         self.check(self.lib.pc_hip_witness_poly(self.h, CURVES[curve], pin, win, n, C.c_void_p(z.ctypes.data), pout, wout))
         return out[: max(n - 1, 0)] if isinstance(out, np.ndarray) else out
+
+    def poly_eval(self, curve, coeffs, z, n=None):
+        """p(z) of n coefficients (host array or device pointer); returns the Montgomery value, (4,) uint64."""
+        pin, win = _ptr(coeffs)
+        if n is None:
+            n = coeffs.shape[0]
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self.check(self.lib.pc_hip_poly_eval(self.h, CURVES[curve], pin, win, n, z.ctypes.data, out.ctypes.data))
+        return out
 
     def div_scan(self, curve, coeffs, z, carry_in=None, out=None, n=None):
         """acc = carry_in; for i = n-1..0: acc = coeffs[i] + z*acc; out[i] = acc  (n outputs)."""

@@ -601,6 +601,23 @@ int pc_hip_last_ntt_phases_ms(const pc_ctx* ctx, float out[2]) {
   return PC_OK;
 }
 
+int pc_hip_poly_eval(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,
+                     void* out_host) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || !out_host || (n && !coeffs)) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    Staged sin(ctx->be, coeffs, where_in, n * 32, true);
+    const uint32_t* z = (const uint32_t*)z_host;
+    switch (field_of) {
+      case PC_CURVE_BLS12_381: pc::poly_eval<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan()); break;
+      case PC_CURVE_BN254: pc::poly_eval<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan()); break;
+      default: pc::poly_eval<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan()); break;
+    }
+    return (int)PC_OK;
+  });
+}
+
 int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,
                          const void* carry_in_host, void* out, pc_mem where_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && (!coeffs || !out))) return PC_ERR_INVALID_ARG;

@@ -99,6 +99,34 @@ void div_scan(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* 
   be.sync();
 }
 
+// p(z) = sum_i x[i] z^i: the up-sweep of the division scan alone (no carries pushed back down, no
+// output polynomial) -- what a shard of a polynomial contributes to the shards below it.
+template <class FrP, class Backend>
+void poly_eval(Backend& be, const uint32_t* x0, size_t count_in, const uint32_t* z_host, uint32_t* out_host, uint32_t G = 16,
+               uint32_t G0 = 8) {
+  typedef Fd<FrP> F;
+  if (count_in == 0) { F::zero().store(out_host); return; }
+  std::vector<uint32_t> counts, fan; std::vector<F> factors;
+  counts.push_back((uint32_t)count_in); factors.push_back(F::load(z_host));
+  do {
+    const uint32_t g = counts.size() == 1 ? G0 : G;
+    F f = factors.back(), fg = F::one();
+    for (uint32_t i = 0; i < g; i++) fg = fg.mul(f);
+    fan.push_back(g);
+    counts.push_back((counts.back() + g - 1) / g); factors.push_back(fg);
+  } while (counts.back() > 1);
+  const size_t L = counts.size() - 1;
+  size_t total = 0; for (size_t k = 1; k <= L; k++) total += counts[k];
+  uint32_t* buf = (uint32_t*)be.workspace((total + 1) * (size_t)FrP::N * 4);
+  const uint32_t* src = x0; uint32_t* dst = buf;
+  for (size_t k = 0; k < L; k++) {
+    ScanUpBody<FrP> b{src, counts[k], fan[k], factors[k], dst, nullptr};
+    be.launch(b, counts[k + 1]);
+    src = dst; dst += (size_t)counts[k + 1] * FrP::N;
+  }
+  be.copy_d2h(out_host, src, (size_t)FrP::N * 4);      // the single element of the last level
+}
+
 // q (n-1 elements) = p (n elements) / (x - z): q[i-1] = value after element i, i = n-1 .. 1.
 template <class FrP, class Backend>
 void witness_polynomial(Backend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t G = 16,

@@ -94,6 +94,10 @@ class HipEngine:
     def read_elem(self, buf, idx):
         return buf[idx].cpu().numpy().view(np.uint64).copy()
 
+    def poly_eval(self, coeffs, n, z):
+        """p(z) of this shard's n coefficients (one up-sweep on the device, 32 bytes back)."""
+        return self.ctx.poly_eval(self.curve, self._ptr(coeffs), z, n=n)
+
     def points_sum(self, pts):
         return _ffi.points_sum(self.curve, pts)
 
@@ -153,18 +157,19 @@ class ShardedKzg:
         return self.open_async(coeffs, n).result()
 
     def open_async(self, coeffs, n):
-        out = self.e.div_scan(coeffs, n, self.z, None)
-        if self.world > 1:
-            # carry into shard r = composition of the shards above it: c = B_s + z^n * c
-            b = self._all_gather(self.e.read_elem(out, 0))
+        if self.world == 1:
+            out = self.e.div_scan(coeffs, n, self.z, None)
+        else:
+            # carry into shard r = composition of the shards above it: c = B_s + z^n * c, with B_s = p_s(z)
+            # (an evaluation-only up-sweep; the full division then runs once, with the carry)
+            b = self._all_gather(self.e.poly_eval(coeffs, n, self.z))
             z = _limbs_to_int(self.z) * pow(_R, -1, self.p) % self.p
             zn_mont = pow(z, n, self.p) * _R % self.p          # Montgomery form of z^n
             rinv = pow(_R, -1, self.p)
             carry = 0
             for s in range(self.world - 1, self.rank, -1):
                 carry = (_limbs_to_int(b[s]) + zn_mont * carry * rinv) % self.p   # Montgomery arithmetic
-            if carry:
-                out = self.e.div_scan(coeffs, n, self.z, _int_to_limbs(carry))
+            out = self.e.div_scan(coeffs, n, self.z, _int_to_limbs(carry) if carry else None)
         if self.rank == 0:
             pend = self._msm_async(out, n - 1, base_offset=1, elem_off=1)    # q[i-1] = out[i] pairs with power i-1
         else:

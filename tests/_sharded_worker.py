@@ -46,6 +46,9 @@ class OracleEngine:
     def read_elem(self, buf, idx):
         return np.ascontiguousarray(buf[idx])
 
+    def poly_eval(self, coeffs, n, z):
+        return np.ascontiguousarray(self.div_scan(coeffs, n, z, None)[0])
+
     def points_sum(self, pts):
         return pc.points_sum(self.curve, pts)
 

@@ -159,3 +159,22 @@ def test_fr_lincomb_matches_bigint(ctx, curve):
     # k = 0 gives the zero polynomial
     z = ctx.fr_lincomb(curve, [], np.zeros((0, 4), dtype=np.uint64), n_out=5)
     assert not z.any()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254", "pallas"])
+def test_poly_eval_matches_oracle(ctx, curve):
+    """pc_hip_poly_eval (the up-sweep of the division scan alone) == Horner evaluation of the oracle,
+    host and device-resident coefficients, lengths around the chunk sizes of the scan levels."""
+    import torch
+    z = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xE7A1, 1))[0]
+    for n in (1, 2, 7, 8, 9, 127, 128, 129, 1000, 4097, 70000):
+        co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xE7A2 + n, n))
+        want = O.poly_eval(curve, co, z)
+        assert (ctx.poly_eval(curve, co, z) == want).all(), n
+        dev = torch.from_numpy(co.view(np.int64)).cuda()
+        assert (ctx.poly_eval(curve, dev.data_ptr(), z, n=n) == want).all(), n
+    assert not ctx.poly_eval(curve, np.zeros((0, 4), dtype=np.uint64), z).any()
+    # and it is element 0 of the division scan (what the sharded open used to read back)
+    co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xE7A3, 5000))
+    scan = ctx.div_scan(curve, co, z)
+    assert (scan[0] == ctx.poly_eval(curve, co, z)).all()
