@@ -13,7 +13,8 @@
 //           (bit-reversed on the way into LDS, DIT butterflies), then * omega_N^(i2*j1)
 //   pass B  tile = R adjacent rows j1; N2-point NTT along each row; transposed store
 //           X[j1 + N1*j2] (R*32 B contiguous runs)
-// Twiddles come from one table W[j] = omega_N^j, j < N (<= 4 MiB at 2^17: L2 resident).
+// Twiddles come from one table W[j] = omega_N^j, j < N (<= 4 MiB at 2^17: L2 resident); the butterfly
+// stages of a pass read theirs from a copy in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
@@ -63,22 +64,28 @@ struct LdsTile {
 
 // DIT butterfly stages over `lines` independent length-2^lg sequences laid out in LDS at
 // pos = line * (len + 1) + p (bit-reversed input, natural output).
+// The 2^(lg-1) twiddles omega_{2^lg}^j of these stages are staged in LDS first (`tw`, limb-major like
+// the tile): every butterfly then reads its twiddle from LDS instead of gathering 32 bytes from the
+// global table (5.7e8 L2 gathers per 2^24-coefficient batch).
 template <class FrP>
 __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t lines, uint32_t lg, const uint32_t* W,
-                                               uint32_t log_n_total, uint32_t first_stage = 1) {
+                                               uint32_t log_n_total, const LdsTile<FrP>& tw, uint32_t first_stage = 1) {
   typedef Fd<FrP> F;
   const uint32_t len = 1u << lg, halfs = len >> 1;
+  for (uint32_t j = threadIdx.x; j < halfs; j += NTT_THREADS)
+    tw.put(j, F::load(W + ((size_t)j << (log_n_total - lg)) * FrP::N));      // omega_{2^lg}^j = W[j << (log_n - lg)]
+  __syncthreads();
   // every size is a power of two: index arithmetic is shifts and masks (an integer divide by a
   // run-time value costs ~30 VALU instructions on this ISA, four of them per butterfly)
   for (uint32_t s = first_stage; s <= lg; s++) {
     const uint32_t h = 1u << (s - 1);
-    const uint32_t tw_shift = log_n_total - s;       // omega_{2^s}^j = W[j << (log_n - s)]
+    const uint32_t tw_shift = lg - s;                // omega_{2^s}^j = tw[j << (lg - s)]
     for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
       uint32_t line = b >> (lg - 1), k = b & (halfs - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
       uint32_t p0 = line * (len + 1) + (g << s) + j, p1 = p0 + h;
       F u = t.get(p0), v = t.get(p1);
-      if (j) v = v.mul(F::load(W + ((size_t)j << tw_shift) * FrP::N));
+      if (j) v = v.mul(tw.get(j << tw_shift));
       t.put(p0, u.add(v)); t.put(p1, u.sub(v));
     }
     __syncthreads();
@@ -94,6 +101,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   const uint32_t lgC = 31 - __builtin_clz(C), tile_bits = lg2 - lgC;
   const uint32_t row = blockIdx.x >> tile_bits, tile = blockIdx.x & ((1u << tile_bits) - 1);
   LdsTile<FrP> t{smem, C * (N1 + 1)};
+  LdsTile<FrP> tw{smem + (size_t)FrP::N * C * (N1 + 1), N1 / 2 + 1};
   const uint32_t* rin = in + (size_t)row * in_cols * FrP::N;
   // Zero padding: if only the first N >> z coefficients can be non-zero (rho_inv = 4 -> z = 2), a
   // column holds data only at i1 < N1 >> z, i.e. (bit-reversed) at LDS positions = 0 mod 2^z, and
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
     for (uint32_t r = 0; r < zpow; r++) t.put(pos + r, v);
   }
   __syncthreads();
-  lds_ntt_stages<FrP>(t, C, lg1, W, log_n, zskip + 1);
+  lds_ntt_stages<FrP>(t, C, lg1, W, log_n, tw, zskip + 1);
   uint32_t* rout = tmp + (size_t)row * N * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
     uint32_t c = idx & (C - 1), j1 = idx >> lgC;
@@ -128,13 +136,14 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const uint32_t* tmp,
   const uint32_t lgR = 31 - __builtin_clz(R), tile_bits = lg1 - lgR;
   const uint32_t row = blockIdx.x >> tile_bits, tile = blockIdx.x & ((1u << tile_bits) - 1);
   LdsTile<FrP> t{smem, R * (N2 + 1)};
+  LdsTile<FrP> tw{smem + (size_t)FrP::N * R * (N2 + 1), N2 / 2 + 1};
   const uint32_t* rin = tmp + ((size_t)row * N + (size_t)tile * R * N2) * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
     uint32_t r = idx >> lg2, i2 = idx & (N2 - 1);
     t.put(r * (N2 + 1) + bitrev(i2, lg2), F::load(rin + (size_t)idx * FrP::N));
   }
   __syncthreads();
-  lds_ntt_stages<FrP>(t, R, lg2, W, log_n);
+  lds_ntt_stages<FrP>(t, R, lg2, W, log_n, tw);
   uint32_t* rout = out + (size_t)row * N * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
     uint32_t r = idx & (R - 1), j2 = idx >> lgR;
@@ -170,7 +179,8 @@ class NttPlan {
     if (need > tmp_bytes_) { be_.sync(); be_.free(tmp_); tmp_ = (uint32_t*)be_.alloc(need); tmp_bytes_ = need; }
     uint32_t C = 8; while (C > N2) C >>= 1; while (C > 1 && C * N1 > NTT_TILE_MAX) C >>= 1;
     uint32_t R = 8; while (R > N1) R >>= 1; while (R > 1 && R * N2 > NTT_TILE_MAX) R >>= 1;
-    size_t lds_a = (size_t)C * (N1 + 1) * FrP::N * 4, lds_b = (size_t)R * (N2 + 1) * FrP::N * 4;
+    // tile + the stage twiddles of the pass (N1/2 resp. N2/2 elements)
+    size_t lds_a = ((size_t)C * (N1 + 1) + N1 / 2 + 1) * FrP::N * 4, lds_b = ((size_t)R * (N2 + 1) + N2 / 2 + 1) * FrP::N * 4;
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) throw std::runtime_error("NTT size exceeds the LDS tile");
     if (lds_a > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_a<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     if (lds_b > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_b<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
