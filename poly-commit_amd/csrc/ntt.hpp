@@ -77,7 +77,8 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t l
   __syncthreads();
   // every size is a power of two: index arithmetic is shifts and masks (an integer divide by a
   // run-time value costs ~30 VALU instructions on this ISA, four of them per butterfly)
-  for (uint32_t s = first_stage; s <= lg; s++) {
+  uint32_t s = first_stage;
+  if (((lg - first_stage + 1) & 1) && s <= lg) {     // odd number of stages: one radix-2 stage first
     const uint32_t h = 1u << (s - 1);
     const uint32_t tw_shift = lg - s;                // omega_{2^s}^j = tw[j << (lg - s)]
     for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
@@ -87,6 +88,29 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t l
       F u = t.get(p0), v = t.get(p1);
       if (j) v = v.mul(tw.get(j << tw_shift));
       t.put(p0, u.add(v)); t.put(p1, u.sub(v));
+    }
+    __syncthreads();
+    s++;
+  }
+  // Two stages per LDS round trip: a lane holds the four elements p, p+h, p+2h, p+3h of a group in
+  // registers, applies stage s to (p, p+h) and (p+2h, p+3h) -- both with omega_{2^s}^j -- and stage
+  // s+1 to (p, p+2h) with omega_{2^(s+1)}^j and (p+h, p+3h) with omega_{2^(s+1)}^(j+h): the same four
+  // products as two radix-2 stages, half the LDS traffic and half the barriers.
+  const uint32_t quarters = len >> 2;
+  for (; s + 1 <= lg; s += 2) {
+    const uint32_t h = 1u << (s - 1);
+    const uint32_t sh1 = lg - s, sh2 = lg - s - 1;
+    for (uint32_t b = threadIdx.x; b < lines * quarters; b += NTT_THREADS) {
+      uint32_t line = b >> (lg - 2), k = b & (quarters - 1);
+      uint32_t g = k >> (s - 1), j = k & (h - 1);
+      uint32_t p0 = line * (len + 1) + (g << (s + 1)) + j;
+      F x0 = t.get(p0), x1 = t.get(p0 + h), x2 = t.get(p0 + 2 * h), x3 = t.get(p0 + 3 * h);
+      if (j) { F w1 = tw.get(j << sh1); x1 = x1.mul(w1); x3 = x3.mul(w1); }
+      F a0 = x0.add(x1), a1 = x0.sub(x1), a2 = x2.add(x3), a3 = x2.sub(x3);
+      if (j) a2 = a2.mul(tw.get(j << sh2));
+      a3 = a3.mul(tw.get((j + h) << sh2));
+      t.put(p0, a0.add(a2)); t.put(p0 + 2 * h, a0.sub(a2));
+      t.put(p0 + h, a1.add(a3)); t.put(p0 + 3 * h, a1.sub(a3));
     }
     __syncthreads();
   }
