@@ -136,45 +136,50 @@ struct Fd {
   // number of non-zero modulus limbs among MOD[lo..hi]
   static constexpr int nz_mod(int lo, int hi_) { int c = 0; for (int i = lo; i <= hi_; i++) c += P::MOD[i] != 0; return c; }
 
-  template <int K>
+  // UNIT: the second operand is the raw integer 1 (Montgomery -> canonical conversion): the only
+  // a_i * b_j left in column K is a_K * 1, so a column is one product plus the reduction terms.
+  template <int K, bool UNIT>
   __device__ __forceinline__ void column_lo(const Fd& o, uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi) const {
     // column K < N: a_i*b_{K-i} (i = 0..K), m_i*p_{K-i} (i = 0..K-1, p_{K-i} != 0)
-    constexpr int CNT = (K + 1) + nz_mod(1, K);
+    constexpr int CNT = (UNIT ? 1 : K + 1) + nz_mod(1, K);
     uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
     int c = 0;
-    PC_UNROLL for (int i = 0; i <= K; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; }
+    if constexpr (UNIT) { x[c] = l[K]; y[c] = o.l[0]; c++; }
+    else { PC_UNROLL for (int i = 0; i <= K; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; } }
     PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
     mac_n<CNT, true>(acc, hi, x, y);
     m[K] = (uint32_t)acc * P::INV;
     mac1(acc, hi, &m[K], &mod[0]);
     acc = (acc >> 32) | ((uint64_t)hi << 32);
-    if constexpr (K + 1 < N) column_lo<K + 1>(o, m, mod, acc, hi);
+    if constexpr (K + 1 < N) column_lo<K + 1, UNIT>(o, m, mod, acc, hi);
   }
-  template <int K>
+  template <int K, bool UNIT>
   __device__ __forceinline__ void column_hi(const Fd& o, const uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi, uint32_t* t) const {
     // column K >= N: i = K-N+1 .. N-1
-    constexpr int CNT = (2 * N - 1 - K) + nz_mod(K - N + 1, N - 1);
+    constexpr int CNT = (UNIT ? 0 : 2 * N - 1 - K) + nz_mod(K - N + 1, N - 1);
     uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
     int c = 0;
-    PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; }
+    if constexpr (!UNIT) { PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; } }
     PC_UNROLL for (int i = K - N + 1; i < N; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
-    mac_n<CNT, true>(acc, hi, x, y);
+    mac_n<CNT, true>(acc, hi, x, y);      // (the last column has no products: its stale carry word only reaches discarded bits)
     t[K - N] = (uint32_t)acc;
     acc = (acc >> 32) | ((uint64_t)hi << 32);
-    if constexpr (K + 1 < 2 * N) column_hi<K + 1>(o, m, mod, acc, hi, t);
+    if constexpr (K + 1 < 2 * N) column_hi<K + 1, UNIT>(o, m, mod, acc, hi, t);
   }
-  __device__ __forceinline__ Fd mul(const Fd& o) const {
+  template <bool UNIT>
+  __device__ __forceinline__ Fd mul_impl(const Fd& o) const {
     uint32_t m[N], t[N + 1];
     uint32_t mod[N];
     PC_UNROLL for (int i = 0; i < N; i++) mod[i] = P::MOD[i];
     uint64_t acc = 0; uint32_t hi = 0;
-    column_lo<0>(o, m, mod, acc, hi);
-    column_hi<N>(o, m, mod, acc, hi, t);
+    column_lo<0, UNIT>(o, m, mod, acc, hi);
+    column_hi<N, UNIT>(o, m, mod, acc, hi, t);
     Fd r;
     PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
     cond_sub(r.l, (uint32_t)acc);
     return r;
   }
+  __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
 #else
   PC_HD Fd mul(const Fd& o) const {
     uint32_t t[N + 1];
@@ -210,7 +215,12 @@ struct Fd {
 
   // Montgomery <-> canonical
   PC_HD Fd from_mont() const {   // multiply by raw 1 => a * R^-1
-    Fd o = zero(); o.l[0] = 1; return mul(o);
+    Fd o = zero(); o.l[0] = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return mul_impl<true>(o);    // reduction only: N^2 + N partial products instead of 2 N^2 + N
+#else
+    return mul(o);
+#endif
   }
   PC_HD Fd to_mont() const { Fd r2; PC_UNROLL for (int i = 0; i < N; i++) r2.l[i] = P::R2[i]; return mul(r2); }
 
