@@ -112,8 +112,14 @@ struct ColumnHashBody {
   PC_HD void operator()(uint32_t j) const {
     D d; d.init();
     d.push_le32(rows); d.push_le32(0);                       // Vec length as u64 LE
+    // two rows in flight: the loads of rows r+1 and r+2 are issued before row r is converted and hashed
+    // (one wave per 64 columns leaves 2 waves per SIMD: without this the kernel waits on every load)
+    F nxt = rows ? F::load(ext + (size_t)j * FrP::N) : F::zero();
+    F nxt2 = rows > 1 ? F::load(ext + ((size_t)n_cols + j) * FrP::N) : F::zero();
     for (uint32_t r = 0; r < rows; r++) {
-      F v = F::load(ext + ((size_t)r * n_cols + j) * FrP::N).from_mont();
+      F cur = nxt; nxt = nxt2;
+      if (r + 2 < rows) nxt2 = F::load(ext + ((size_t)(r + 2) * n_cols + j) * FrP::N);
+      F v = cur.from_mont();
       PC_UNROLL for (int k = 0; k < FrP::N; k++) d.push_le32(v.l[k]);
     }
     uint32_t dig[8]; d.finish(dig);
