@@ -53,10 +53,10 @@ class HipEngine:
             self.precompute_ms = (time.perf_counter() - t0) * 1e3
         # The SRS's MSM pipelines (streams + workspace, GBs for a large SRS) are created on first use:
         # touch all of them now so that no later call pays for it.
-        one = np.zeros((1, 4), dtype=np.uint64)
-        one[0, 0] = 1
+        # (an empty MSM: the pipeline is created, nothing is launched)
+        none = np.zeros((1, 4), dtype=np.uint64)
         for _ in range(3):
-            self.srs.msm(one, n=1)
+            self.srs.msm(none, n=0)
 
     def _ptr(self, buf, elem_off=0):
         if isinstance(buf, np.ndarray):
