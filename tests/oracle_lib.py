@@ -24,8 +24,13 @@ def lib():
         so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
         src_m = max(os.path.getmtime(os.path.join(ROOT, "oracle", f))
                     for f in ("oracle.cpp", "oracle_field.hpp", "oracle_constants.h"))
-        if not os.path.exists(so) or os.path.getmtime(so) < src_m:
-            build()
+        # several ranks of one node may get here at once (bench.py --gpus N): build under a file lock
+        import fcntl
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        with open(so + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if not os.path.exists(so) or os.path.getmtime(so) < src_m:
+                build()
         _lib = C.CDLL(so)
         _lib.orc_fq_limbs.restype = C.c_int
         _lib.orc_kzg_commit.restype = C.c_int
