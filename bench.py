@@ -327,6 +327,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # The same kernel without a second pipeline competing for the CUs: a few strictly serial MSMs after
+    # the timed region (reported beside the timed-region figure, which includes queueing behind the
+    # other pipeline's kernels).
+    eng.phases = []
+    for _ in range(3):
+        job.commit_async(coeffs, n).result()
+    acc_serial_ms = float(np.mean([ph[3] for ph in eng.phases])) if eng.phases else 0.0
+
     pairs_per_step = world * (2 * n - 1) if world == 1 else world * (2 * n) - 1
     value = pairs_per_step * args.steps / dt
     ph = ph_sum / max(n_msm, 1)
@@ -361,7 +369,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "kernel": "k_accumulate (bucket accumulation), avg of hipEvent-timed launches on the MSM pipelines' streams",
-                         "algorithmic_bytes_per_launch": pairs_per_launch * PAIR_BYTES[curve]},
+                         "algorithmic_bytes_per_launch": pairs_per_launch * PAIR_BYTES[curve],
+                         "serial": {"kernel_ms": acc_serial_ms,
+                                    "achieved": n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 if acc_serial_ms > 0 else None,
+                                    "frac": n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc_serial_ms > 0 else None,
+                                    "note": "3 blocking commit MSMs after the timed region: no other pipeline on the GPU"}},
         }
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(curve, args.log_degree)
