@@ -98,19 +98,15 @@ struct HipBackend {
         if ((cu / 2) % cu_parts == cu_part) mask[cu / 32] |= 1u << (cu % 32);   // pairs of CUs (a WGP-like unit) stay together
       PC_HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data()));
     } else if (tail_split) {
-      // Two queues per pipeline: sort + accumulate at normal (or, with high_prio, high) priority, the
+      // Two queues per pipeline: sort + accumulate at normal priority, the
       // latency-bound reductions at low priority, so that a bucket accumulation arriving at a busy chip gets the CUs first.
       int lo = 0, hi = 0;
       PC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const int main_prio = high_prio ? hi : 0;
-      PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, main_prio));
+      (void)hi;    // (raising the main queues to `hi` as well measured the same at 2^20 and 4 % slower at 2^22)
+      PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, 0));
       PC_HIP_CHECK(hipStreamCreateWithPriority(&tail_stream, hipStreamNonBlocking, lo));
       PC_HIP_CHECK(hipEventCreateWithFlags(&tail_ev, hipEventDisableTiming));
       main_stream = stream;
-    } else if (high_prio) {
-      int lo = 0, hi = 0;
-      PC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
     } else {
       PC_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
@@ -186,10 +182,6 @@ struct HipBackend {
   void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
   void* work_ws = nullptr; size_t work_ws_bytes = 0;
   int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
-  // Shared by the pipelines of one SRS: the bucket accumulations of different pipelines run one after
-  // another (each fills every CU by itself; two at once only slow each other), everything else overlaps.
-  hipEvent_t* acc_chain = nullptr; bool* acc_chain_armed = nullptr;
-  bool high_prio = false;      // single queue at the priority of the pipelines' main queues (the context's own stream)
   bool tail_split = false; hipStream_t main_stream = nullptr, tail_stream = nullptr; hipEvent_t tail_ev = nullptr;
 
   // bucket accumulation with the neighbour merge of cut runs (msm_coop.hpp)

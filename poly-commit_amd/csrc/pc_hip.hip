@@ -56,10 +56,8 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
 template <class C>
 void HipBackend::accumulate(const AccumulateBody<C>& body, size_t lanes) {
   if (lanes == 0) return;
-  if (acc_chain && *acc_chain_armed) PC_HIP_CHECK(hipStreamWaitEvent(stream, *acc_chain, 0));
   hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, body, (uint32_t)lanes);
   PC_HIP_CHECK(hipGetLastError());
-  if (acc_chain) { PC_HIP_CHECK(hipEventRecord(*acc_chain, stream)); *acc_chain_armed = true; }
 }
 
 template <class C>
@@ -165,7 +163,6 @@ struct pc_srs {
   pc::MsmConfig cfg;
   MsmLane* lanes[PC_MSM_LANES] = {nullptr, nullptr, nullptr};
   int next_lane = 0;
-  hipEvent_t acc_chain = nullptr; bool acc_chain_armed = false;     // see HipBackend::acc_chain
   // pc_hip_msm_many: window table of bases[base_offset .. base_offset + m) and the pipeline sized for B x m
   struct Many { size_t base_offset = 0, m = 0, B = 0; uint32_t* table = nullptr; MsmLane* lane = nullptr; } many;
 };
@@ -205,13 +202,7 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
     // (pipelines of a large SRS keep one plain queue: the split only pays up to ~2^20 pairs per call, and
     // priority-created streams measured 5 % slower at 2^22 even with the split unused)
     L->be.tail_split = tsplit && srs->n <= ((size_t)3 << 19);
-    { const char* e = getenv("PC_HIP_TAIL_PRIO"); L->be.high_prio = e && e[0] == '2'; }     // 2: main queues at high priority (experiment)
     if (i == 0 || !split) L->be.init(); else L->be.init(i - 1, PC_MSM_LANES - 1);
-    static const bool chain = []() { const char* e = getenv("PC_HIP_ACC_CHAIN"); return e && e[0] == '1'; }();
-    if (chain) {
-      if (!srs->acc_chain) PC_HIP_CHECK(hipEventCreateWithFlags(&srs->acc_chain, hipEventDisableTiming));
-      L->be.acc_chain = &srs->acc_chain; L->be.acc_chain_armed = &srs->acc_chain_armed;
-    }
     switch (srs->curve) {
       case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, srs->n, srs->cfg); break;
       case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, srs->n, srs->cfg); break;
@@ -292,9 +283,6 @@ int pc_hip_init(int device_id, pc_ctx** out) {
   pc_ctx* ctx = new (std::nothrow) pc_ctx();
   if (!ctx) return PC_ERR_OOM;
   ctx->device = device_id;
-  // the division scan / folds on the context's stream feed the MSM pipelines: same priority as their main queues
-  // (normal by default; PC_HIP_TAIL_PRIO=2 raises both)
-  { const char* e = getenv("PC_HIP_TAIL_PRIO"); ctx->be.high_prio = e && e[0] == '2'; }
   int rc = guarded(ctx, [&]() { ctx->be.init(); return (int)PC_OK; });
   if (rc != PC_OK) { delete ctx; return rc; }
   *out = ctx;
@@ -392,7 +380,6 @@ void pc_hip_srs_free(pc_srs* srs) {
   if (srs->bases) (void)hipFree(srs->bases);
   if (srs->table) (void)hipFree(srs->table);
   drop_many(srs);
-  if (srs->acc_chain) (void)hipEventDestroy(srs->acc_chain);
   delete srs;
 }
 int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {
