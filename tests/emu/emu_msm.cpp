@@ -183,6 +183,15 @@ extern "C" void emu_div_scan(int curve, const uint32_t* x, size_t n, const uint3
   }
 }
 
+extern "C" void emu_poly_eval(int curve, const uint32_t* x, size_t n, const uint32_t* z, uint32_t* out, uint32_t G) {
+  CpuStepBackend be;
+  switch (curve) {
+    case 0: pc::poly_eval<pc_bls12_381_fr>(be, x, n, z, out, G); break;
+    case 1: pc::poly_eval<pc_bn254_fr>(be, x, n, z, out, G); break;
+    case 2: pc::poly_eval<pc_pallas_fr>(be, x, n, z, out, G); break;
+  }
+}
+
 // IPA round bodies, stepped
 template <class C>
 static void ipa_bodies(uint32_t* key, size_t half, const uint32_t* u_canon, uint32_t* lo, const uint32_t* hi, const uint32_t* s_mont,

@@ -213,6 +213,26 @@ def test_division_scan_stepped(curve):
     assert (lo == whole[:n]).all()
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_poly_eval_stepped(curve):
+    """pc_hip_poly_eval's level structure (the up-sweep of the division scan alone) == Horner evaluation
+    with Python integers, for lengths around the chunk sizes and two fan-ins."""
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    zi = R.gen_scalars(fr, 0xE7A1, 1)[0]
+    z = O.fr_mont_array(curve, [zi])[0]
+    for n in (1, 2, 7, 8, 9, 63, 64, 65, 129, 1000):
+        ci = R.gen_scalars(fr, 0xE7A2 + n, n)
+        want = 0
+        for c in reversed(ci):
+            want = (want * zi + c) % p
+        co = O.fr_mont_array(curve, ci)
+        for G in (16, 4):
+            out = np.zeros(4, dtype=np.uint64)
+            emu().emu_poly_eval(O.CURVES[curve], p32(co.view(np.uint32)), C.c_size_t(n), p32(z.view(np.uint32)), p32(out.view(np.uint32)), G)
+            assert O.fr_from_mont_array(curve, out.reshape(1, 4))[0] == want, (n, G)
+
+
 @pytest.mark.parametrize("curve", ["pallas", "bls12_381"])
 def test_ipa_round_bodies_stepped(curve):
     """fr_fold / fr_dot / ec_fold / fr_powers (ipa_pc/mod.rs:641-649, 672-707) vs Python big ints."""
