@@ -57,8 +57,13 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     ok = True
+    # --engine hip: the real device engine, every rank on GPU 0 (gloo carries the 100-byte exchanges);
+    # with --precompute the SRS chunk also gets its window table.  Default: the oracle-backed test double.
+    use_hip = "--engine" in sys.argv and sys.argv[sys.argv.index("--engine") + 1] == "hip"
+    precompute = "--precompute" in sys.argv
+    ctx = pc.Context(0) if use_hip else None
     for curve in ("bls12_381", "bn254"):
-        n = 96                                     # coefficients per rank
+        n = 3000 if use_hip else 96                # coefficients per rank
         total = n * world
         powers = O.gen_bases(curve, total)         # the "global" SRS
         coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC0FFEE, total))
@@ -68,10 +73,16 @@ def main():
         chunk = np.zeros((n + 1, powers.shape[1]), dtype=np.uint64)
         chunk[1:] = powers[lo:lo + n]
         chunk[0] = powers[lo - 1] if rank else powers[0]
-        job = sharded.ShardedKzg(OracleEngine(curve), curve, rank, world, dist)
-        job.load_srs_chunk(chunk)
-        job.set_point(z)
         mine = np.ascontiguousarray(coeffs[lo:lo + n])
+        if use_hip:
+            import torch
+            job = sharded.ShardedKzg(sharded.HipEngine(ctx, curve), curve, rank, world, dist)
+            job.load_srs_chunk(chunk, precompute=precompute)
+            mine = torch.from_numpy(mine.view(np.int64)).cuda()
+        else:
+            job = sharded.ShardedKzg(OracleEngine(curve), curve, rank, world, dist)
+            job.load_srs_chunk(chunk)
+        job.set_point(z)
         comm = job.commit(mine, n)
         proof = job.open(mine, n)
         rc1, want_c = O.kzg_commit(curve, powers, coeffs, 2)
