@@ -178,3 +178,40 @@ def test_poly_eval_matches_oracle(ctx, curve):
     co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xE7A3, 5000))
     scan = ctx.div_scan(curve, co, z)
     assert (scan[0] == ctx.poly_eval(curve, co, z)).all()
+
+
+def _gold():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+
+
+def test_golden_ligero_commit_lincomb_msm_many(ctx):
+    """The committed fixtures (tests/golden/golden.json, tools/gen_golden.py) for the newer entry points,
+    through the C ABI: fused Ligero commit (leaves, nodes, root), open's linear combination, many short MSMs."""
+    G = _gold()
+    hexs = lambda xs: [int(x, 16) for x in xs]
+    for case in G["ligero_commit"]:
+        curve = case["curve"]
+        mat = np.stack([O.fr_mont_array(curve, hexs(row)) for row in case["matrix"]])
+        for v in case["variants"]:
+            nodes, leaves = ctx.ligero_commit(curve, np.ascontiguousarray(mat), case["log_n"], col_hash=v["col_hash"],
+                                              tree_hash=v["tree_hash"], len_prefix=v["len_prefix"])
+            assert [leaves[j].tobytes().hex() for j in range(32)] == v["leaves"]
+            assert [nodes[j].tobytes().hex() for j in range(31)] == v["nodes"] and nodes[0].tobytes().hex() == v["root"]
+    for case in G["fr_lincomb"]:
+        curve = case["curve"]
+        polys = [O.fr_mont_array(curve, hexs(q)) for q in case["polys"]]
+        got = ctx.fr_lincomb(curve, polys, O.fr_mont_array(curve, hexs(case["xi"])))
+        assert O.fr_from_mont_array(curve, got) == hexs(case["result"])
+    for case in G["msm_many"]:
+        curve = case["curve"]
+        bases = O.points_to_array(curve, [None if p is None else (int(p[0], 16), int(p[1], 16)) for p in case["bases"]])
+        srs = ctx.upload_srs(curve, bases)
+        rows = np.stack([O.ints_to_limbs(hexs(row), 4) for row in case["rows"]])
+        got, inf = srs.msm_many(np.ascontiguousarray(rows))
+        pts = O.array_to_points(curve, got)
+        for k, want in enumerate(case["results"]):
+            assert pts[k] == (None if want is None else (int(want[0], 16), int(want[1], 16)))
+        assert list(inf) == [w is None for w in case["results"]]
+        srs.free()

@@ -25,7 +25,8 @@ def pt(P):
     return None if P is None else [hex(P[0]), hex(P[1])]
 
 
-gold = {"msm": [], "ntt": [], "kzg": [], "ipa": [], "ligero_dims": [], "roots": {}, "gen_scalars": {}}
+gold = {"msm": [], "ntt": [], "kzg": [], "ipa": [], "ligero_dims": [], "roots": {}, "gen_scalars": {},
+        "ligero_commit": [], "fr_lincomb": [], "msm_many": []}
 for curve in R.CURVES:
     fr = R.CURVES[curve]["fr"]
     r = R.FIELDS[fr]["p"]
@@ -65,6 +66,30 @@ for curve in R.CURVES:
                         "point": hex(zp), "h_prime": pt(hp), "challenges": [hex(x) for x in ch],
                         "l_vec": [pt(x) for x in l], "r_vec": [pt(x) for x in rr], "final_comm_key": pt(fk),
                         "c": hex(c)})
+    # --- Ligero commit steps 1-3 on a 4 x 8 matrix, rho^-1 = 4: encode, column digests, Merkle tree -----
+    mat = [R.gen_scalars(fr, 0x5EED0500 + i, 8) for i in range(4)]
+    ext = [R.ntt(fr, row, 5) for row in mat]                       # 8 * 4 = 32 = 2^5 evaluations per row
+    cols = [[ext[i][j] for i in range(4)] for j in range(32)]
+    entry = {"curve": curve, "matrix": [[hex(x) for x in row] for row in mat], "log_n": 5, "variants": []}
+    for col_hash, tree_hash, lp in (("blake2s", "sha256", True), ("sha256", "blake2s", False)):
+        leaves = [R.column_digest(fr, c, col_hash) for c in cols]
+        nodes = R.merkle_tree(leaves, tree_hash, lp)
+        sib, path = R.merkle_path(nodes, leaves, 5)
+        entry["variants"].append({"col_hash": col_hash, "tree_hash": tree_hash, "len_prefix": lp,
+                                  "leaves": [l.hex() for l in leaves], "root": nodes[0].hex(),
+                                  "nodes": [x.hex() for x in nodes],
+                                  "path_of_leaf_5": [sib.hex()] + [x.hex() for x in path]})
+    gold["ligero_commit"].append(entry)
+    # --- open's linear combination, ragged lengths ---------------------------------------------------
+    polys = [R.gen_scalars(fr, 0x5EED0700 + j, n) for j, n in enumerate((9, 1, 5))]
+    xi = R.gen_scalars(fr, 0x5EED0777, 3)
+    gold["fr_lincomb"].append({"curve": curve, "polys": [[hex(x) for x in q] for q in polys], "xi": [hex(x) for x in xi],
+                               "result": [hex(x) for x in R.fr_lincomb(fr, polys, xi)]})
+    # --- many short MSMs over the same bases (Hyrax rows): 3 rows of 6 scalars over bases[:6] -------
+    rows = [R.gen_scalars(fr, 0x4A11 + k, 6) for k in range(3)]
+    rows[1] = [0] * 6
+    gold["msm_many"].append({"curve": curve, "bases": [pt(b) for b in bases[:6]], "rows": [[hex(x) for x in row] for row in rows],
+                             "results": [pt(R.msm(curve, bases[:6], row)) for row in rows]})
 for field, bits in (("bls12_381_fr", 255), ("bn254_fr", 254)):
     for lg in (12, 16, 20, 22, 24):
         for rho in (4, 2):
