@@ -109,6 +109,15 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
 
 
+/* Device buffers for callers that do not link a HIP runtime themselves (the Rust shim, the C++ host
+ * mirror): the vectors of an IPA opening stay in HBM across all rounds (ipa_pc/mod.rs:664-711) and
+ * are addressed by the raw device pointers the pc_hip_fr_* / PC_MEM_DEVICE entry points take.
+ * Copies are synchronous.  Nothing in the reference corresponds to them. */
+int pc_hip_malloc(pc_ctx* ctx, size_t bytes, void** out_dev);
+int pc_hip_free(pc_ctx* ctx, void* dev);
+int pc_hip_memcpy_h2d(pc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int pc_hip_memcpy_d2h(pc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
 /* Many short MSMs over the SAME bases in one pass:
  *   out[k] = sum_{j < m} scalars[k][j] * bases[base_offset + j],   k < n_msms,
  * scalars = n_msms x m elements, contiguous.  This is HyraxPC::commit's "one multi-commitment per

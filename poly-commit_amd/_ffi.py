@@ -64,6 +64,10 @@ def load_library():
     lib.pc_hip_msm.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip)]
     lib.pc_hip_msm_batch.argtypes = [vp, vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), sz, ip, ip, vp,
                                      C.POINTER(ip)]
+    lib.pc_hip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.pc_hip_free.argtypes = [vp, vp]
+    lib.pc_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    lib.pc_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     lib.pc_hip_msm_many.argtypes = [vp, vp, sz, vp, ip, ip, sz, sz, vp, C.POINTER(ip)]
     lib.pc_hip_msm_async.argtypes = [vp, vp, sz, vp, ip, ip, sz, vp, C.POINTER(ip), C.POINTER(vp)]
     lib.pc_hip_job_wait.argtypes = [vp, vp]

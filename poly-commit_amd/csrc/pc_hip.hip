@@ -476,6 +476,28 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
   });
 }
 
+int pc_hip_malloc(pc_ctx* ctx, size_t bytes, void** out_dev) {
+  if (!ctx || !out_dev) return PC_ERR_INVALID_ARG;
+  *out_dev = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() { *out_dev = ctx->be.alloc(bytes); return (int)PC_OK; });
+}
+int pc_hip_free(pc_ctx* ctx, void* dev) {
+  if (!ctx) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() { ctx->be.free(dev); return (int)PC_OK; });
+}
+int pc_hip_memcpy_h2d(pc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!ctx || (bytes && (!dst_dev || !src_host))) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() { if (bytes) { ctx->be.copy_h2d(dst_dev, src_host, bytes); ctx->be.sync(); } return (int)PC_OK; });
+}
+int pc_hip_memcpy_d2h(pc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!ctx || (bytes && (!dst_host || !src_dev))) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() { if (bytes) ctx->be.copy_d2h(dst_host, src_dev, bytes); return (int)PC_OK; });
+}
+
 int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* scalars, pc_scalar_form form, pc_mem where,
                     size_t m, size_t n_msms, void* out_xy, int* out_is_infinity) {
   if (!ctx || !srs || srs->ctx != ctx || !out_xy || (m && n_msms && !scalars)) return PC_ERR_INVALID_ARG;

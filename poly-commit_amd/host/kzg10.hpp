@@ -54,6 +54,7 @@ struct FrT {
   FrT operator-(const FrT& o) const { return of(f().sub(o.f())); }
   FrT operator*(const FrT& o) const { return of(f().mul(o.f())); }
   FrT neg() const { return zero() - *this; }
+  FrT inverse() const { return of(f().inv()); }     // 0 -> 0
 };
 
 // Same memory layout as arkworks' short_weierstrass::Affine { x, y, infinity } (104 / 72 bytes).

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "../../poly-commit_amd/host/marlin_kzg10.hpp"
 #include "../../poly-commit_amd/host/linear_codes.hpp"
+#include "../../poly-commit_amd/host/ipa_pc.hpp"
 
 using namespace pc_host;
 
@@ -229,7 +230,52 @@ static void run(pc_ctx* ctx, const char* name) {
     CHECK(path.size() == (ark_log2(st.ext_mat.m) - 1) * 32 && memcmp(sib, st.leaves.data() + 4 * 32, 32) == 0);
     CHECK(memcmp(path.data() + path.size() - 32, st.nodes.data() + 2 * 32, 32) == 0);   // leaf 5 is in the left half: last sibling is node 2
   }
-  printf("%s: ligero reed_solomon/compute_matrices/commit/row_mul, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
+  // ---- InnerProductArgPC: cm_commit and the halving loop of open (ipa_pc/mod.rs:54-72, 664-711) against the
+  //      same rounds replayed with host point / field arithmetic ----
+  {
+    struct Fixed : IpaChallengeSource<E> {
+      std::vector<FrT<E>> u; size_t k = 0;
+      FrT<E> next(const G1Affine<E>&, const G1Affine<E>&) override { return u[k++]; }
+    } ch;
+    const size_t n0 = 8;
+    std::vector<G1Affine<E>> key; std::vector<FrT<E>> c, z;
+    for (size_t i = 0; i < n0; i++) { key.push_back(g.mul(rng.next_fr())); c.push_back(rng.next_fr()); }
+    for (int i = 0; i < 3; i++) ch.u.push_back(rng.next_fr());
+    const FrT<E> point = rng.next_fr();
+    const G1Affine<E> h_prime = g.mul(rng.next_fr());
+    G1Affine<E> cm;
+    CHECK(!InnerProductArgPC<E>::cm_commit(ctx, key, c, nullptr, nullptr, cm));
+    { G1Affine<E> want = G1Affine<E>::zero(); for (size_t i = 0; i < n0; i++) want = want.add(key[i].mul(c[i])); CHECK(cm == want); }
+    FrT<E> rnd = rng.next_fr();
+    G1Affine<E> cmh;
+    CHECK(!InnerProductArgPC<E>::cm_commit(ctx, key, c, &h_prime, &rnd, cmh));
+    CHECK(cmh == cm.add(h_prime.mul(rnd)));
+    IpaProof<E> proof;
+    CHECK(!InnerProductArgPC<E>::open_rounds(ctx, key, c, point, h_prime, ch, proof));
+    CHECK(proof.l_vec.size() == 3 && proof.r_vec.size() == 3 && ch.k == 3);
+    { FrT<E> cur = FrT<E>::one(); for (size_t i = 0; i < n0; i++) { z.push_back(cur); cur = cur * point; } }
+    size_t n = n0;
+    for (size_t round = 0; n > 1; round++) {
+      const size_t h = n / 2;
+      G1Affine<E> l = G1Affine<E>::zero(), r = G1Affine<E>::zero();
+      FrT<E> ipl = FrT<E>::zero(), ipr = FrT<E>::zero();
+      for (size_t i = 0; i < h; i++) {
+        l = l.add(key[i].mul(c[h + i])); r = r.add(key[h + i].mul(c[i]));
+        ipl = ipl + c[h + i] * z[i]; ipr = ipr + c[i] * z[h + i];
+      }
+      l = l.add(h_prime.mul(ipl)); r = r.add(h_prime.mul(ipr));
+      CHECK(l == proof.l_vec[round] && r == proof.r_vec[round]);
+      const FrT<E> u = ch.u[round], ui = u.inverse();
+      CHECK(u * ui == FrT<E>::one());
+      for (size_t i = 0; i < h; i++) { c[i] = c[i] + ui * c[h + i]; z[i] = z[i] + u * z[h + i]; key[i] = key[i].add(key[h + i].mul(u)); }
+      n = h;
+    }
+    CHECK(proof.final_comm_key == key[0] && proof.c == c[0]);
+    std::vector<FrT<E>> odd(c.begin(), c.begin() + 3);
+    std::vector<G1Affine<E>> k3(key.begin(), key.begin() + 3);
+    CHECK(InnerProductArgPC<E>::open_rounds(ctx, k3, odd, point, h_prime, ch, proof).kind == Error::Backend);    // not a power of two
+  }
+  printf("%s: ipa cm_commit/open rounds, ligero reed_solomon/compute_matrices/commit/row_mul, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
 }
 
 int main() {

@@ -16,7 +16,7 @@ def build():
         import importlib
         importlib.import_module("poly_commit_amd.build").build()
     src = os.path.join(ROOT, "tests", "cpp", "test_kzg10_host.cpp")
-    deps = [src, os.path.join(libdir, "host", "kzg10.hpp"), os.path.join(libdir, "libpc_hip.so")]
+    deps = [src, os.path.join(libdir, "libpc_hip.so")] + [os.path.join(libdir, "host", h) for h in os.listdir(os.path.join(libdir, "host"))]
     if os.path.exists(BIN) and os.path.getmtime(BIN) >= max(os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", BIN, src, "-L" + libdir, "-lpc_hip",
