@@ -83,3 +83,24 @@ def test_point_mul_host_utility(curve):
     for k in (0, 1, 2, R.FIELDS[fr]["p"] - 1, R.gen_scalars(fr, 5, 1)[0]):
         got = pc.point_mul(curve, O.points_to_array(curve, [P])[0], O.fr_mont_array(curve, [k])[0])
         assert O.array_to_points(curve, got)[0] == R.ec_mul(curve, k, P)
+
+
+def test_header_is_plain_c99_and_links(tmp_path):
+    """include/pc_hip.h is a C header (what cgo / bindgen / JNI stubs consume): a C99 translation unit that
+    takes the address of every declared entry point compiles with -pedantic and links against the library."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "pc_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(pc_hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pc_hip.h"\n#include <stdio.h>\nint main(void) {\n  const void* fns[] = {\n' +
+                   ",\n".join(f"    (const void*)(size_t)&{n}" for n in names) +
+                   "\n  };\n  printf(\"%d\\n\", (int)(sizeof fns / sizeof fns[0]));\n  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.join(root, "poly-commit_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L" + libdir, "-lpc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and int(out.stdout) == len(names)
