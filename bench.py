@@ -2,7 +2,8 @@
 """bench.py -- KZG commit+open hot path on MI355X (BASELINE.json configs[1]).
 
 One step = one MarlinKZG10<Bls12_381> commit + one single-point open of one dense
-polynomial of degree 2^20 per GPU, hiding off (the shape bench-templates times,
+polynomial of degree 2^24 per GPU (primary; the 2^20 case BASELINE.json also names is reported in the
+`secondary` block of the same JSON line), hiding off (the shape bench-templates times,
 bench-templates/src/lib.rs:69-84,106-138):
     commit : MSM of d+1 pairs over the resident SRS           (kzg10/mod.rs:175-178)
     open   : witness polynomial p/(x-z) on the device          (kzg10/mod.rs:217-240)
@@ -11,7 +12,7 @@ SRS, coefficients and the evaluation point's quotient stay in HBM; only the two 
 affine results come back to the host.  value = G1 (base, scalar) pairs per second, whole job.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ONE polynomial of degree
-N*2^20 whose SRS and coefficients are sharded in contiguous chunks (weak scaling: fixed pairs
+N*2^24 whose SRS and coefficients are sharded in contiguous chunks (weak scaling: fixed pairs
 per GPU); each rank runs the full Pippenger on its chunk and the partial commitments /
 opening proofs are combined with an all_gather + EC adds (RCCL has no EC reduce op); the
 division carry crosses ranks as one Fr element.  See poly-commit_amd/sharded.py.
@@ -224,14 +225,181 @@ def bench_batch(args):
         dist.destroy_process_group()
 
 
+def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, with_h2d):
+    """One KZG commit+open workload on this rank: timed legs + the post-region blocking MSMs.
+    Returns a dict (timings are this rank's; the caller takes the max over ranks)."""
+    import collections
+    import math
+    import torch
+    import oracle_lib as O          # synthetic inputs only (never the measured path)
+    from poly_commit_amd import sharded
+
+    d = 1 << log_degree
+    n = d + 1 if world == 1 else d          # coefficients held by this rank
+    # ---- synthetic inputs (SURVEY.md 8d): bases (i+1)G, coefficients SplitMix64(seed) -------
+    eng = sharded.HipEngine(ctx, curve)
+    job = sharded.ShardedKzg(eng, curve, rank, world, dist)
+    bases = O.gen_bases(curve, n + 1)       # +1: the open of shard r > 0 reaches one base back
+    job.load_srs_chunk(bases, precompute=bool(args.precompute))
+    del bases
+    coeffs_h = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0001 + rank, n))
+    coeffs = torch.from_numpy(coeffs_h.view(np.int64)).cuda()
+    z_mont = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x2EE7, 1))[0]
+    job.set_point(z_mont)
+    torch.cuda.synchronize()
+
+    depth = max(0, args.inflight)
+    pending = collections.deque()
+
+    def drain():
+        while pending:
+            pending.popleft().result()
+
+    def step_resident(_k):
+        # commit and open of one polynomial; up to `depth` results stay in flight so that the
+        # latency-bound tail of one MSM overlaps the bucket accumulation of the next
+        pending.append(job.commit_async(coeffs, n))
+        if depth == 0:                       # strictly blocking calls: the commitment is back before the open starts
+            pending.popleft().result()
+        pending.append(job.open_async(coeffs, n))
+        while len(pending) > depth:
+            pending.popleft().result()
+
+    def timed(step_fn, steps, warmup):
+        for k in range(warmup):
+            step_fn(k)
+        drain()
+        eng.phases = []
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step_fn(k)
+        drain()                              # every commitment and proof is on the host here
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, list(eng.phases)
+
+    if steps is None and dist is not None:
+        steps = 20          # every rank must run the same number of steps
+    if steps is None:       # no --steps: long enough for >= 1.2 s of timed region (the driver's gpu_busy sampler needs it)
+        t0 = time.perf_counter()
+        step_resident(0); drain()
+        torch.cuda.synchronize()
+        est = time.perf_counter() - t0
+        steps = max(10, int(math.ceil(1.2 / max(est, 1e-4))))
+    dt, phases = timed(step_resident, steps, warmup)
+    ph = np.mean(np.array(phases), axis=0) if phases else np.zeros(8)
+
+    # ---- the same steps with the coefficients handed over as HOST memory (what the Rust shim holds):
+    # one pinned H2D copy per polynomial (commit and open share it), double-buffered so that the copy of
+    # step k+1 overlaps the MSMs of step k.  Reported beside `value`, never as `value`.
+    h2d = None
+    if with_h2d and world == 1:
+        host = torch.from_numpy(coeffs_h.view(np.int64)).pin_memory()
+        bufs = [torch.empty_like(coeffs) for _ in range(3)]
+        cs = torch.cuda.Stream()
+        evs = [torch.cuda.Event() for _ in range(3)]
+
+        def issue_copy(k):
+            with torch.cuda.stream(cs):
+                bufs[k % 3].copy_(host, non_blocking=True)
+                evs[k % 3].record(cs)
+
+        started = set()
+
+        def step_h2d(k):
+            if k not in started:
+                issue_copy(k); started.add(k)
+            issue_copy(k + 1); started.add(k + 1)     # its buffer was last read by step k-2, drained by now
+            evs[k % 3].synchronize()
+            pending.append(job.commit_async(bufs[k % 3], n))
+            if depth == 0:
+                pending.popleft().result()
+            pending.append(job.open_async(bufs[k % 3], n))
+            while len(pending) > min(depth, 2):
+                pending.popleft().result()
+
+        dt_h, _ = timed(step_h2d, steps, warmup)
+        torch.cuda.synchronize()
+        h2d = {"ms_per_step": dt_h / steps * 1e3, "value": (2 * n - 1) * steps / dt_h, "unit": "pairs/s",
+               "note": "coefficients start in pinned HOST memory every step: one H2D copy of the polynomial per "
+                       "commit+open (32 B/coefficient), triple-buffered on its own stream so it overlaps the previous "
+                       "step's MSMs (SURVEY.md 8d: scalars H2D included)"}
+        del bufs, host
+
+    # The kernels without a second pipeline competing for the CUs: strictly serial MSMs after the
+    # timed region.  msm_phase_ms and roofline.serial come from these (they agree with rocprofv3's
+    # per-kernel averages); the timed-region brackets include queueing behind the other pipeline.
+    eng.phases = []
+    for _ in range(3):
+        job.commit_async(coeffs, n).result()
+    sp = np.mean(np.array(eng.phases), axis=0) if eng.phases else np.zeros(8)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        job.commit_async(coeffs, n).result()
+    blocking_msm_ms = (time.perf_counter() - t0) / 3 * 1e3
+
+    pairs_per_step = world * (2 * n - 1) if world == 1 else world * (2 * n) - 1
+    acc_ms, acc_serial_ms = float(ph[3]), float(sp[3])
+    pairs_per_launch = (2 * n - 1) / 2.0
+    bytes_per_launch = pairs_per_launch * PAIR_BYTES[curve]
+    achieved = bytes_per_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+    ach_serial = n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 if acc_serial_ms > 0 else None
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")       # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py);
+    if os.path.exists(tf):                                            # keyed by size and table mode, null when not measured
+        try:
+            key = f"{curve}:2^{log_degree}:{'table' if args.precompute else 'table-free'}"
+            traffic = json.load(open(tf)).get("accumulate_hbm_bytes_per_launch", {}).get(key)
+        except Exception:
+            traffic = None
+    res = {
+        "log_degree": log_degree, "steps": steps, "warmup": warmup, "dt": dt, "pairs_per_step": pairs_per_step,
+        "value": pairs_per_step * steps / dt, "ms_per_step": dt / steps * 1e3,
+        "commit_open_per_s": steps / dt if world == 1 else None,
+        "value_h2d_inclusive": h2d,
+        "srs_window_table_build_ms": eng.precompute_ms,
+        "blocking_msm_ms": blocking_msm_ms,
+        "msm_phase_ms": {k: float(v) for k, v in zip(
+            ["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], sp[:6])},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                     "kernel": "k_accumulate (bucket accumulation): average hipEvent bracket of its launches on the MSM "
+                               "pipelines' streams inside the timed region",
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "serial": {"kernel_ms": acc_serial_ms, "achieved": ach_serial,
+                                "frac": ach_serial / HBM_PEAK_GBPS if ach_serial else None,
+                                "algorithmic_bytes_per_launch": n * PAIR_BYTES[curve],
+                                "note": "the same kernel in 3 blocking commit MSMs after the timed region (no other pipeline "
+                                        "on the GPU): the figure rocprofv3's per-kernel average reproduces"}},
+    }
+    eng.srs.free()
+    del coeffs
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: as many as give >= 1.2 s of timed region, at least 10)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-degree", type=int, default=20)
+    ap.add_argument("--log-degree", type=int, default=24,
+                    help="degree of the primary workload (default 2^24: the north-star size; BASELINE.json's metric is "
+                         "quoted at 2^20 and 2^24 -- the other one is reported in the `secondary` block)")
+    ap.add_argument("--secondary-log-degree", type=int, default=20, help="0 = no secondary block")
     ap.add_argument("--curve", default="bls12_381")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-coefficients (H2D-inclusive) leg")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=2,
@@ -245,14 +413,18 @@ def main():
                          "(pc_hip_srs_precompute; part of SRS residency, outside the timed region); 0: table-free MSM")
     args = ap.parse_args()
     if args.workload == "ntt":
+        if args.steps is None:
+            args.steps = 100
         return bench_ntt(args)
     if args.workload == "batch":
+        if args.steps is None:
+            args.steps = 10
+        if args.log_degree == 24:
+            args.log_degree = 20
         return bench_batch(args)
 
     import torch
-    import oracle_lib as O          # synthetic inputs + cpu_baseline leg only (never the measured path)
     import poly_commit_amd as pc
-    from poly_commit_amd import sharded
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -268,113 +440,51 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     curve = args.curve
-    d = 1 << args.log_degree
-    n = d + 1 if world == 1 else d          # coefficients held by this rank
     ctx = pc.Context(local_rank)
     if args.window_bits or args.chunk:
         ctx.set_msm_tuning(args.window_bits, args.chunk)
     ctx.set_timing(True)
 
-    # ---- synthetic inputs: bases (i+1)G, coefficients SplitMix64(seed) -------
-    eng = sharded.HipEngine(ctx, curve)
-    job = sharded.ShardedKzg(eng, curve, rank, world, dist)
-    bases = O.gen_bases(curve, n + 1)       # +1: the open of shard r > 0 reaches one base back
-    job.load_srs_chunk(bases, precompute=bool(args.precompute))
-    coeffs_h = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0001 + rank, n))
-    coeffs = torch.from_numpy(coeffs_h.view(np.int64)).cuda()
-    z_mont = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x2EE7, 1))[0]
-    job.set_point(z_mont)
-    torch.cuda.synchronize()
-
-    import collections
-    depth = max(0, args.inflight)
-    pending = collections.deque()
-
-    def step():
-        # commit and open of one polynomial; up to `depth` results stay in flight so that the
-        # latency-bound tail of one MSM overlaps the bucket accumulation of the next
-        pending.append(job.commit_async(coeffs, n))
-        if depth == 0:                       # strictly blocking calls: the commitment is back before the open starts
-            pending.popleft().result()
-        pending.append(job.open_async(coeffs, n))
-        while len(pending) > depth:
-            pending.popleft().result()
-
-    def drain():
-        while pending:
-            pending.popleft().result()
-
-    ph_sum, n_msm = np.zeros(8), 0
-    for _ in range(args.warmup):
-        step()
-    drain()
-    eng.phases = []
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()                                  # every commitment and proof is on the host here
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    for ph in eng.phases:
-        ph_sum += np.array(ph); n_msm += 1
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # The same kernel without a second pipeline competing for the CUs: a few strictly serial MSMs after
-    # the timed region (reported beside the timed-region figure, which includes queueing behind the
-    # other pipeline's kernels).
-    eng.phases = []
-    for _ in range(3):
-        job.commit_async(coeffs, n).result()
-    acc_serial_ms = float(np.mean([ph[3] for ph in eng.phases])) if eng.phases else 0.0
-
-    pairs_per_step = world * (2 * n - 1) if world == 1 else world * (2 * n) - 1
-    value = pairs_per_step * args.steps / dt
-    ph = ph_sum / max(n_msm, 1)
-    # dominant kernel = bucket accumulation (phase index 3); algorithmic bytes = pairs * B/pair
-    acc_ms = float(ph[3])
-    pairs_per_launch = (2 * n - 1) / 2.0
-    achieved = pairs_per_launch * PAIR_BYTES[curve] / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+    prim = kzg_case(ctx, args, curve, args.log_degree, args.steps, args.warmup, world, rank, dist, with_h2d=not args.no_h2d)
+    sec = None
+    if world == 1 and args.secondary_log_degree and args.secondary_log_degree != args.log_degree:
+        sec = kzg_case(ctx, args, curve, args.secondary_log_degree, None, args.warmup, world, rank, dist,
+                       with_h2d=not args.no_h2d)
 
     if rank == 0:
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("accumulate_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        def cfg(lg):
+            return (f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{lg} per GPU, SRS resident, hiding off "
+                    f"(BASELINE metric sizes: 2^20 = configs[1], 2^24 = north-star target)")
         out = {
             "metric": "MSM G1-scalar-pairs/sec inside KZG commit+open (MarlinKZG10<Bls12_381> shape, hiding off)",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": prim["value"], "unit": "pairs/s", "n_gpus": world, "steps": prim["steps"], "warmup": prim["warmup"],
+            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer)", "data": "synthetic",
-            "config": {"workload": f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{args.log_degree} per GPU, "
-                                   f"SRS resident, hiding off (BASELINE configs[1])",
-                       "curve": curve, "log_degree": args.log_degree, "pairs_per_step": pairs_per_step,
-                       "inflight": depth, "srs_window_table": bool(args.precompute),
-                       "srs_window_table_build_ms": eng.precompute_ms,    # once per key, outside the timed region
+            "parity": "oracle-only (the reference holds no golden vector on this path; its arithmetic crates are not "
+                      "buildable here) -- see DESIGN.md section 2",
+            "config": {"workload": cfg(args.log_degree), "curve": curve, "log_degree": args.log_degree,
+                       "pairs_per_step": prim["pairs_per_step"], "inflight": max(0, args.inflight),
+                       "srs_window_table": bool(args.precompute),
+                       "srs_window_table_build_ms": prim["srs_window_table_build_ms"],    # once per key, outside the timed region
+                       "coefficients": "device-resident when the timed region starts (value); pinned host memory "
+                                       "(value_h2d_inclusive)",
                        "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients sharded in {world} contiguous chunks, "
                                                                  f"all_gather of partial points"},
-            "commit_open_per_s": args.steps / dt if world == 1 else None,
-            "msm_phase_ms": {k: float(v) for k, v in zip(
-                ["digits_hist", "scan", "scatter", "accumulate", "seg_reduce", "bucket_reduce"], ph[:6])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_accumulate (bucket accumulation), avg of hipEvent-timed launches on the MSM pipelines' streams",
-                         "algorithmic_bytes_per_launch": pairs_per_launch * PAIR_BYTES[curve],
-                         "serial": {"kernel_ms": acc_serial_ms,
-                                    "achieved": n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 if acc_serial_ms > 0 else None,
-                                    "frac": n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc_serial_ms > 0 else None,
-                                    "note": "3 blocking commit MSMs after the timed region: no other pipeline on the GPU"}},
+            "commit_open_per_s": prim["commit_open_per_s"],
+            "value_h2d_inclusive": prim["value_h2d_inclusive"],
+            "blocking_msm_ms": prim["blocking_msm_ms"],
+            "msm_phase_ms": prim["msm_phase_ms"],
+            "roofline": prim["roofline"],
         }
+        if sec is not None:
+            out["secondary"] = {
+                "config": {"workload": cfg(sec["log_degree"]), "log_degree": sec["log_degree"],
+                           "pairs_per_step": sec["pairs_per_step"],
+                           "srs_window_table_build_ms": sec["srs_window_table_build_ms"]},
+                "value": sec["value"], "unit": "pairs/s", "steps": sec["steps"], "warmup": sec["warmup"],
+                "ms_per_step": sec["ms_per_step"], "commit_open_per_s": sec["commit_open_per_s"],
+                "value_h2d_inclusive": sec["value_h2d_inclusive"], "blocking_msm_ms": sec["blocking_msm_ms"],
+                "msm_phase_ms": sec["msm_phase_ms"], "roofline": sec["roofline"]}
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(curve, args.log_degree)
         print(json.dumps(out))

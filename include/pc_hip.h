@@ -140,7 +140,11 @@ int pc_hip_set_timing(pc_ctx* ctx, int on);
  * in: rows x in_cols elements (row-major, Montgomery), in_cols <= 2^log_n; each row is
  * zero-padded to 2^log_n and transformed; out: rows x 2^log_n, natural order,
  * out[r][j] = sum_i in[r][i] * omega^(i j) with arkworks' omega (pinned by
- * test_reed_solomon, utils.rs:303-331). */
+ * test_reed_solomon, utils.rs:303-331).
+ * log_n <= PC_HIP_NTT_MAX_LOG_N (the transform runs as two LDS-staged passes of 2^ceil(log_n/2) and
+ * 2^floor(log_n/2) points; Ligero's rows are 2^17 at 2^24 coefficients); larger sizes return
+ * PC_ERR_UNSUPPORTED before anything is allocated. */
+#define PC_HIP_NTT_MAX_LOG_N 22
 int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem where_in, size_t rows,
                      size_t in_cols, unsigned log_n, void* out, pc_mem where_out);
 /* Kernel-only milliseconds of the last pc_hip_ntt_batch: [pass A, pass B]. */

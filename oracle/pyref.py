@@ -270,11 +270,22 @@ def ark_log2(x):
     return (x - 1).bit_length()
 
 
+def _is_normal(x):
+    return x == x and abs(x) != float("inf") and abs(x) >= 2.2250738585072014e-308
+
+
 def calculate_t(field_bits, sec_param, distance, codeword_len):
+    """linear_codes/utils.rs:156-184; Err(InvalidParameters) -> ValueError."""
     residual = codeword_len / 2.0 ** field_bits
-    rhs = math.log2(2.0 ** (-sec_param) - residual)
+    arg = 2.0 ** (-sec_param) - residual
+    rhs = math.log2(arg) if arg > 0 else float("nan")          # f64::log2 of <= 0 is NaN / -inf: not normal
+    if not _is_normal(rhs):
+        raise ValueError("the field is not big enough for this codeword length and security parameter")
     nom = rhs - 1.0
-    denom = math.log2(1.0 - 0.5 * distance[0] / distance[1])
+    darg = 1.0 - 0.5 * distance[0] / distance[1]
+    denom = math.log2(darg) if darg > 0 else float("nan")
+    if not _is_normal(denom):
+        raise ValueError("the distance is wrong")
     t = math.ceil(nom / denom)
     return t if t < codeword_len else codeword_len
 

@@ -1,119 +1,20 @@
 // C ABI of the gfx950 backend (include/pc_hip.h).  Thin glue: context/SRS lifetime, buffer
-// staging, error translation.  The work is in msm.hpp / ntt.hpp.
+// staging, error translation.  The kernels live in the per-curve / per-field translation units
+// (curve_*.hip, field_*.hip) and are reached through the ops tables of pc_internal.hpp.
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
 #include <vector>
-#include "../../include/pc_hip.h"
-#include "hip_backend.hpp"
-#include "msm.hpp"
-#include "msm_coop.hpp"
-#include "msm_sort.hpp"
 #include <stdlib.h>
 #include <string.h>
+#include "pc_internal.hpp"
 
-namespace pc {
-template <class C>
-void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_t* hist, uint32_t* offsets, uint32_t* cursor,
-                              uint32_t* entries) {
-  if (sort_mode < 0) { const char* e = getenv("PC_HIP_SORT"); sort_mode = (e && !strcmp(e, "atomic")) ? 0 : 1; }
-  if (sort_mode == 0) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }
-  SortGeom sg = make_sort_geom(g, C::FrP::BITS);
-  if (sg.fine_bits > 10 || sg.NC > 16384) {   // c > 22, or more bucket sets than the LDS histogram holds
-    sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return;
-  }
-  // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)
-  const size_t gw = (size_t)sg.nblocks * sg.NC, nb1 = (size_t)sg.NC + 1;
-  const size_t rec_off = ((gw + 2 * nb1) * 4 + 15) & ~(size_t)15;
-  const size_t need = rec_off + (size_t)g.n * g.Wd * 8;
-  if (need > sort_ws_bytes) {
-    if (sort_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0; }
-    PC_HIP_CHECK(hipMalloc(&sort_ws, need)); sort_ws_bytes = need;
-  }
-  uint32_t* G = (uint32_t*)sort_ws; uint32_t* bintotal = G + gw; uint32_t* binbase = bintotal + nb1;
-  uint2* records = (uint2*)((char*)sort_ws + rec_off);
-  const size_t lds = (size_t)sg.NC * 4;
-  if (lds > 64 * 1024) {
-    PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  // a large LDS histogram leaves one workgroup per CU: make it 16 waves so latency stays hidden
-  const int sort_threads = lds > 32 * 1024 ? 1024 : 256;
-  hipLaunchKernelGGL((k_sort_pass<C, false>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)nullptr, (uint2*)nullptr);
-  PC_HIP_CHECK(hipGetLastError());
-  mark();   // 1: digits + coarse histogram
-  hipLaunchKernelGGL(k_sort_binscan, dim3((sg.NC + 15) / 16), dim3(256), 0, stream, G, sg.nblocks, sg.NC, bintotal);
-  PC_HIP_CHECK(hipGetLastError());
-  exclusive_scan_u32(bintotal, binbase, nb1);
-  mark();   // 2: scans
-  hipLaunchKernelGGL((k_sort_pass<C, true>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)binbase, records);
-  PC_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_sort_fine, dim3(sg.NC), dim3(256), 0, stream, sg, (const uint32_t*)binbase, (const uint2*)records, entries, offsets);
-  PC_HIP_CHECK(hipGetLastError());
-  mark();   // 3: coarse scatter + fine sort
-}
-
-template <class C>
-void HipBackend::accumulate(const AccumulateBody<C>& body, size_t lanes) {
-  if (lanes == 0) return;
-  hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, body, (uint32_t)lanes);
-  PC_HIP_CHECK(hipGetLastError());
-}
-
-template <class C>
-void HipBackend::seg_reduce_tail(const MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
-                                 const uint32_t* offsets, uint32_t* buckets) {
-  hipLaunchKernelGGL(k_seg_reduce_tail<C>, dim3(1), dim3(256), 0, stream, g, level, slots, pk[0], pk[1], pp[0], pp[1], cur, offsets, buckets);
-  PC_HIP_CHECK(hipGetLastError());
-}
-
-template <class C>
-void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, bool bits, const uint32_t* x,
-                              const uint32_t* old_in, uint32_t* out) {
-  if (bits) {   // 16 <= K <= 256: one workgroup of K lanes per group
-    uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
-    size_t lds = (size_t)K * XyzzD<C>::WORDS * 4;
-    hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, lgK, weight_off, cnt, n_old, x,
-                       old_in, out);
-    PC_HIP_CHECK(hipGetLastError());
-  } else {
-    BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
-    launch(b, (size_t)cnt * (1 + n_old));
-  }
-}
-}  // namespace pc
-#include "ntt.hpp"
-#include "poly.hpp"
-#include "ipa.hpp"
-#include "hash.hpp"
-#include "glv.hpp"
-#include <map>
-#include <memory>
+using pc::MsmRunner;
+using pc::NttRunner;
 
 namespace {
-
-struct MsmRunner {
-  virtual ~MsmRunner() {}
-  virtual void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) = 0;
-  virtual void finish(uint32_t* out_host) = 0;
-};
-
-template <class C>
-struct MsmRunnerT : MsmRunner {
-  pc::HipBackend& be;
-  pc::MsmPlan<C, pc::HipBackend> plan;
-  MsmRunnerT(pc::HipBackend& b, size_t n, const pc::MsmConfig& cfg, uint32_t subs = 0) : be(b), plan(b, n, cfg, subs) {}
-  void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) override {
-    const uint32_t* sdev = (const uint32_t*)scalars;
-    be.n_ev = 0; be.mark();
-    if (where == PC_MEM_HOST && n) {
-      be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
-      sdev = plan.scalar_staging();
-    }
-    plan.enqueue(bases, base_off, sdev, n, from_mont);
-  }
-  void finish(uint32_t* out_host) override { plan.finish(out_host); }
-};
 
 // One independent MSM pipeline: own stream, own workspace.  Several lanes per SRS let the
 // latency-bound tail of one MSM (segmented / bucket reduction, download, host Horner) overlap
@@ -126,17 +27,6 @@ struct MsmLane {
 };
 
 }  // namespace
-
-struct NttRunner {
-  virtual ~NttRunner() {}
-  virtual void run(const uint32_t* in, size_t rows, size_t in_cols, uint32_t* out) = 0;
-};
-template <class FrP>
-struct NttRunnerT : NttRunner {
-  pc::NttPlan<FrP> plan;
-  NttRunnerT(pc::HipBackend& be, unsigned log_n) : plan(be, log_n) {}
-  void run(const uint32_t* in, size_t rows, size_t in_cols, uint32_t* out) override { plan.run(in, rows, in_cols, out); }
-};
 
 struct pc_ctx {
   std::map<std::pair<int, unsigned>, std::unique_ptr<NttRunner>> ntt_plans;
@@ -183,6 +73,8 @@ static int guarded(pc_ctx* ctx, Fn fn) {
   } catch (const pc::HipError& e) {
     ctx->last_error = e.what();
     return e.code == hipErrorOutOfMemory ? PC_ERR_OOM : PC_ERR_HIP;
+  } catch (const pc::MsmCapacityError& e) {
+    ctx->last_error = e.what(); return PC_ERR_TOO_LARGE;
   } catch (const std::bad_alloc&) {
     ctx->last_error = "host allocation failed"; return PC_ERR_OOM;
   } catch (const std::exception& e) {
@@ -203,11 +95,7 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
     // priority-created streams measured 5 % slower at 2^22 even with the split unused)
     L->be.tail_split = tsplit && srs->n <= ((size_t)3 << 19);
     if (i == 0 || !split) L->be.init(); else L->be.init(i - 1, PC_MSM_LANES - 1);
-    switch (srs->curve) {
-      case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, srs->n, srs->cfg); break;
-      case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, srs->n, srs->cfg); break;
-      default: L->runner = new MsmRunnerT<pc_curve_pallas>(L->be, srs->n, srs->cfg); break;
-    }
+    L->runner = pc::curve_ops(srs->curve).make_runner(L->be, srs->n, srs->cfg, 0);
   } catch (...) { delete L; throw; }
   srs->lanes[i] = L;
   return L;
@@ -217,6 +105,9 @@ static MsmLane* srs_lane(pc_srs* srs, int i) {
 static void complete_job(pc_ctx* ctx, pc_job* job) {
   pc_srs* srs = job->srs;
   MsmLane* L = srs->lanes[job->lane];
+  // Whatever happens below (finish() may throw on a HIP error), the lane must not keep a pointer to this
+  // job: it may live on the caller's stack (pc_hip_msm, pc_hip_msm_batch) or be deleted by pc_hip_job_wait.
+  L->inflight = nullptr; job->done = true; job->status = PC_ERR_HIP;
   L->runner->finish(job->out_xy);
   if (job->out_inf) {
     uint32_t acc = 0;
@@ -225,7 +116,7 @@ static void complete_job(pc_ctx* ctx, pc_job* job) {
   }
   for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
   if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
-  job->done = true; L->inflight = nullptr;
+  job->status = PC_OK;
 }
 
 // Queue one MSM on the next lane (completing whatever that lane still holds).
@@ -401,12 +292,7 @@ int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t
     const size_t bytes = (size_t)Wd * srs->n * pt_stride * 4;
     uint32_t* table = (uint32_t*)ctx->be.alloc(bytes);
     try {
-      switch (srs->curve) {
-        case PC_CURVE_BLS12_381: { pc::WindowTableBody<pc_curve_bls12_381> b{srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride}; ctx->be.launch(b, srs->n, 64); } break;
-        case PC_CURVE_BN254: { pc::WindowTableBody<pc_curve_bn254> b{srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride}; ctx->be.launch(b, srs->n, 64); } break;
-        default: { pc::WindowTableBody<pc_curve_pallas> b{srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride}; ctx->be.launch(b, srs->n, 64); } break;
-      }
-      ctx->be.sync();
+      pc::curve_ops(srs->curve).window_table(ctx->be, srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride);
     } catch (...) { ctx->be.free(table); throw; }
     for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
     srs->table = table;
@@ -517,21 +403,12 @@ int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* sc
       MsmLane* L = nullptr;
       try {
         const uint32_t* b0 = srs->bases + base_offset * srs->aw;
-        switch (srs->curve) {
-          case PC_CURVE_BLS12_381: { pc::WindowTableBody<pc_curve_bls12_381> b{b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw}; ctx->be.launch(b, m, 64); } break;
-          case PC_CURVE_BN254: { pc::WindowTableBody<pc_curve_bn254> b{b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw}; ctx->be.launch(b, m, 64); } break;
-          default: { pc::WindowTableBody<pc_curve_pallas> b{b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw}; ctx->be.launch(b, m, 64); } break;
-        }
-        ctx->be.sync();
+        pc::curve_ops(srs->curve).window_table(ctx->be, b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw);
         pc::MsmConfig cfg = srs->cfg;
         cfg.c = 0; cfg.T = 0; cfg.tbl = table; cfg.tbl_c = c; cfg.tbl_stride = (uint32_t)m; cfg.tbl_pt_stride = (uint32_t)srs->aw; cfg.tbl_min_n = 0;
         L = new MsmLane();
         L->be.init();
-        switch (srs->curve) {
-          case PC_CURVE_BLS12_381: L->runner = new MsmRunnerT<pc_curve_bls12_381>(L->be, n_msms * m, cfg, (uint32_t)n_msms); break;
-          case PC_CURVE_BN254: L->runner = new MsmRunnerT<pc_curve_bn254>(L->be, n_msms * m, cfg, (uint32_t)n_msms); break;
-          default: L->runner = new MsmRunnerT<pc_curve_pallas>(L->be, n_msms * m, cfg, (uint32_t)n_msms); break;
-        }
+        L->runner = pc::curve_ops(srs->curve).make_runner(L->be, n_msms * m, cfg, (uint32_t)n_msms);
       } catch (...) { delete L; ctx->be.free(table); throw; }
       M.table = table; M.lane = L; M.base_offset = base_offset; M.m = m; M.B = n_msms;
     }
@@ -573,7 +450,8 @@ int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem wher
                      unsigned log_n, void* out, pc_mem where_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || (rows && (!in || !out))) return PC_ERR_INVALID_ARG;
   const unsigned max_lg = field_of == PC_CURVE_BN254 ? 28 : 32;
-  if (log_n > max_lg || log_n > 27) return PC_ERR_TOO_LARGE;
+  if (log_n > max_lg) return PC_ERR_TOO_LARGE;
+  if (log_n > PC_HIP_NTT_MAX_LOG_N) return PC_ERR_UNSUPPORTED;   // two LDS-staged passes: one factor must fit the 160 KB LDS
   if (in_cols > ((size_t)1 << log_n)) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
@@ -581,12 +459,7 @@ int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem wher
     auto key = std::make_pair((int)field_of, log_n);
     auto it = ctx->ntt_plans.find(key);
     if (it == ctx->ntt_plans.end()) {
-      std::unique_ptr<NttRunner> r;
-      switch (field_of) {
-        case PC_CURVE_BLS12_381: r.reset(new NttRunnerT<pc_bls12_381_fr>(ctx->be, log_n)); break;
-        case PC_CURVE_BN254: r.reset(new NttRunnerT<pc_bn254_fr>(ctx->be, log_n)); break;
-        default: r.reset(new NttRunnerT<pc_pallas_fr>(ctx->be, log_n)); break;
-      }
+      std::unique_ptr<NttRunner> r(pc::field_ops(field_of).make_ntt(ctx->be, log_n));
       it = ctx->ntt_plans.emplace(key, std::move(r)).first;
     }
     const size_t N = (size_t)1 << log_n;
@@ -618,11 +491,7 @@ int pc_hip_poly_eval(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem 
   return guarded(ctx, [&]() {
     Staged sin(ctx->be, coeffs, where_in, n * 32, true);
     const uint32_t* z = (const uint32_t*)z_host;
-    switch (field_of) {
-      case PC_CURVE_BLS12_381: pc::poly_eval<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan()); break;
-      case PC_CURVE_BN254: pc::poly_eval<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan()); break;
-      default: pc::poly_eval<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan()); break;
-    }
+    pc::field_ops(field_of).poly_eval(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan());
     return (int)PC_OK;
   });
 }
@@ -637,32 +506,15 @@ int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_
     Staged sin(ctx->be, coeffs, where_in, n * 32, true);
     Staged sout(ctx->be, out, where_out, n * 32, false);
     const uint32_t* z = (const uint32_t*)z_host; const uint32_t* cin = (const uint32_t*)carry_in_host;
-    switch (field_of) {
-      case PC_CURVE_BLS12_381: pc::div_scan<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan()); break;
-      case PC_CURVE_BN254: pc::div_scan<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan()); break;
-      default: pc::div_scan<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan()); break;
-    }
+    pc::field_ops(field_of).div_scan(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan());
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n * 32);
     return (int)PC_OK;
   });
 }
 
-extern "C++" {
-template <class C>
-static void points_sum_t(const uint32_t* pts, size_t count, uint32_t* out) {
-  constexpr int AW = 2 * C::FqP::N;
-  pc::XyzzD<C> acc = pc::XyzzD<C>::infinity();
-  for (size_t i = 0; i < count; i++) acc.add_affine(pc::AffD<C>::load(pts + i * AW));
-  acc.to_affine().store(out);
-}
-}  // extern "C++"
 int pc_hip_points_sum(pc_curve curve, const void* points_xy, size_t count, void* out_xy) {
   if ((int)curve < 0 || (int)curve > 2 || !out_xy || (count && !points_xy)) return PC_ERR_INVALID_ARG;
-  switch (curve) {
-    case PC_CURVE_BLS12_381: points_sum_t<pc_curve_bls12_381>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
-    case PC_CURVE_BN254: points_sum_t<pc_curve_bn254>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
-    default: points_sum_t<pc_curve_pallas>((const uint32_t*)points_xy, count, (uint32_t*)out_xy); break;
-  }
+  pc::curve_ops(curve).points_sum((const uint32_t*)points_xy, count, (uint32_t*)out_xy);
   return PC_OK;
 }
 
@@ -678,15 +530,7 @@ int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_m
     Staged sout(ctx->be, out_digests, where_out, n_cols * 32, false);
     const uint32_t* e = (const uint32_t*)sin.dev; uint32_t* o = (uint32_t*)sout.dev;
     ctx->be.n_ev = 0; ctx->be.mark();
-#define PC_COLHASH(FrP)                                                                                              \
-    if (hash == PC_HASH_SHA256) { pc::ColumnHashBody<FrP, pc::Sha256> b{e, (uint32_t)rows, (uint32_t)n_cols, o}; ctx->be.launch(b, n_cols, 64); } \
-    else { pc::ColumnHashBody<FrP, pc::Blake2s256> b{e, (uint32_t)rows, (uint32_t)n_cols, o}; ctx->be.launch(b, n_cols, 64); }
-    switch (field_of) {
-      case PC_CURVE_BLS12_381: PC_COLHASH(pc_bls12_381_fr) break;
-      case PC_CURVE_BN254: PC_COLHASH(pc_bn254_fr) break;
-      default: PC_COLHASH(pc_pallas_fr) break;
-    }
-#undef PC_COLHASH
+    pc::field_ops(field_of).column_hash(ctx->be, (int)hash, e, (uint32_t)rows, (uint32_t)n_cols, o);
     ctx->be.mark();
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out_digests, sout.dev, n_cols * 32); else ctx->be.sync();
     ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
@@ -705,11 +549,7 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
     Staged sin(ctx->be, coeffs, where_in, n * 32, true);
     Staged sout(ctx->be, out, where_out, (n - 1) * 32, false);
     const uint32_t* z = (const uint32_t*)z_host;
-    switch (field_of) {
-      case PC_CURVE_BLS12_381: pc::witness_polynomial<pc_bls12_381_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan()); break;
-      case PC_CURVE_BN254: pc::witness_polynomial<pc_bn254_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan()); break;
-      default: pc::witness_polynomial<pc_pallas_fr>(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan()); break;
-    }
+    pc::field_ops(field_of).witness(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan());
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, (n - 1) * 32);
     return (int)PC_OK;
   });
@@ -717,70 +557,12 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
 
 
 // ---- IPA round kernels --------------------------------------------------------------------
-extern "C++" {
-template <class FrP>
-static void fr_fold_t(pc::HipBackend& be, uint32_t* lo, const uint32_t* hi, size_t n, const uint32_t* s) {
-  pc::FrFoldBody<FrP> b{lo, hi, pc::Fd<FrP>::load(s)};
-  be.launch(b, n); be.sync();
-}
-template <class FrP>
-static void fr_dot_t(pc::HipBackend& be, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
-  typedef pc::Fd<FrP> F;
-  // stage 1: up to 2^17 strided partial products-sums (wide); stage 2: 256 strided sums of those;
-  // the host folds the last 256 (~15 us)
-  const uint32_t wide = n < (1u << 17) ? (uint32_t)(n ? n : 1) : (1u << 17);
-  const uint32_t lanes = wide < 256 ? wide : 256;
-  static thread_local std::vector<uint32_t> h;
-  h.resize((size_t)lanes * FrP::N);
-  const size_t need = ((size_t)wide + lanes) * FrP::N * 4;
-  if (need > be.scan_tmp_bytes) {      // reuse the backend's small scratch buffer
-    if (be.scan_tmp) { be.sync(); (void)hipFree(be.scan_tmp); }
-    PC_HIP_CHECK(hipMalloc(&be.scan_tmp, need)); be.scan_tmp_bytes = need;
-  }
-  uint32_t* part1 = (uint32_t*)be.scan_tmp; uint32_t* part = part1 + (size_t)wide * FrP::N;
-  pc::FrDotBody<FrP> body{a, b, (uint32_t)n, wide, part1};
-  be.launch(body, wide);
-  pc::FrSumBody<FrP> body2{part1, wide, lanes, part};
-  be.launch(body2, lanes);
-  be.copy_d2h(h.data(), part, h.size() * 4);
-  F acc = F::zero();
-  for (uint32_t t = 0; t < lanes; t++) acc = acc.add(F::load(&h[(size_t)t * FrP::N]));
-  acc.store(out);
-}
-template <class FrP>
-static void fr_powers_t(pc::HipBackend& be, const uint32_t* z, size_t n, uint32_t* out) {
-  typedef pc::Fd<FrP> F;
-  pc::FrPowersBody<FrP> body; body.out = out;
-  F w = F::load(z);
-  for (int k = 0; k < 32; k++) { w.store(body.pt.w[k]); w = w.sqr(); }
-  be.launch(body, n); be.sync();
-}
-template <class C>
-static void ec_fold_t(pc::HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
-  typedef typename pc::GlvOf<C>::T G;
-  pc::Fd<typename C::FrP> u = pc::Fd<typename C::FrP>::load(u_mont).from_mont();
-  uint64_t k[4]; memcpy(k, u.l, 32);
-  pc::GlvSplit sp = pc::glv_decompose<G>(k);
-  pc::EcFoldGlvBody<C> body; body.key = key; body.half = (uint32_t)half;
-  body.n1.from_scalar(sp.k1); body.n2.from_scalar(sp.k2); body.neg1 = sp.neg1; body.neg2 = sp.neg2;
-  for (int i = 0; i < C::FqP::N; i++) body.beta[i] = G::BETA_MONT[i];
-  be.launch(body, half, 64); be.sync();
-}
-}  // extern "C++"
-
-#define FIELD_DISPATCH(field_of, CALL)                                        \
-  switch (field_of) {                                                         \
-    case PC_CURVE_BLS12_381: { typedef pc_bls12_381_fr FrP; CALL; } break;    \
-    case PC_CURVE_BN254: { typedef pc_bn254_fr FrP; CALL; } break;            \
-    default: { typedef pc_pallas_fr FrP; CALL; } break;                       \
-  }
-
 int pc_hip_fr_fold(pc_ctx* ctx, pc_curve field_of, void* lo_dev, const void* hi_dev, size_t n_half, const void* s_host) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !s_host || (n_half && (!lo_dev || !hi_dev))) return PC_ERR_INVALID_ARG;
   if (n_half >= (1ull << 32)) return PC_ERR_TOO_LARGE;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    if (n_half) FIELD_DISPATCH(field_of, fr_fold_t<FrP>(ctx->be, (uint32_t*)lo_dev, (const uint32_t*)hi_dev, n_half, (const uint32_t*)s_host));
+    if (n_half) pc::field_ops(field_of).fr_fold(ctx->be, (uint32_t*)lo_dev, (const uint32_t*)hi_dev, n_half, (const uint32_t*)s_host);
     return (int)PC_OK;
   });
 }
@@ -789,7 +571,7 @@ int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void*
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    FIELD_DISPATCH(field_of, fr_dot_t<FrP>(ctx->be, (const uint32_t*)a_dev, (const uint32_t*)b_dev, n, (uint32_t*)out_host));
+    pc::field_ops(field_of).fr_dot(ctx->be, (const uint32_t*)a_dev, (const uint32_t*)b_dev, n, (uint32_t*)out_host);
     return (int)PC_OK;
   });
 }
@@ -798,15 +580,16 @@ int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t 
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    if (n) FIELD_DISPATCH(field_of, fr_powers_t<FrP>(ctx->be, (const uint32_t*)z_host, n, (uint32_t*)out_dev));
+    if (n) pc::field_ops(field_of).fr_powers(ctx->be, (const uint32_t*)z_host, n, (uint32_t*)out_dev);
     return (int)PC_OK;
   });
 }
 int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
                          unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
                          pc_mem where_ext, void* leaves_out_host, void* nodes_out_host) {
-  if (!ctx || !rows || !in_cols || !mat || !nodes_out_host || log_n > 27 || in_cols > ((size_t)1 << log_n))
+  if (!ctx || !rows || !in_cols || !mat || !nodes_out_host || log_n > 32 || in_cols > ((size_t)1 << log_n))
     return PC_ERR_INVALID_ARG;
+  if (log_n > PC_HIP_NTT_MAX_LOG_N) return PC_ERR_UNSUPPORTED;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   const size_t N = (size_t)1 << log_n;
   void* ext = nullptr; void* leaves = nullptr; void* nodes = nullptr;
@@ -846,13 +629,6 @@ int pc_hip_last_ligero_phases_ms(const pc_ctx* ctx, float out[4]) {
   return PC_OK;
 }
 
-extern "C++" {
-template <class FrP>
-static void fr_lincomb_t(pc::HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out) {
-  pc::FrLinCombBody<FrP> b{(const uint64_t*)addr, (const uint32_t*)lens, (const uint32_t*)xi, (uint32_t)k, (uint32_t*)out};
-  be.launch(b, n_out, 256);
-}
-}
 int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_mem where_in, size_t n_leaves,
                        int len_prefix, void* out_nodes, pc_mem where_out) {
   if (!ctx || ((int)hash != PC_HASH_SHA256 && (int)hash != PC_HASH_BLAKE2S) || !n_leaves || !leaf_digests || !out_nodes)
@@ -871,13 +647,7 @@ int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_m
       const size_t cnt = (size_t)1 << d;
       const uint32_t* child = bottom ? (const uint32_t*)sin.dev : nodes + (((size_t)2 << d) - 1) * 8;
       uint32_t* parent = nodes + (cnt - 1) * 8;
-      if (hash == PC_HASH_SHA256) {
-        pc::MerkleLevelBody<pc::Sha256> b{child, parent, (uint32_t)n_leaves, bottom ? 1u : 0u, len_prefix ? 1u : 0u};
-        ctx->be.launch(b, cnt, 64);
-      } else {
-        pc::MerkleLevelBody<pc::Blake2s256> b{child, parent, (uint32_t)n_leaves, bottom ? 1u : 0u, len_prefix ? 1u : 0u};
-        ctx->be.launch(b, cnt, 64);
-      }
+      pc::merkle_level(ctx->be, (int)hash, child, parent, (uint32_t)n_leaves, bottom ? 1u : 0u, len_prefix ? 1u : 0u, cnt);
     }
     ctx->be.mark();
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out_nodes, sout.dev, n_nodes * 32); else ctx->be.sync();
@@ -917,7 +687,7 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
     Staged dxi(ctx->be, xi_host, PC_MEM_HOST, (k ? k : 1) * 32, k != 0);
     Staged sout(ctx->be, out, where_out, n_out * 32, false);
     ctx->be.n_ev = 0; ctx->be.mark();
-    FIELD_DISPATCH(field_of, fr_lincomb_t<FrP>(ctx->be, daddr.dev, dlen.dev, dxi.dev, k, sout.dev, n_out));
+    pc::field_ops(field_of).fr_lincomb(ctx->be, daddr.dev, dlen.dev, dxi.dev, k, sout.dev, n_out);
     ctx->be.mark();
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n_out * 32); else ctx->be.sync();
     ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
@@ -934,50 +704,15 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) 
     if (!n_half) return (int)PC_OK;
     drop_table(srs);                            // the key changes: its window tables are stale
     drop_many(srs);
-    switch (srs->curve) {
-      case PC_CURVE_BLS12_381: ec_fold_t<pc_curve_bls12_381>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
-      case PC_CURVE_BN254: ec_fold_t<pc_curve_bn254>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
-      default: ec_fold_t<pc_curve_pallas>(ctx->be, srs->bases, n_half, (const uint32_t*)u_host); break;
-    }
+    pc::curve_ops(srs->curve).ec_fold(ctx->be, srs->bases, n_half, (const uint32_t*)u_host);
     return (int)PC_OK;
   });
 }
-extern "C++" {
-template <class C>
-static void point_mul_t(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out) {
-  typedef pc::host64::Xyzz64<C> P64;
-  constexpr int FW = C::FqP::N;
-  pc::Fd<typename C::FrP> k = pc::Fd<typename C::FrP>::load(k_mont).from_mont();
-  bool inf = true; for (int i = 0; i < 2 * FW; i++) inf &= pt[i] == 0;
-  P64 base = P64::infinity();
-  if (!inf) {
-    base.X = P64::Fq::load(pt); base.Y = P64::Fq::load(pt + FW); base.ZZ = P64::Fq::one(); base.ZZZ = P64::Fq::one();
-  }
-  P64 acc = P64::infinity();
-  for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
-    acc = acc.dbl();
-    if ((k.l[bit >> 5] >> (bit & 31)) & 1) acc.add(base);
-  }
-  acc.store_affine(out);
-}
-}  // extern "C++"
 int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy) {
   if ((int)curve < 0 || (int)curve > 2 || !point_xy || !scalar_mont || !out_xy) return PC_ERR_INVALID_ARG;
-  switch (curve) {
-    case PC_CURVE_BLS12_381: point_mul_t<pc_curve_bls12_381>((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy); break;
-    case PC_CURVE_BN254: point_mul_t<pc_curve_bn254>((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy); break;
-    default: point_mul_t<pc_curve_pallas>((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy); break;
-  }
+  pc::curve_ops(curve).point_mul((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy);
   return PC_OK;
 }
-extern "C++" {
-template <class C>
-static void fixed_base_t(pc::HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out) {
-  pc::FixedBaseMulBody<C> body; body.scalars = scalars; body.out = out;
-  for (int i = 0; i < pc::FixedBaseMulBody<C>::AW; i++) body.g[i] = g[i];
-  be.launch(body, n, 64); be.sync();
-}
-}  // extern "C++"
 int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_host, const void* scalars_dev, size_t n,
                                 void* out_points_dev) {
   if (!ctx || (int)curve < 0 || (int)curve > 2 || !g_xy_host || (n && (!scalars_dev || !out_points_dev))) return PC_ERR_INVALID_ARG;
@@ -985,11 +720,7 @@ int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_ho
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (!n) return (int)PC_OK;
-    switch (curve) {
-      case PC_CURVE_BLS12_381: fixed_base_t<pc_curve_bls12_381>(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev); break;
-      case PC_CURVE_BN254: fixed_base_t<pc_curve_bn254>(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev); break;
-      default: fixed_base_t<pc_curve_pallas>(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev); break;
-    }
+    pc::curve_ops(curve).fixed_base(ctx->be, (const uint32_t*)g_xy_host, (const uint32_t*)scalars_dev, n, (uint32_t*)out_points_dev);
     return (int)PC_OK;
   });
 }

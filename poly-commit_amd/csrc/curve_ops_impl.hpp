@@ -1,0 +1,90 @@
+// Instantiation of everything templated on one curve; each curve_<name>.hip includes this header and
+// defines one CurveOps table (pc_internal.hpp).
+#pragma once
+#include <string.h>
+#include "pc_internal.hpp"
+#include "hip_backend_msm.hpp"
+#include "ipa.hpp"
+#include "glv.hpp"
+
+namespace pc {
+
+template <class C>
+struct MsmRunnerT : MsmRunner {
+  HipBackend& be;
+  MsmPlan<C, HipBackend> plan;
+  MsmRunnerT(HipBackend& b, size_t n, const MsmConfig& cfg, uint32_t subs = 0) : be(b), plan(b, n, cfg, subs) {}
+  void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) override {
+    const uint32_t* sdev = (const uint32_t*)scalars;
+    be.n_ev = 0; be.mark();
+    if (where == PC_MEM_HOST && n) {
+      be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
+      sdev = plan.scalar_staging();
+    }
+    plan.enqueue(bases, base_off, sdev, n, from_mont);
+  }
+  void finish(uint32_t* out_host) override { plan.finish(out_host); }
+};
+
+template <class C>
+void build_window_table(HipBackend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride) {
+  WindowTableBody<C> b{bases, n, c, Wd, table, stride};
+  be.launch(b, n, 64);
+  be.sync();
+}
+
+// key[i] = affine(key[i] + u * key[half + i]): GLV split of the shared challenge on the host, one ladder per lane
+template <class C>
+void ec_fold_run(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
+  typedef typename GlvOf<C>::T G;
+  Fd<typename C::FrP> u = Fd<typename C::FrP>::load(u_mont).from_mont();
+  uint64_t k[4]; memcpy(k, u.l, 32);
+  GlvSplit sp = glv_decompose<G>(k);
+  EcFoldGlvBody<C> body; body.key = key; body.half = (uint32_t)half;
+  body.n1.from_scalar(sp.k1); body.n2.from_scalar(sp.k2); body.neg1 = sp.neg1; body.neg2 = sp.neg2;
+  for (int i = 0; i < C::FqP::N; i++) body.beta[i] = G::BETA_MONT[i];
+  be.launch(body, half, 64); be.sync();
+}
+
+template <class C>
+struct CurveOpsImpl {
+  static constexpr int AW = 2 * C::FqP::N;
+  static MsmRunner* make_runner(HipBackend& be, size_t n_max, const MsmConfig& cfg, uint32_t subs) {
+    return new MsmRunnerT<C>(be, n_max, cfg, subs);
+  }
+  static void window_table(HipBackend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride) {
+    build_window_table<C>(be, bases, n, c, Wd, table, stride);
+  }
+  static void ec_fold(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
+    ec_fold_run<C>(be, key, half, u_mont);
+  }
+  static void fixed_base(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out) {
+    FixedBaseMulBody<C> body; body.scalars = scalars; body.out = out;
+    for (int i = 0; i < AW; i++) body.g[i] = g[i];
+    be.launch(body, n, 64); be.sync();
+  }
+  static void points_sum(const uint32_t* pts, size_t count, uint32_t* out) {
+    XyzzD<C> acc = XyzzD<C>::infinity();
+    for (size_t i = 0; i < count; i++) acc.add_affine(AffD<C>::load(pts + i * AW));
+    acc.to_affine().store(out);
+  }
+  static void point_mul(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out) {
+    typedef host64::Xyzz64<C> P64;
+    constexpr int FW = C::FqP::N;
+    Fd<typename C::FrP> k = Fd<typename C::FrP>::load(k_mont).from_mont();
+    bool inf = true; for (int i = 0; i < 2 * FW; i++) inf &= pt[i] == 0;
+    P64 base = P64::infinity();
+    if (!inf) { base.X = P64::Fq::load(pt); base.Y = P64::Fq::load(pt + FW); base.ZZ = P64::Fq::one(); base.ZZZ = P64::Fq::one(); }
+    P64 acc = P64::infinity();
+    for (int bit = C::FrP::N * 32 - 1; bit >= 0; bit--) {
+      acc = acc.dbl();
+      if ((k.l[bit >> 5] >> (bit & 31)) & 1) acc.add(base);
+    }
+    acc.store_affine(out);
+  }
+  static CurveOps table() {
+    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &fixed_base, &points_sum, &point_mul};
+  }
+};
+
+}  // namespace pc

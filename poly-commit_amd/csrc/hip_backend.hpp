@@ -1,5 +1,6 @@
-// HIP execution backend for the orchestration templates (msm.hpp, ...): one stream, every
-// kernel body launched through a single generic __global__ wrapper, scans through hipCUB.
+// HIP execution backend for the orchestration templates (msm.hpp, ...): one stream (plus an optional
+// low-priority tail stream), every kernel body launched through a single generic __global__ wrapper,
+// the u32 scan as three small kernels of its own.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdexcept>
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(256) k_run(Body body, uint32_t lanes) {
 // tile = 1024 elements per workgroup (256 lanes x 4): tile sums -> scan of the tile sums (recursive
 // for > 1M tiles, which never happens here) -> per-tile exclusive scan seeded with the tile base.
 static constexpr uint32_t SCAN_TILE = 1024;
-__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* lds /* 256 */, uint32_t& total) {
+static __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* lds /* 256 */, uint32_t& total) {
   const uint32_t tid = threadIdx.x;
   lds[tid] = v;
   __syncthreads();
@@ -43,7 +44,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* lds 
   total = lds[255];
   return lds[tid] - v;
 }
-__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* in, size_t n, uint32_t* tile_sums) {
+static __global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* in, size_t n, uint32_t* tile_sums) {
   __shared__ uint32_t lds[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
   uint32_t s = 0;
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* in, size
   uint32_t total; (void)wg_exclusive_scan(s, lds, total);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(256) k_scan_small(uint32_t* v, uint32_t n) {   // in place, n <= 2^20, one workgroup
+static __global__ void __launch_bounds__(256) k_scan_small(uint32_t* v, uint32_t n) {   // in place, n <= 2^20, one workgroup
   __shared__ uint32_t lds[256];
   uint32_t carry = 0;
   for (uint32_t base = 0; base < n; base += SCAN_TILE) {
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256) k_scan_small(uint32_t* v, uint32_t n) {  
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* in, size_t n, const uint32_t* tile_base, uint32_t* out) {
+static __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* in, size_t n, const uint32_t* tile_base, uint32_t* out) {
   __shared__ uint32_t lds[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
   uint32_t a[4]; uint32_t s = 0;

@@ -1,0 +1,80 @@
+// HipBackend's MSM-specific launchers (templated on the curve): LDS radix sort, accumulate with the
+// neighbour merge, the one-launch seg-reduce tail and the cooperative bucket-reduction levels.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+#include "hip_backend.hpp"
+#include "msm.hpp"
+#include "msm_coop.hpp"
+#include "msm_sort.hpp"
+
+namespace pc {
+template <class C>
+void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_t* hist, uint32_t* offsets, uint32_t* cursor,
+                              uint32_t* entries) {
+  if (sort_mode < 0) { const char* e = getenv("PC_HIP_SORT"); sort_mode = (e && !strcmp(e, "atomic")) ? 0 : 1; }
+  if (sort_mode == 0) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }
+  SortGeom sg = make_sort_geom(g, C::FrP::BITS);
+  if (sg.fine_bits > 10 || sg.NC > 16384) {   // c > 22, or more bucket sets than the LDS histogram holds
+    sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return;
+  }
+  // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)
+  const size_t gw = (size_t)sg.nblocks * sg.NC, nb1 = (size_t)sg.NC + 1;
+  const size_t rec_off = ((gw + 2 * nb1) * 4 + 15) & ~(size_t)15;
+  const size_t need = rec_off + (size_t)g.n * g.Wd * 8;
+  if (need > sort_ws_bytes) {
+    if (sort_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0; }
+    PC_HIP_CHECK(hipMalloc(&sort_ws, need)); sort_ws_bytes = need;
+  }
+  uint32_t* G = (uint32_t*)sort_ws; uint32_t* bintotal = G + gw; uint32_t* binbase = bintotal + nb1;
+  uint2* records = (uint2*)((char*)sort_ws + rec_off);
+  const size_t lds = (size_t)sg.NC * 4;
+  if (lds > 64 * 1024) {
+    PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  // a large LDS histogram leaves one workgroup per CU: make it 16 waves so latency stays hidden
+  const int sort_threads = lds > 32 * 1024 ? 1024 : 256;
+  hipLaunchKernelGGL((k_sort_pass<C, false>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)nullptr, (uint2*)nullptr);
+  PC_HIP_CHECK(hipGetLastError());
+  mark();   // 1: digits + coarse histogram
+  hipLaunchKernelGGL(k_sort_binscan, dim3((sg.NC + 15) / 16), dim3(256), 0, stream, G, sg.nblocks, sg.NC, bintotal);
+  PC_HIP_CHECK(hipGetLastError());
+  exclusive_scan_u32(bintotal, binbase, nb1);
+  mark();   // 2: scans
+  hipLaunchKernelGGL((k_sort_pass<C, true>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)binbase, records);
+  PC_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_sort_fine, dim3(sg.NC), dim3(256), 0, stream, sg, (const uint32_t*)binbase, (const uint2*)records, entries, offsets);
+  PC_HIP_CHECK(hipGetLastError());
+  mark();   // 3: coarse scatter + fine sort
+}
+
+template <class C>
+void HipBackend::accumulate(const AccumulateBody<C>& body, size_t lanes) {
+  if (lanes == 0) return;
+  hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, body, (uint32_t)lanes);
+  PC_HIP_CHECK(hipGetLastError());
+}
+
+template <class C>
+void HipBackend::seg_reduce_tail(const MsmGeom& g, uint32_t level, uint32_t slots, uint32_t* const* pk, uint32_t* const* pp, int cur,
+                                 const uint32_t* offsets, uint32_t* buckets) {
+  hipLaunchKernelGGL(k_seg_reduce_tail<C>, dim3(1), dim3(256), 0, stream, g, level, slots, pk[0], pk[1], pp[0], pp[1], cur, offsets, buckets);
+  PC_HIP_CHECK(hipGetLastError());
+}
+
+template <class C>
+void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, bool bits, const uint32_t* x,
+                              const uint32_t* old_in, uint32_t* out) {
+  if (bits) {   // 16 <= K <= 256: one workgroup of K lanes per group
+    uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
+    size_t lds = (size_t)K * XyzzD<C>::WORDS * 4;
+    hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, lgK, weight_off, cnt, n_old, x,
+                       old_in, out);
+    PC_HIP_CHECK(hipGetLastError());
+  } else {
+    BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};
+    launch(b, (size_t)cnt * (1 + n_old));
+  }
+}
+}  // namespace pc

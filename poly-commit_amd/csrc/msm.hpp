@@ -54,6 +54,9 @@ inline uint32_t atomic_inc_u32(uint32_t* p) { uint32_t o = *p; *p = o + 1; retur
 
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 
+// a call that does not fit the workspace of its plan (reported as PC_ERR_TOO_LARGE, nothing launched)
+struct MsmCapacityError : std::runtime_error { using std::runtime_error::runtime_error; };
+
 struct MsmGeom {
   uint32_t n;          // pairs in this call
   uint32_t c;          // window bits
@@ -525,13 +528,31 @@ class MsmPlan {
     if (subs_ && (!cfg_.tbl || !cfg_.tbl_c || n_max % subs_)) throw std::runtime_error("MsmPlan: many-MSM mode needs a window table");
     if (cfg_.T2 < 4) cfg_.T2 = 4;       // each level must shrink the list: 2*ceil(s/T2) < s
     if (cfg_.T2b < 4) cfg_.T2b = 4;
-    if (cfg_.K0 < 2) cfg_.K0 = 2;
-    if (cfg_.K1 < 2) cfg_.K1 = 2;
+    // plan_geometry divides the bucket count by these and turns them into Horner exponents: powers of two only
+    // (K1 / the cooperative levels: at most one workgroup of 256 lanes)
+    auto pow2_floor = [](uint32_t v, uint32_t lo, uint32_t hi) { uint32_t p = lo; while (p * 2 <= v && p * 2 <= hi) p *= 2; return p; };
+    cfg_.K0 = pow2_floor(cfg_.K0, 2, 1u << 12);
+    cfg_.tbl_K0 = pow2_floor(cfg_.tbl_K0, 2, 1u << 12);
+    cfg_.K1 = pow2_floor(cfg_.K1, 2, 256);
+    if (cfg_.T2 > 4096) cfg_.T2 = 4096;
+    if (cfg_.T2b > 4096) cfg_.T2b = 4096;
     min_T_ = cfg_.T ? cfg_.T : 16;
     // The window width is chosen per call from the call's n (a resident SRS serves MSMs of many
     // lengths: KZG opens, IPA halving rounds).  Size every buffer for the worst call n <= n_max.
+    // The width is a step function of n (msm_choose_c: one value per power-of-two bracket, plus the n < 32 and
+    // table thresholds), while the entry count n * Wd grows with n inside a bracket: evaluate both ends of every
+    // bracket -- a call just below a power of two has the bracket's (smaller) c, hence more digits per
+    // scalar than any power-of-two n (KZG opens have n - 1 pairs over a 2^k SRS).
     size_t NBmax = 1, Mmax = 1, red_max = 1, res_max = 1;
-    for (size_t n = subs_ ? n_max : 1;; n = (n * 2 < n_max) ? n * 2 : n_max) {
+    std::vector<size_t> sizes;
+    if (subs_) sizes.push_back(n_max);
+    else {
+      for (size_t p2 = 1; p2 <= n_max; p2 <<= 1) { sizes.push_back(p2); if (p2 > 1) sizes.push_back(p2 - 1); if (p2 > (n_max >> 1)) break; }
+      sizes.push_back(31); sizes.push_back(32); sizes.push_back(n_max);
+      if (cfg_.tbl && cfg_.tbl_min_n) { sizes.push_back(cfg_.tbl_min_n); if (cfg_.tbl_min_n > 1) sizes.push_back(cfg_.tbl_min_n - 1); }
+    }
+    for (size_t n : sizes) {
+      if (n < 1 || n > n_max) continue;
       plan_geometry(n);
       NBmax = std::max<size_t>(NBmax, g_.NB);
       Mmax = std::max<size_t>(Mmax, n * (size_t)g_.Wd);
@@ -539,8 +560,8 @@ class MsmPlan {
       for (uint32_t l = 0; l < n_levels_; l++) total += (size_t)(1 + lvl_narr_[l]) * g_.W * lvl_m_[l];
       red_max = std::max(red_max, total);
       res_max = std::max<size_t>(res_max, (size_t)g_.W * (n_levels_ ? lvl_narr_[n_levels_ - 1] : 1));
-      if (n >= n_max) break;
     }
+    entries_cap_ = Mmax; nb_cap_ = NBmax;
     hist_ = offsets_ = cursor_ = entries_ = buckets_ = scalars_ = red_ = nullptr; pk_[0] = pk_[1] = pp_[0] = pp_[1] = nullptr;
     try {
     hist_ = (uint32_t*)be_.alloc((NBmax + 1) * 4);
@@ -605,13 +626,15 @@ class MsmPlan {
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
     g.T = T; g.T2 = cfg_.T2; g.T2b = cfg_.T2b;
+    // capacity checks BEFORE anything is launched (the buffers were sized in the constructor for every n <= n_max)
+    const size_t lanes = ceil_div_u32(Mmax, T);
+    if (n > n_max_ || Mmax > entries_cap_ || g.NB > nb_cap_ || 2 * lanes > part_slots_)
+      throw MsmCapacityError("MsmPlan: call exceeds the workspace this plan was sized for");
 
     be_.memset(buckets_, 0, (size_t)g.NB * Pt::WORDS * 4);
     // steps 1-3: entries grouped by bucket + CSR offsets (backend chooses the sort)
     be_.template sort_entries<C>(g, scalars_dev, hist_, offsets_, cursor_, entries_);
 
-    size_t lanes = ceil_div_u32(Mmax, T);
-    if (2 * lanes > part_slots_) throw std::runtime_error("MsmPlan: partial list undersized");
     { AccumulateBody<C> b{g, g.tbl_stride ? cfg_.tbl : bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
     be_.mark();   // 4: accumulate
     // the reductions below are latency-bound: they go to the pipeline's low-priority queue (HIP backend)
@@ -734,7 +757,7 @@ class MsmPlan {
   size_t red_points_ = 0;
   MsmGeom g_;
   uint32_t min_T_;
-  size_t part_slots_ = 0;
+  size_t part_slots_ = 0, entries_cap_ = 0, nb_cap_ = 0;
   uint32_t *hist_, *offsets_, *cursor_, *entries_, *buckets_, *scalars_, *red_;
   uint32_t* pk_[2]; uint32_t* pp_[2];
   uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32]; uint32_t lvl_bits_[32]; uint32_t lvl_narr_[32];

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
 // A workgroup covers 16 bins x 16 segments of the block range: each thread sums its segment, the 16
 // segment sums of a bin are scanned through LDS, then the segment is walked again to write the
 // prefixes -- a dependent chain of 2 * ceil(nblocks / 16) loads instead of nblocks (0.12 -> 0.02 ms).
-__global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32_t nblocks, uint32_t NC, uint32_t* bintotal) {
+static __global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32_t nblocks, uint32_t NC, uint32_t* bintotal) {
   __shared__ uint32_t seg_sum[16][17];
   const uint32_t kb = threadIdx.x & 15, seg = threadIdx.x >> 4;
   const uint32_t k = blockIdx.x * 16 + kb;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32_t nblo
   if (blockIdx.x == 0 && threadIdx.x == 0) bintotal[NC] = 0;
 }
 
-__global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
+static __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
                                                   uint32_t* offsets) {
   __shared__ uint32_t h[2048];        // [0, F): counts / cursors; [F, 2F): scan ping-pong
   const uint32_t k = blockIdx.x, start = binbase[k], end = binbase[k + 1];

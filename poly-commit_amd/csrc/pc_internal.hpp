@@ -1,0 +1,71 @@
+// Internal interfaces between the translation units of libpc_hip.so.
+//
+// The library is built from several .hip files compiled in parallel (poly-commit_amd/build.py):
+//   abi.hip            the extern "C" entry points (include/pc_hip.h): lifetime, staging, error translation
+//   curve_<name>.hip   everything templated on one curve: MSM pipeline, window table, key fold, fixed-base mul
+//   field_<name>.hip   everything templated on one scalar field: NTT, division scan, IPA vector kernels,
+//                      column digests
+// abi.hip reaches the templates through the two tables of plain function pointers below, one
+// instance per curve / field.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/pc_hip.h"
+#include "hip_backend.hpp"
+#include "msm.hpp"
+
+namespace pc {
+
+struct MsmRunner {
+  virtual ~MsmRunner() {}
+  virtual void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) = 0;
+  virtual void finish(uint32_t* out_host) = 0;
+};
+
+struct NttRunner {
+  virtual ~NttRunner() {}
+  virtual void run(const uint32_t* in, size_t rows, size_t in_cols, uint32_t* out) = 0;
+};
+
+struct CurveOps {
+  int aw;                 // 32-bit words per affine point
+  uint32_t scalar_bits;
+  MsmRunner* (*make_runner)(HipBackend& be, size_t n_max, const MsmConfig& cfg, uint32_t subs);
+  void (*window_table)(HipBackend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride);
+  void (*ec_fold)(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont);
+  void (*fixed_base)(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out);
+  // host-side helpers (a handful of points, as the reference does on the host)
+  void (*points_sum)(const uint32_t* pts, size_t count, uint32_t* out);
+  void (*point_mul)(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out);
+};
+
+struct FieldOps {
+  NttRunner* (*make_ntt)(HipBackend& be, unsigned log_n);
+  void (*poly_eval)(HipBackend& be, const uint32_t* x, size_t n, const uint32_t* z_host, uint32_t* out_host, uint32_t fan);
+  void (*div_scan)(HipBackend& be, const uint32_t* x, size_t n, const uint32_t* z_host, const uint32_t* carry_in_host, uint32_t* out,
+                   uint32_t fan);
+  void (*witness)(HipBackend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t fan);
+  void (*fr_fold)(HipBackend& be, uint32_t* lo, const uint32_t* hi, size_t n, const uint32_t* s);
+  void (*fr_dot)(HipBackend& be, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out_host);
+  void (*fr_powers)(HipBackend& be, const uint32_t* z, size_t n, uint32_t* out);
+  void (*fr_lincomb)(HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out);
+  void (*column_hash)(HipBackend& be, int hash, const uint32_t* ext, uint32_t rows, uint32_t n_cols, uint32_t* out);
+};
+
+// (accessor functions rather than global tables: a namespace-scope constant would also be emitted into the
+// device image, where the host function addresses do not exist)
+const CurveOps& curve_ops_bls12_381(); const CurveOps& curve_ops_bn254(); const CurveOps& curve_ops_pallas();
+const FieldOps& field_ops_bls12_381(); const FieldOps& field_ops_bn254(); const FieldOps& field_ops_pallas();
+
+inline const CurveOps& curve_ops(pc_curve c) {
+  return c == PC_CURVE_BLS12_381 ? curve_ops_bls12_381() : c == PC_CURVE_BN254 ? curve_ops_bn254() : curve_ops_pallas();
+}
+inline const FieldOps& field_ops(pc_curve c) {
+  return c == PC_CURVE_BLS12_381 ? field_ops_bls12_381() : c == PC_CURVE_BN254 ? field_ops_bn254() : field_ops_pallas();
+}
+
+// hash-only kernels (hash_tu.hip)
+void merkle_level(HipBackend& be, int hash, const uint32_t* child, uint32_t* parent, uint32_t n_leaves, uint32_t bottom,
+                  uint32_t len_prefix, size_t cnt);
+
+}  // namespace pc

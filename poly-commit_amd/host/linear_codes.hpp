@@ -31,12 +31,16 @@ inline long calculate_t(int field_bits, size_t sec_param, size_t dist_num, size_
 struct LigeroPCParams {              // linear_codes/ligero.rs:22-39 (the fields the encoder needs)
   size_t sec_param = 128, rho_inv = 4;
   // (n_rows, n_cols) for a polynomial of poly_len coefficients
+  // The reference unwraps calculate_t here and aborts with Error::InvalidParameters (ligero.rs:124); the mirror
+  // returns that error instead of committing with a meaningless shape.
   template <class E>
-  std::pair<size_t, size_t> compute_dimensions(size_t poly_len) const {
+  Error compute_dimensions(size_t poly_len, size_t& n, size_t& m) const {
     long t = calculate_t(E::C::FrP::BITS, sec_param, rho_inv - 1, rho_inv, poly_len);
-    size_t n = (size_t)1 << ark_log2((size_t)ceil(sqrt((double)ceil_div(2 * poly_len, (size_t)t))));
-    size_t m = ceil_div(poly_len, n);
-    return {n, m};
+    if (t < 0) { Error e; e.kind = Error::InvalidParameters; e.msg = "calculate_t: the field is not big enough for this codeword length / security parameter, or the distance is wrong"; return e; }
+    if (t == 0) { Error e; e.kind = Error::InvalidParameters; e.msg = "calculate_t: empty polynomial"; return e; }
+    n = (size_t)1 << ark_log2((size_t)ceil(sqrt((double)ceil_div(2 * poly_len, (size_t)t))));
+    m = ceil_div(poly_len, n);
+    return Error();
   }
 };
 
@@ -60,7 +64,8 @@ struct LinearEncode {
   // compute_matrices: pad the coefficients to n_rows*n_cols, row-major, encode every row
   static Error compute_matrices(pc_ctx* ctx, const DensePolynomial<E>& polynomial, const LigeroPCParams& param, Matrix<E>& mat, Matrix<E>& ext_mat) {
     std::vector<FrT<E>> coeffs = polynomial.coeffs;
-    auto dims = param.compute_dimensions<E>(coeffs.size());
+    std::pair<size_t, size_t> dims;
+    if (Error e = param.compute_dimensions<E>(coeffs.size(), dims.first, dims.second)) return e;
     coeffs.resize(dims.first * dims.second, FrT<E>::zero());
     mat.n = dims.first; mat.m = dims.second; mat.entries = coeffs;
     return encode_rows(ctx, mat, param.rho_inv, ext_mat);
@@ -88,7 +93,8 @@ struct LinearCodePCS {
   Error commit(pc_ctx* ctx, const DensePolynomial<E>& polynomial, const LigeroPCParams& param, LinCodePCCommitment& com,
                LinCodePCCommitmentState<E>& state, bool keep_ext_mat = true) const {
     std::vector<FrT<E>> coeffs = polynomial.coeffs;
-    auto dims = param.compute_dimensions<E>(coeffs.size());
+    std::pair<size_t, size_t> dims;
+    if (Error e = param.compute_dimensions<E>(coeffs.size(), dims.first, dims.second)) return e;
     coeffs.resize(dims.first * dims.second, FrT<E>::zero());
     state.mat.n = dims.first; state.mat.m = dims.second; state.mat.entries = coeffs;
     size_t size = 1; unsigned lg = 0; while (size < dims.second * param.rho_inv) { size <<= 1; lg++; }

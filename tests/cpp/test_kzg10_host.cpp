@@ -181,8 +181,9 @@ static void run(pc_ctx* ctx, const char* name) {
       for (size_t j = 0; j < size; j++) { CHECK(pol.evaluate(x) == encoded[j]); x = x * w; }   // large_domain.element(j)
     }
     LigeroPCParams param;                                       // rho_inv 4, lambda 128
-    auto d24 = param.compute_dimensions<E>((size_t)1 << 24);
-    if (E::ID != PC_CURVE_BN254) CHECK(d24.first == 512 && d24.second == 32768);
+    std::pair<size_t, size_t> d24;
+    CHECK(!param.compute_dimensions<E>((size_t)1 << 24, d24.first, d24.second));
+    CHECK(d24.first == 512 && d24.second == 32768);
     DensePolynomial<E> pol = rand_poly<E>(999, rng);
     Matrix<E> mat, ext;
     CHECK(!LinearEncode<E>::compute_matrices(ctx, pol, param, mat, ext));
@@ -278,7 +279,29 @@ static void run(pc_ctx* ctx, const char* name) {
   printf("%s: ipa cm_commit/open rounds, ligero reed_solomon/compute_matrices/commit/row_mul, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
 }
 
+// Host arithmetic that needs no device: the reference's own calculate_t tests
+// (linear_codes/utils.rs:344-359, Fq of BLS12-377 = 377 bits) and the shape table of SURVEY.md 8d.
+static void host_logic_checks() {
+  long t;
+  t = calculate_t(377, 128, 3, 4, (size_t)1 << 32); CHECK(t > 0 && t < 200);        // test_calculate_t_with_good_parameters
+  t = calculate_t(377, 256, 3, 4, (size_t)1 << 32); CHECK(t > 0 && t < 400);
+  CHECK(calculate_t(377, 377 - 60, 3, 4, (size_t)1 << 60) < 0);                     // test_calculate_t_with_bad_parameters
+  CHECK(calculate_t(377, 400, 3, 4, (size_t)1 << 32) < 0);
+  LigeroPCParams param;                                                              // rho_inv 4, lambda 128
+  const size_t want[5][3] = {{12, 8, 512}, {16, 32, 2048}, {20, 128, 8192}, {22, 256, 16384}, {24, 512, 32768}};
+  for (auto& w : want) {
+    size_t n = 0, m = 0;
+    CHECK(!param.compute_dimensions<Bls12_381>((size_t)1 << w[0], n, m)); CHECK(n == w[1] && m == w[2]);
+    CHECK(!param.compute_dimensions<Bn254>((size_t)1 << w[0], n, m)); CHECK(n == w[1] && m == w[2]);
+  }
+  LigeroPCParams bad; bad.sec_param = 400;                                           // no 255-bit field gives 2^-400
+  size_t n = 0, m = 0;
+  CHECK(bad.compute_dimensions<Bls12_381>((size_t)1 << 20, n, m).kind == Error::InvalidParameters);
+  printf("host logic OK (calculate_t bounds of linear_codes/utils.rs:344-359, Ligero shape table, InvalidParameters)\n");
+}
+
 int main() {
+  host_logic_checks();
   pc_ctx* ctx = nullptr;
   int rc = pc_hip_init(0, &ctx);
   if (rc != PC_OK) { printf("pc_hip_init failed: %s\n", pc_hip_strerror(rc)); return rc == PC_ERR_NO_DEVICE ? 77 : 1; }

@@ -81,6 +81,25 @@ extern "C" void emu_msm(int curve, const uint32_t* bases, const uint32_t* scalar
   }
 }
 
+// A plan sized for an SRS of n_srs points serving a shorter call (KZG open: n_srs - 1 pairs; IPA rounds): the
+// call's window width differs from the one of n_srs.  Returns 0, or 1 if the plan refused the call.
+template <class C>
+static int run_sized(const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off, int from_mont, uint32_t* out) {
+  CpuStepBackend be;
+  pc::MsmConfig cfg;
+  pc::MsmPlan<C, CpuStepBackend> plan(be, n_srs, cfg);
+  try { plan.run(bases, base_off, scalars, n, from_mont != 0, out); } catch (const pc::MsmCapacityError&) { return 1; }
+  return 0;
+}
+extern "C" int emu_msm_sized(int curve, const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off,
+                             int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: return run_sized<pc_curve_bls12_381>(bases, n_srs, scalars, n, base_off, from_mont, out);
+    case 1: return run_sized<pc_curve_bn254>(bases, n_srs, scalars, n, base_off, from_mont, out);
+    default: return run_sized<pc_curve_pallas>(bases, n_srs, scalars, n, base_off, from_mont, out);
+  }
+}
+
 // table mode (pc_hip_srs_precompute): window table built by the same body the GPU runs, then the
 // plan with one shared bucket set.  n_srs bases, MSM over [base_off, base_off + n).
 template <class C>

@@ -122,6 +122,21 @@ def test_msm_stepped_adversarial_scalars():
             assert (run_msm(curve, b, sc, c, T, T2, K0) == want).all(), (name, c, T)
 
 
+@pytest.mark.parametrize("n_srs,n", [(1024, 1023), (1024, 512), (1024, 31), (2048, 2047), (33, 31), (300, 255)])
+def test_msm_plan_sized_for_srs_serves_shorter_calls(n_srs, n):
+    """A plan is sized once per SRS; a call just below a power of two runs with the smaller window of its
+    bracket, i.e. with MORE digits per scalar than any power-of-two length (the KZG open shape: n - 1 pairs
+    over a 2^k SRS).  The workspace must cover it (round-1 advisor finding: it did not)."""
+    curve = "bn254"
+    b = O.gen_bases(curve, n_srs)
+    s = O.gen_scalars(curve, 11 + n, n)
+    out = np.zeros(2 * O.fq_limbs(curve), dtype=np.uint64)
+    rc = emu().emu_msm_sized(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(n_srs), p32(s.view(np.uint32)), C.c_size_t(n),
+                             n_srs - n, 0, p32(out.view(np.uint32)))
+    assert rc == 0, "the plan refused a call within its SRS length"
+    assert (out == O.msm_pippenger(curve, np.ascontiguousarray(b[n_srs - n:]), s, 4, 1)).all()
+
+
 def test_msm_stepped_offset_and_montgomery():
     curve = "bn254"
     n = 200

@@ -161,6 +161,22 @@ def test_fr_lincomb_matches_bigint(ctx, curve):
     assert not z.any()
 
 
+# The one literal input/output vector the reference holds on this path: test_row_mul,
+# poly-commit/src/utils.rs:274-286 (Matrix::row_mul, used by Ligero's open, linear_codes/mod.rs:539).
+ROW_MUL_ROWS = [[10, 100, 4], [23, 1, 0], [55, 58, 9]]
+ROW_MUL_V = [12, 41, 55]
+ROW_MUL_WANT = [4088, 4431, 543]
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254", "pallas"])
+def test_row_mul_reference_vector(ctx, curve):
+    """`mat.row_mul(&v) == [4088, 4431, 543]` (utils.rs:274-286) through pc_hip_fr_lincomb, the entry point
+    that replaces row_mul; given in the integers, so it holds in every scalar field."""
+    rows = [O.fr_mont_array(curve, r) for r in ROW_MUL_ROWS]
+    got = ctx.fr_lincomb(curve, rows, O.fr_mont_array(curve, ROW_MUL_V))
+    assert O.fr_from_mont_array(curve, got) == ROW_MUL_WANT
+
+
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254", "pallas"])
 def test_poly_eval_matches_oracle(ctx, curve):
     """pc_hip_poly_eval (the up-sweep of the division scan alone) == Horner evaluation of the oracle,
