@@ -237,6 +237,20 @@ int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t 
  * i < n_half -- `k_l += k_r.mul(round_challenge)` followed by normalize_batch (:699-707).  The
  * following round's MSMs address the halves with base_offset 0 and n_half/2. */
 int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host);
+/* Late halving rounds without folding the key (same l_vec / r_vec / final_comm_key, bit for bit): once n has
+ * shrunk to n0 the resident key K0 = key[0..n0) stays as it is and the per-base factors s_j that the remaining
+ * folds `k_l += k_r * u` (ipa_pc/mod.rs:699-701) would have applied are kept as a device vector s (n0 Fr,
+ * Montgomery, initialised to ones, e.g. by pc_hip_fr_powers with z = 1).  Then for the round at size m <= n0
+ *   l = MSM(K0, out_l) + h' <c_r, z_l>,  r = MSM(K0, out_r) + h' <c_l, z_r>        (ipa_pc/mod.rs:671-675)
+ * with out_l[j] = (j mod m <  m/2) ? coeffs[m/2 + j mod m] * s[j] : 0,
+ *      out_r[j] = (j mod m >= m/2) ? coeffs[j mod m - m/2] * s[j] : 0,
+ * and the fold by u at size fold_m is s[j] *= u where (j mod fold_m) >= fold_m/2; final_comm_key = MSM(K0, s).
+ * A fold of n/2 full-width scalar multiplications costs the latency of one 255-bit ladder (~2.4 ms) however small
+ * n gets; two more MSMs over n0 bases do not.  One call does (in this order) the optional fold of s
+ * (fold_u_host != NULL) and the optional scalar vectors of the round at size m (out_l_dev/out_r_dev != NULL,
+ * coeffs_dev = the m current coefficients). */
+int pc_hip_ipa_key_scalars(pc_ctx* ctx, pc_curve field_of, const void* coeffs_dev, size_t m, void* s_dev, size_t n0,
+                           const void* fold_u_host, size_t fold_m, void* out_l_dev, void* out_r_dev);
 /* Host-side scalar multiplication of one affine point by one Fr (Montgomery):
  * `h_prime.mul(inner_product(..))`, ipa_pc/mod.rs:672,675 -- one point, stays on the host as in
  * the reference. */

@@ -375,15 +375,122 @@ int orc_kzg_open(int curve, const uint64_t* powers, size_t n_powers, const uint6
   return orc_kzg_commit(curve, powers, n_powers, q.data(), n > 1 ? n - 1 : 0, threads, out);
 }
 
-// ---- IPA halving rounds, ipa_pc/mod.rs:664-711, challenges supplied by the caller ------
-// comm_key: n affine points; coeffs: n Fr (mont); z: evaluation point (mont); h_prime: 1 affine;
-// challenges: log2(n) Fr (mont).  Outputs: l_vec / r_vec (log2 n affine points each),
-// final_comm_key (1 affine), c (1 Fr mont).
-void orc_ipa_rounds(int curve, const uint64_t* comm_key, const uint64_t* coeffs_in, size_t n,
-                    const uint64_t* zpt, const uint64_t* h_prime, const uint64_t* challenges, int threads,
-                    uint64_t* l_out, uint64_t* r_out, uint64_t* final_key, uint64_t* c_out) {
-  CURVE_SWITCH(curve, {
-    typedef Fp<C::FrP> F; constexpr int N = C::FqP::N;
+// ---- BLAKE2s-256 (RFC 7693), byte-oriented: the digest D of InnerProductArgPC<G, D, P> in the reference's
+//      tests and benches (ipa_pc/mod.rs:1056-1064, benches/ipa_times.rs:16).  Pinned against Python's hashlib
+//      in tests/test_oracle_cpu.py. ------------------------------------------------------------------------
+namespace b2s {
+static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+static const uint8_t SIGMA[10][16] = {
+  {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+  {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+  {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+  {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+  {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+static inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void compress(uint32_t h[8], const uint8_t block[64], uint64_t t, bool last) {
+  uint32_t m[16], v[16];
+  for (int i = 0; i < 16; i++) m[i] = (uint32_t)block[4 * i] | ((uint32_t)block[4 * i + 1] << 8) | ((uint32_t)block[4 * i + 2] << 16) | ((uint32_t)block[4 * i + 3] << 24);
+  for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+  v[12] ^= (uint32_t)t; v[13] ^= (uint32_t)(t >> 32);
+  if (last) v[14] = ~v[14];
+  auto G = [&](int a, int b, int c, int d, uint32_t x, uint32_t y) {
+    v[a] = v[a] + v[b] + x; v[d] = ror(v[d] ^ v[a], 16); v[c] = v[c] + v[d]; v[b] = ror(v[b] ^ v[c], 12);
+    v[a] = v[a] + v[b] + y; v[d] = ror(v[d] ^ v[a], 8); v[c] = v[c] + v[d]; v[b] = ror(v[b] ^ v[c], 7);
+  };
+  for (int r = 0; r < 10; r++) {
+    const uint8_t* s = SIGMA[r];
+    G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]); G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+    G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+  }
+  for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+static void digest(const uint8_t* msg, size_t len, uint8_t out[32]) {
+  uint32_t h[8];
+  for (int i = 0; i < 8; i++) h[i] = IV[i];
+  h[0] ^= 0x01010020u;                                   // digest length 32, no key, fanout 1, depth 1
+  size_t off = 0;
+  while (len - off > 64) { compress(h, msg + off, off + 64, false); off += 64; }
+  uint8_t block[64]; memset(block, 0, 64);
+  memcpy(block, msg + off, len - off);
+  compress(h, block, len, true);
+  for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)h[i]; out[4 * i + 1] = (uint8_t)(h[i] >> 8); out[4 * i + 2] = (uint8_t)(h[i] >> 16); out[4 * i + 3] = (uint8_t)(h[i] >> 24); }
+}
+}  // namespace b2s
+extern "C" void orc_blake2s(const uint8_t* msg, size_t len, uint8_t* out32) { b2s::digest(msg, len, out32); }
+extern "C++" {
+// ---- Transcript bytes: ark-serialize's serialize_uncompressed of the items InnerProductArgPC::open hashes
+//      (ipa_pc/mod.rs:615-623, 681-688).  ark-serialize / ark-ec 0.5 are not under /root/reference; restated from
+//      their published behaviour:
+//        field element            canonical residue, little-endian, ceil(bits / 8) bytes
+//        short-Weierstrass point  (generic impl: BN254, Pallas)  x as above, then y in ceil((bits + 2) / 8) bytes
+//                                 with the SWFlags in the top bits of the LAST byte: 0x80 = y is the larger of
+//                                 {y, -y} ("negative"), 0x40 = point at infinity (x = y = 0)
+//        BLS12-381 G1             ark-bls12-381 overrides the generic impl with the zcash / IETF encoding:
+//                                 x, y big-endian, 48 bytes each; top bits of byte 0: 0x80 compressed (clear here),
+//                                 0x40 infinity (all other bytes zero), 0x20 unused in the uncompressed form
+template <class F>
+static void ser_field(const F& v, size_t nbytes, std::vector<uint8_t>& out) {
+  uint64_t c[F::N]; v.to_canonical(c);
+  for (size_t i = 0; i < nbytes; i++) out.push_back(i < 8 * (size_t)F::N ? (uint8_t)(c[i / 8] >> (8 * (i % 8))) : 0);
+}
+template <class C>
+static void ser_point(int curve, const Aff<C>& p, std::vector<uint8_t>& out) {
+  typedef Fp<typename C::FqP> Fq;
+  const size_t xb = (C::FqP::BITS + 7) / 8, yb = (C::FqP::BITS + 2 + 7) / 8;
+  if (curve == 0) {                       // zcash encoding
+    const size_t at = out.size();
+    std::vector<uint8_t> le;
+    if (p.is_inf()) { out.insert(out.end(), 2 * xb, 0); out[at] |= 0x40; return; }
+    ser_field(p.x, xb, le); out.insert(out.end(), le.rbegin(), le.rend());
+    le.clear(); ser_field(p.y, xb, le); out.insert(out.end(), le.rbegin(), le.rend());
+    return;
+  }
+  if (p.is_inf()) { out.insert(out.end(), xb + yb, 0); out.back() |= 0x40; return; }
+  ser_field(p.x, xb, out);
+  ser_field(p.y, yb, out);
+  // y <= -y  ->  YIsNegative ... no flag is set for the smaller ("positive") root
+  uint64_t a[Fq::N], b[Fq::N]; p.y.to_canonical(a); p.y.neg().to_canonical(b);
+  bool y_gt_neg = false;
+  for (int i = Fq::N - 1; i >= 0; i--) if (a[i] != b[i]) { y_gt_neg = a[i] > b[i]; break; }
+  if (!y_gt_neg) out.back() |= 0x80;
+}
+// Field::from_random_bytes (ark-ff): the first 8 N bytes as a little-endian integer with the bits above
+// MODULUS_BIT_SIZE cleared; None if that integer is >= the modulus.
+template <class F>
+static bool from_random_bytes(const uint8_t* bytes, size_t len, F& out) {
+  uint64_t c[F::N];
+  for (int i = 0; i < F::N; i++) { c[i] = 0; for (int k = 0; k < 8; k++) { size_t idx = 8 * i + k; if (idx < len) c[i] |= (uint64_t)bytes[idx] << (8 * k); } }
+  const int shave = 64 * F::N - F::Params::BITS;
+  if (shave > 0) c[F::N - 1] &= ~(uint64_t)0 >> shave;
+  for (int i = F::N - 1; i >= 0; i--) { if (c[i] < F::Params::MOD[i]) break; if (c[i] > F::Params::MOD[i] || i == 0) return false; }
+  out = F::from_canonical(c);
+  return true;
+}
+// compute_random_oracle_challenge, ipa_pc/mod.rs:74-87
+template <class F>
+static F random_oracle_challenge(const std::vector<uint8_t>& bytes) {
+  for (uint64_t i = 0;; i++) {
+    std::vector<uint8_t> in(bytes);
+    for (int k = 0; k < 8; k++) in.push_back((uint8_t)(i >> (8 * k)));
+    uint8_t h[32]; b2s::digest(in.data(), in.size(), h);
+    F out;
+    if (from_random_bytes<F>(h, 32, out)) return out;
+  }
+}
+}  // extern "C++"
+
+// ---- IPA halving rounds, ipa_pc/mod.rs:664-711 ------------------------------------------
+// comm_key: n affine points; coeffs: n Fr (mont); z: evaluation point (mont); h_prime: 1 affine.
+// challenges != null: log2(n) Fr (mont) supplied by the caller.  challenges == null: Fiat-Shamir as in the
+// reference -- round_challenge = RO(ser(round_challenge) || ser(L) || ser(R)) (:681-688), starting from
+// *rc0 (the challenge open() derived before the loop, :615-625); the challenges used are written to ch_out.
+// Outputs: l_vec / r_vec (log2 n affine points each), final_comm_key (1 affine), c (1 Fr mont).
+extern "C++" {
+template <class C>
+static void ipa_rounds_impl(int curve, const uint64_t* comm_key, const uint64_t* coeffs_in, size_t n, const uint64_t* zpt,
+                            const uint64_t* h_prime, const uint64_t* challenges, const uint64_t* rc0, int threads, uint64_t* l_out,
+                            uint64_t* r_out, uint64_t* final_key, uint64_t* c_out, uint64_t* ch_out) {
+    typedef Fp<typename C::FrP> F; constexpr int N = C::FqP::N;
     std::vector<F> cs(n), zs(n);
     F cur = F::one(), zz = F::from_raw(zpt);
     for (size_t i = 0; i < n; i++) { cs[i] = F::from_raw(coeffs_in + 4 * i); zs[i] = cur; cur = cur * zz; }
@@ -391,6 +498,7 @@ void orc_ipa_rounds(int curve, const uint64_t* comm_key, const uint64_t* coeffs_
     Jac<C> hp = Jac<C>::from_affine(load_aff<C>(h_prime));
     size_t rnd = 0;
     std::vector<uint64_t> big(4 * n);
+    F round_challenge = rc0 ? F::from_raw(rc0) : F::zero();
     auto cm_commit = [&](const uint64_t* k, const F* s, size_t m) {   // ipa_pc/mod.rs:54-72
       for (size_t i = 0; i < m; i++) s[i].to_canonical(&big[4 * i]);
       return msm_pippenger<C>(k, big.data(), m, threads, 1);
@@ -405,9 +513,18 @@ void orc_ipa_rounds(int curve, const uint64_t* comm_key, const uint64_t* coeffs_
       Jac<C> l = cm_commit(key.data(), &cs[h], h).add(hp.mul_limbs(ipc, 4));
       inner(&cs[0], &zs[h], h).to_canonical(ipc);
       Jac<C> r = cm_commit(key.data() + 2 * N * h, &cs[0], h).add(hp.mul_limbs(ipc, 4));
-      store_aff<C>(l.to_affine(), l_out + 2 * N * rnd);
-      store_aff<C>(r.to_affine(), r_out + 2 * N * rnd);
-      F u = F::from_raw(challenges + 4 * rnd), ui = u.inv();
+      Aff<C> la = l.to_affine(), ra = r.to_affine();
+      store_aff<C>(la, l_out + 2 * N * rnd);
+      store_aff<C>(ra, r_out + 2 * N * rnd);
+      F u;
+      if (challenges) u = F::from_raw(challenges + 4 * rnd);
+      else {
+        std::vector<uint8_t> bytes;
+        ser_field(round_challenge, (C::FrP::BITS + 7) / 8, bytes); ser_point<C>(curve, la, bytes); ser_point<C>(curve, ra, bytes);
+        u = round_challenge = random_oracle_challenge<F>(bytes);
+      }
+      if (ch_out) u.to_raw(ch_out + 4 * rnd);
+      F ui = u.inv();
       rnd++;
       uint64_t uc[4]; u.to_canonical(uc);
       for (size_t i = 0; i < h; i++) { cs[i] = cs[i] + ui * cs[h + i]; zs[i] = zs[i] + u * zs[h + i]; }
@@ -426,7 +543,34 @@ void orc_ipa_rounds(int curve, const uint64_t* comm_key, const uint64_t* coeffs_
     }
     memcpy(final_key, key.data(), 2 * N * 8);
     cs[0].to_raw(c_out);
+}
+}  // extern "C++"
+void orc_ipa_rounds(int curve, const uint64_t* comm_key, const uint64_t* coeffs_in, size_t n,
+                    const uint64_t* zpt, const uint64_t* h_prime, const uint64_t* challenges, int threads,
+                    uint64_t* l_out, uint64_t* r_out, uint64_t* final_key, uint64_t* c_out) {
+  CURVE_SWITCH(curve, ipa_rounds_impl<C>(curve, comm_key, coeffs_in, n, zpt, h_prime, challenges, nullptr, threads, l_out, r_out, final_key, c_out, nullptr));
+}
+void orc_ipa_rounds_fs(int curve, const uint64_t* comm_key, const uint64_t* coeffs_in, size_t n, const uint64_t* zpt,
+                       const uint64_t* h_prime, const uint64_t* round_challenge0, int threads, uint64_t* l_out, uint64_t* r_out,
+                       uint64_t* final_key, uint64_t* c_out, uint64_t* challenges_out) {
+  CURVE_SWITCH(curve, ipa_rounds_impl<C>(curve, comm_key, coeffs_in, n, zpt, h_prime, nullptr, round_challenge0, threads, l_out, r_out, final_key, c_out, challenges_out));
+}
+// The challenge open() derives before the loop (ipa_pc/mod.rs:615-625): RO(ser(combined_commitment) || ser(point) ||
+// ser(combined_v)); and the generic transcript pieces, for the tests.
+void orc_ipa_first_challenge(int curve, const uint64_t* commitment_xy, const uint64_t* point, const uint64_t* value, uint64_t* out) {
+  CURVE_SWITCH(curve, {
+    typedef Fp<C::FrP> F;
+    std::vector<uint8_t> bytes;
+    ser_point<C>(curve, load_aff<C>(commitment_xy), bytes);
+    ser_field(F::from_raw(point), (C::FrP::BITS + 7) / 8, bytes);
+    ser_field(F::from_raw(value), (C::FrP::BITS + 7) / 8, bytes);
+    random_oracle_challenge<F>(bytes).to_raw(out);
   });
+}
+size_t orc_ser_point(int curve, const uint64_t* xy, uint8_t* out) {
+  size_t n = 0;
+  CURVE_SWITCH(curve, { std::vector<uint8_t> b; ser_point<C>(curve, load_aff<C>(xy), b); memcpy(out, b.data(), b.size()); n = b.size(); });
+  return n;
 }
 
 // ---- Ligero shape + encode ------------------------------------------------------------

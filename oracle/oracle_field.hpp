@@ -23,6 +23,7 @@ typedef unsigned __int128 u128;
 
 template <class P>
 struct Fp {
+  typedef P Params;
   static constexpr int N = P::N;
   uint64_t l[N];
 

@@ -372,6 +372,102 @@ def ipa_rounds(curve, comm_key, coeffs, z_point, h_prime, challenges):
     return l_vec, r_vec, key[0], cs[0]
 
 
+# ----------------------------------------------------------------------------------------
+# Fiat-Shamir transcript of InnerProductArgPC::open (ipa_pc/mod.rs:74-87, 615-625, 681-688).
+# The byte conventions live in ark-serialize / ark-ff / ark-ec 0.5 (not under /root/reference): restated
+# from their published behaviour -- see oracle/oracle.cpp (ser_point) for the statement.
+# ----------------------------------------------------------------------------------------
+def ser_field(field, v):
+    nbytes = (FIELDS[field]["p"].bit_length() + 7) // 8
+    return int(v).to_bytes(nbytes, "little")
+
+
+def ser_point(curve, P):
+    """serialize_uncompressed of a G1 affine point."""
+    fq = CURVES[curve]["fq"]
+    p = FIELDS[fq]["p"]
+    xb = (p.bit_length() + 7) // 8
+    yb = (p.bit_length() + 2 + 7) // 8
+    if curve == "bls12_381":                       # ark-bls12-381: zcash / IETF encoding, big-endian
+        if P is None:
+            return bytes([0x40]) + bytes(2 * xb - 1)
+        return P[0].to_bytes(xb, "big") + P[1].to_bytes(xb, "big")
+    if P is None:
+        out = bytearray(xb + yb)
+        out[-1] |= 0x40
+        return bytes(out)
+    out = bytearray(P[0].to_bytes(xb, "little") + P[1].to_bytes(yb, "little"))
+    if P[1] <= (p - P[1]) % p:                     # SWFlags::YIsNegative unless y > -y
+        out[-1] |= 0x80
+    return bytes(out)
+
+
+def from_random_bytes(field, b):
+    """Field::from_random_bytes: low 8*N bytes little-endian, bits above the modulus size cleared; None if >= p."""
+    p = FIELDS[field]["p"]
+    n64 = FIELDS[field]["limbs64"]
+    v = int.from_bytes(b[: 8 * n64].ljust(8 * n64, b"\0"), "little")
+    v &= (1 << p.bit_length()) - 1
+    return v if v < p else None
+
+
+def random_oracle_challenge(field, data):
+    """compute_random_oracle_challenge with D = Blake2s (ipa_pc/mod.rs:74-87)."""
+    import hashlib
+    i = 0
+    while True:
+        c = from_random_bytes(field, hashlib.blake2s(data + i.to_bytes(8, "little")).digest())
+        if c is not None:
+            return c
+        i += 1
+
+
+def ipa_open(curve, comm_key, h, polys, comms, point, opening_challenges):
+    """InnerProductArgPC::open without hiding and degree bounds (ipa_pc/mod.rs:475-723).  polys: coefficient
+    lists (canonical ints) of at most len(comm_key) coefficients; comms: their commitments; opening_challenges:
+    what the caller's sponge squeezes at :502 / :525 / :556, one per polynomial (the sponge is the caller's).
+    Returns (l_vec, r_vec, final_comm_key, c, round_challenges)."""
+    fr = CURVES[curve]["fr"]
+    p = FIELDS[fr]["p"]
+    n = len(comm_key)
+    combined = [0] * n
+    combined_comm = None
+    for poly, comm, xi in zip(polys, comms, opening_challenges):
+        for i, v in enumerate(poly):
+            combined[i] = (combined[i] + xi * v) % p
+        combined_comm = ec_add(curve, combined_comm, ec_mul(curve, xi, comm))
+    combined_v = poly_eval(fr, combined, point)
+    rc = random_oracle_challenge(fr, ser_point(curve, combined_comm) + ser_field(fr, point) + ser_field(fr, combined_v))
+    h_prime = ec_mul(curve, rc, h)
+    chal = []
+
+    class _FS:
+        def __getitem__(self, rnd):
+            return chal[rnd]
+    # replay ipa_rounds with the transcript-derived challenges
+    zs = [pow(point, i, p) for i in range(n)]
+    key, cs = list(comm_key), list(combined)
+    l_vec, r_vec = [], []
+    m = n
+    while m > 1:
+        hh = m // 2
+        ip_l = sum(a * b for a, b in zip(cs[hh:m], zs[:hh])) % p
+        ip_r = sum(a * b for a, b in zip(cs[:hh], zs[hh:m])) % p
+        l = ec_add(curve, msm(curve, key[:hh], cs[hh:m]), ec_mul(curve, ip_l, h_prime))
+        r = ec_add(curve, msm(curve, key[hh:m], cs[:hh]), ec_mul(curve, ip_r, h_prime))
+        l_vec.append(l)
+        r_vec.append(r)
+        rc = random_oracle_challenge(fr, ser_field(fr, rc) + ser_point(curve, l) + ser_point(curve, r))
+        chal.append(rc)
+        ui = pow(rc, -1, p)
+        for i in range(hh):
+            cs[i] = (cs[i] + ui * cs[hh + i]) % p
+            zs[i] = (zs[i] + rc * zs[hh + i]) % p
+            key[i] = ec_add(curve, key[i], ec_mul(curve, rc, key[hh + i]))
+        m = hh
+    return l_vec, r_vec, key[0], cs[0], chal
+
+
 def column_digest(field, column_canonical, hash_name):
     """FieldToBytesColHasher<F, D>::evaluate (bench-templates/src/lib.rs:327-337): D over
     to_bytes!(column) = u64 LE length || 32-byte LE canonical residues."""

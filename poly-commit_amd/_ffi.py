@@ -86,6 +86,7 @@ def load_library():
     lib.pc_hip_fr_dot.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
     lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
+    lib.pc_hip_ipa_key_scalars.argtypes = [vp, ip, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_poly_eval.argtypes = [vp, ip, vp, ip, sz, vp, vp]
@@ -288,6 +289,14 @@ class Context:
     def fr_powers(self, curve, z, n, out_dev):
         z = np.ascontiguousarray(z, dtype=np.uint64)
         self.check(self.lib.pc_hip_fr_powers(self.h, CURVES[curve], C.c_void_p(z.ctypes.data), n, out_dev))
+
+    def ipa_key_scalars(self, curve, coeffs_dev, m, s_dev, n0, fold_u=None, fold_m=0, out_l_dev=None, out_r_dev=None):
+        """pc_hip_ipa_key_scalars: fold the key factors s by fold_u (optional), build the round's MSM scalars (optional)."""
+        fu = None
+        if fold_u is not None:
+            fold_u = np.ascontiguousarray(fold_u, dtype=np.uint64)
+            fu = C.c_void_p(fold_u.ctypes.data)
+        self.check(self.lib.pc_hip_ipa_key_scalars(self.h, CURVES[curve], coeffs_dev, m, s_dev, n0, fu, fold_m, out_l_dev, out_r_dev))
 
     def fixed_base_batch_mul(self, curve, g_xy, scalars_dev, n, out_dev):
         """out[i] = scalars[i] * g (device buffers): the SRS generation of KZG10::setup."""

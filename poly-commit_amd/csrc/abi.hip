@@ -584,6 +584,20 @@ int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t 
     return (int)PC_OK;
   });
 }
+int pc_hip_ipa_key_scalars(pc_ctx* ctx, pc_curve field_of, const void* coeffs_dev, size_t m, void* s_dev, size_t n0,
+                           const void* fold_u_host, size_t fold_m, void* out_l_dev, void* out_r_dev) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !s_dev || !n0 || (n0 & (n0 - 1))) return PC_ERR_INVALID_ARG;
+  if (fold_u_host && (fold_m < 2 || (fold_m & (fold_m - 1)) || fold_m > n0)) return PC_ERR_INVALID_ARG;
+  if ((out_l_dev != nullptr) != (out_r_dev != nullptr)) return PC_ERR_INVALID_ARG;
+  if (out_l_dev && (!coeffs_dev || m < 2 || (m & (m - 1)) || m > n0)) return PC_ERR_INVALID_ARG;
+  if (n0 >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    pc::field_ops(field_of).ipa_key_scalars(ctx->be, (const uint32_t*)coeffs_dev, m, (uint32_t*)s_dev, n0, (const uint32_t*)fold_u_host, fold_m,
+                                            (uint32_t*)out_l_dev, (uint32_t*)out_r_dev);
+    return (int)PC_OK;
+  });
+}
 int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
                          unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
                          pc_mem where_ext, void* leaves_out_host, void* nodes_out_host) {

@@ -43,7 +43,17 @@ void ec_fold_run(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_m
   EcFoldGlvBody<C> body; body.key = key; body.half = (uint32_t)half;
   body.n1.from_scalar(sp.k1); body.n2.from_scalar(sp.k2); body.neg1 = sp.neg1; body.neg2 = sp.neg2;
   for (int i = 0; i < C::FqP::N; i++) body.beta[i] = G::BETA_MONT[i];
-  be.launch(body, half, 64); be.sync();
+  constexpr int FN = C::FqP::N;
+  if (half >= 4096) {
+    // ladders leave Jacobian results; one inversion per K of them (normalize_batch, ipa_pc/mod.rs:706-708)
+    uint32_t* ws = (uint32_t*)be.workspace(half * (size_t)4 * FN * 4);
+    body.jac_out = ws;
+    be.launch(body, half, 64);
+    const uint32_t K = half >= ((size_t)1 << 20) ? 16 : half >= ((size_t)1 << 17) ? 8 : 4;     // >= 2^14 lanes while it matters
+    JacBatchAffineBody<C> nb{ws, ws + half * (size_t)3 * FN, key, (uint32_t)half, K};
+    be.launch(nb, (half + K - 1) / K, 64);
+  } else be.launch(body, half, 64);
+  be.sync();
 }
 
 template <class C>

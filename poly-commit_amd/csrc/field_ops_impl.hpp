@@ -62,6 +62,12 @@ struct FieldOpsImpl {
     for (int k = 0; k < 32; k++) { w.store(body.pt.w[k]); w = w.sqr(); }
     be.launch(body, n); be.sync();
   }
+  static void ipa_key_scalars(HipBackend& be, const uint32_t* c, size_t m, uint32_t* s, size_t n0, const uint32_t* fold_u, size_t fold_m,
+                              uint32_t* out_l, uint32_t* out_r) {
+    if (fold_u) { IpaKeyScalarUpdateBody<FrP> b{s, (uint32_t)fold_m, F::load(fold_u)}; be.launch(b, n0); }
+    if (out_l) { IpaFixedKeyScalarsBody<FrP> b{c, s, (uint32_t)m, out_l, out_r}; be.launch(b, n0); }
+    be.sync();
+  }
   static void fr_lincomb(HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out) {
     FrLinCombBody<FrP> b{(const uint64_t*)addr, (const uint32_t*)lens, (const uint32_t*)xi, (uint32_t)k, (uint32_t*)out};
     be.launch(b, n_out, 256);
@@ -71,7 +77,7 @@ struct FieldOpsImpl {
     else { ColumnHashBody<FrP, Blake2s256> b{e, rows, n_cols, o}; be.launch(b, n_cols, 64); }
   }
   static FieldOps table() {
-    return FieldOps{&make_ntt, &poly_eval_f, &div_scan_f, &witness_f, &fr_fold, &fr_dot, &fr_powers, &fr_lincomb, &column_hash};
+    return FieldOps{&make_ntt, &poly_eval_f, &div_scan_f, &witness_f, &fr_fold, &fr_dot, &fr_powers, &ipa_key_scalars, &fr_lincomb, &column_hash};
   }
 };
 

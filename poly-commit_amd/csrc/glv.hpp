@@ -68,6 +68,8 @@ struct EcFoldGlvBody {
   NafMasks<5> n1, n2;      // NAF of |k1|, |k2|
   uint32_t neg1, neg2;
   uint32_t beta[Fq::N];
+  uint32_t* jac_out = nullptr;   // not null: store (X, Y, Z) of lane i here instead of normalising in the lane
+                                 // (JacBatchAffineBody then writes key[i] with one inversion per K points)
   PC_HD void operator()(uint32_t i) const {
     AffD<C> kl = AffD<C>::load(key + (size_t)i * AW), kr = AffD<C>::load(key + (size_t)(half + i) * AW);
     AffD<C> p1 = kr.neg_if(neg1 != 0);
@@ -83,7 +85,11 @@ struct EcFoldGlvBody {
       if (n2.pos[w] & m) acc.add_affine(p2); else if (n2.neg[w] & m) acc.add_affine(m2);
     }
     acc.add_affine(kl);
-    acc.to_affine().store(key + (size_t)i * AW);
+    if (jac_out) {
+      uint32_t* o = jac_out + (size_t)i * 3 * Fq::N;
+      if (acc.is_inf()) { Fq::zero().store(o); Fq::zero().store(o + Fq::N); Fq::zero().store(o + 2 * Fq::N); }
+      else { acc.X.store(o); acc.Y.store(o + Fq::N); acc.Z.store(o + 2 * Fq::N); }
+    } else acc.to_affine().store(key + (size_t)i * AW);
   }
 };
 

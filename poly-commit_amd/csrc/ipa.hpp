@@ -61,6 +61,34 @@ struct FrPowersBody {
   }
 };
 
+// Late halving rounds without touching the key (ipa_pc/mod.rs:664-711 for n <= n0): the resident key K0 of the
+// round where the prover switches stays fixed; the key the reference would hold after further folds is
+//   key_i = sum over j = i (mod m) of s_j * K0_j,      s_j = product of the challenges whose fold put K0_j on
+// the "times u" side, so the round's two commitments are MSMs over K0 with combined scalars,
+//   L = sum_{j mod m <  h} (c[h + j mod m] * s_j) K0_j,     R = sum_{j mod m >= h} (c[j mod m - h] * s_j) K0_j,
+// and final_comm_key = sum_j s_j K0_j.  A fold of n/2 full scalar multiplications is latency-bound at ~2.4 ms
+// however small n gets; two more MSMs of n0 pairs are not.
+template <class FrP>
+struct IpaKeyScalarUpdateBody {      // the fold by u at size m: s_j *= u where (j mod m) >= m/2
+  typedef Fd<FrP> F;
+  uint32_t* s; uint32_t m; F u;
+  PC_HD void operator()(uint32_t j) const {
+    if ((j & (m - 1)) >= (m >> 1)) F::load(s + (size_t)j * FrP::N).mul(u).store(s + (size_t)j * FrP::N);
+  }
+};
+template <class FrP>
+struct IpaFixedKeyScalarsBody {      // scalar vectors of L and R for the round at size m
+  typedef Fd<FrP> F;
+  const uint32_t* c; const uint32_t* s; uint32_t m; uint32_t* out_l; uint32_t* out_r;
+  PC_HD void operator()(uint32_t j) const {
+    const uint32_t i = j & (m - 1), h = m >> 1;
+    const F sj = F::load(s + (size_t)j * FrP::N);
+    const F v = F::load(c + (size_t)(i < h ? h + i : i - h) * FrP::N).mul(sj);
+    (i < h ? v : F::zero()).store(out_l + (size_t)j * FrP::N);
+    (i < h ? F::zero() : v).store(out_r + (size_t)j * FrP::N);
+  }
+};
+
 // scalar * affine point with a NAF-recoded scalar shared by all lanes (branch-uniform), Jacobian
 template <class C, int NW>
 PC_HD JacD<C> naf_mul(const NafMasks<NW>& naf, const AffD<C>& p) {

@@ -48,6 +48,8 @@ struct FieldOps {
   void (*fr_fold)(HipBackend& be, uint32_t* lo, const uint32_t* hi, size_t n, const uint32_t* s);
   void (*fr_dot)(HipBackend& be, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out_host);
   void (*fr_powers)(HipBackend& be, const uint32_t* z, size_t n, uint32_t* out);
+  void (*ipa_key_scalars)(HipBackend& be, const uint32_t* c, size_t m, uint32_t* s, size_t n0, const uint32_t* fold_u, size_t fold_m,
+                          uint32_t* out_l, uint32_t* out_r);
   void (*fr_lincomb)(HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out);
   void (*column_hash)(HipBackend& be, int hash, const uint32_t* ext, uint32_t rows, uint32_t n_cols, uint32_t* out);
 };

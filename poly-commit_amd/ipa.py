@@ -6,15 +6,95 @@ that produces the challenge (`compute_random_oracle_challenge`, :74-87, Blake2s 
 ark-serialize bytes) is host work on two points and stays with the caller: it is passed in as
 `next_challenge(l_xy, r_xy) -> u (Montgomery Fr limbs)`.
 """
+import hashlib
+
 import numpy as np
 
 from . import _ffi
 from .sharded import FR_MODULUS, _R, _int_to_limbs, _limbs_to_int
 
+# base-field moduli: needed only to serialise points for the transcript
+FQ_MODULUS = {
+    "bls12_381": 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+    "bn254": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    "pallas": 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+}
 
-def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, timings=None):
+
+# ---- Fiat-Shamir transcript (ipa_pc/mod.rs:74-87, 615-625, 681-688); byte conventions of ark-serialize /
+# ark-ff / ark-ec / ark-bls12-381 0.5 restated from their published behaviour (see host/transcript.hpp) ----
+def ser_fr(curve, limbs_mont):
+    p = FR_MODULUS[curve]
+    v = _limbs_to_int(limbs_mont) * pow(_R, -1, p) % p
+    return v.to_bytes((p.bit_length() + 7) // 8, "little")
+
+
+def ser_point(curve, xy_mont):
+    q = FQ_MODULUS[curve]
+    nq = len(xy_mont) // 2
+    rq = 1 << (64 * nq)
+    xb, yb = (q.bit_length() + 7) // 8, (q.bit_length() + 2 + 7) // 8
+    inf = not np.asarray(xy_mont).any()
+    x = _limbs_to_int(xy_mont[:nq]) * pow(rq, -1, q) % q
+    y = _limbs_to_int(xy_mont[nq:]) * pow(rq, -1, q) % q
+    if curve == "bls12_381":
+        if inf:
+            return bytes([0x40]) + bytes(2 * xb - 1)
+        return x.to_bytes(xb, "big") + y.to_bytes(xb, "big")
+    out = bytearray(xb + yb)
+    if inf:
+        out[-1] |= 0x40
+        return bytes(out)
+    out[:] = x.to_bytes(xb, "little") + y.to_bytes(yb, "little")
+    if y <= (q - y) % q:
+        out[-1] |= 0x80
+    return bytes(out)
+
+
+def random_oracle_challenge(curve, data):
+    """compute_random_oracle_challenge with D = Blake2s: returns the challenge as Montgomery limbs."""
+    p = FR_MODULUS[curve]
+    i = 0
+    while True:
+        h = hashlib.blake2s(data + i.to_bytes(8, "little")).digest()
+        v = int.from_bytes(h, "little") & ((1 << p.bit_length()) - 1)
+        if v < p:
+            return _int_to_limbs(v * _R % p)
+        i += 1
+
+
+def ipa_open(ctx, curve, comm_key, h_xy, polys_dev, lens, comms, point_mont, opening_challenges, timings=None):
+    """InnerProductArgPC::open without hiding / degree bounds (ipa_pc/mod.rs:475-723): combine with the sponge's
+    opening challenges (supplied), derive the random-oracle challenges from the transcript, run the rounds.
+    polys_dev: device pointers of the coefficient vectors; comms: their commitments (x||y).
+    Returns (l_vec, r_vec, final_comm_key, c)."""
+    import torch
+    n = comm_key.shape[0]
+    p = FR_MODULUS[curve]
+    xi = np.ascontiguousarray(opening_challenges, dtype=np.uint64)
+    comb = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.fr_lincomb(curve, list(polys_dev), xi, n_out=n, out=comb.data_ptr(), lens=list(lens))
+    ccomm = _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, c, x) for c, x in zip(comms, xi)]))
+    v = ctx.poly_eval(curve, comb.data_ptr(), point_mont, n=n)
+    rc = random_oracle_challenge(curve, ser_point(curve, ccomm) + ser_fr(curve, point_mont) + ser_fr(curve, v))
+    h_prime = _ffi.point_mul(curve, np.ascontiguousarray(h_xy), rc)
+    state = {"rc": rc}
+
+    def next_challenge(l, r):
+        state["rc"] = random_oracle_challenge(curve, ser_fr(curve, state["rc"]) + ser_point(curve, l) + ser_point(curve, r))
+        return state["rc"]
+    return ipa_open_rounds(ctx, curve, comm_key, comb, n, point_mont, h_prime, next_challenge, timings), rc
+
+
+FIXED_KEY_BELOW = 1 << 17     # rounds with n <= this keep the key and fold per-base factors instead (pc_hip_ipa_key_scalars)
+
+
+def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, timings=None,
+                    fixed_key_below=None):
     """comm_key: n x (x||y) host array; coeffs_dev: torch cuda int64 tensor (n,4), Montgomery,
     CONSUMED (folded in place).  Returns (l_vec, r_vec, final_comm_key, c) as numpy arrays."""
+    if fixed_key_below is None:
+        fixed_key_below = FIXED_KEY_BELOW
     import time
     import torch
     assert n & (n - 1) == 0
@@ -38,12 +118,25 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     ctx.fr_powers(curve, point_mont, n, z.data_ptr())
     cptr, zptr = coeffs_dev.data_ptr(), z.data_ptr()
     l_vec, r_vec = [], []
+    n0, s_dev, al, ar = 0, None, None, None
     while n > 1:
         h = n // 2
+        if not n0 and n <= fixed_key_below:
+            # from here on the resident key key[0..n0) stays fixed; the folds act on the per-base factors s
+            n0 = n
+            one = _int_to_limbs(_R % p)
+            s_dev = torch.empty((n0, 4), dtype=torch.int64, device=coeffs_dev.device)
+            ctx.fr_powers(curve, one, n0, s_dev.data_ptr())                # s = (1, 1, ...)
+            al, ar = torch.empty_like(s_dev), torch.empty_like(s_dev)
         # l = cm_commit(key_l, coeffs_r) + h' * <coeffs_r, z_l>;  r = cm_commit(key_r, coeffs_l) + h' * <coeffs_l, z_r>
         with _T("msm_enqueue"):
-            jl = srs.msm_async(cptr + 32 * h, n=h, base_offset=0, montgomery=True)
-            jr = srs.msm_async(cptr, n=h, base_offset=h, montgomery=True)
+            if n0:
+                ctx.ipa_key_scalars(curve, cptr, n, s_dev.data_ptr(), n0, out_l_dev=al.data_ptr(), out_r_dev=ar.data_ptr())
+                jl = srs.msm_async(al.data_ptr(), n=n0, base_offset=0, montgomery=True)
+                jr = srs.msm_async(ar.data_ptr(), n=n0, base_offset=0, montgomery=True)
+            else:
+                jl = srs.msm_async(cptr + 32 * h, n=h, base_offset=0, montgomery=True)
+                jr = srs.msm_async(cptr, n=h, base_offset=h, montgomery=True)
         with _T("fr_dot"):
             ip_l = ctx.fr_dot(curve, cptr + 32 * h, zptr, h)
             ip_r = ctx.fr_dot(curve, cptr, zptr + 32 * h, h)
@@ -61,9 +154,15 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
             ctx.fr_fold(curve, cptr, cptr + 32 * h, h, _int_to_limbs(ui))   # coeffs_l += u^-1 coeffs_r
             ctx.fr_fold(curve, zptr, zptr + 32 * h, h, u)                   # z_l += u z_r
         with _T("ec_fold"):
-            srs.ec_fold(h, u)                                               # key_l += u key_r, normalised
+            if n0:
+                ctx.ipa_key_scalars(curve, None, 0, s_dev.data_ptr(), n0, fold_u=u, fold_m=n)   # the same fold, on the factors
+            else:
+                srs.ec_fold(h, u)                                           # key_l += u key_r, normalised
         n = h
-    final_key = srs.read(0, 1)[0]
+    if n0:
+        final_key = srs.msm(s_dev.data_ptr(), n=n0, base_offset=0, montgomery=True)[0]   # sum_j s_j K0_j
+    else:
+        final_key = srs.read(0, 1)[0]
     c = coeffs_dev[0].cpu().numpy().view(np.uint64).copy()
     srs.free()
     return np.stack(l_vec), np.stack(r_vec), final_key, c

@@ -233,6 +233,42 @@ extern "C" void emu_ipa_bodies(int curve, uint32_t* key, size_t half, const uint
   }
 }
 
+// the fixed-key late rounds (IpaKeyScalarUpdateBody / IpaFixedKeyScalarsBody) and the batched normalisation
+template <class FrP>
+static void key_scalars(const uint32_t* c, uint32_t m, uint32_t* s, uint32_t n0, const uint32_t* fold_u, uint32_t fold_m, uint32_t* out_l, uint32_t* out_r) {
+  CpuStepBackend be;
+  if (fold_u) { pc::IpaKeyScalarUpdateBody<FrP> b{s, fold_m, pc::Fd<FrP>::load(fold_u)}; be.launch(b, n0); }
+  if (out_l) { pc::IpaFixedKeyScalarsBody<FrP> b{c, s, m, out_l, out_r}; be.launch(b, n0); }
+}
+extern "C" void emu_ipa_key_scalars(int curve, const uint32_t* c, uint32_t m, uint32_t* s, uint32_t n0, const uint32_t* fold_u, uint32_t fold_m,
+                                    uint32_t* out_l, uint32_t* out_r) {
+  switch (curve) {
+    case 0: key_scalars<pc_bls12_381_fr>(c, m, s, n0, fold_u, fold_m, out_l, out_r); break;
+    case 1: key_scalars<pc_bn254_fr>(c, m, s, n0, fold_u, fold_m, out_l, out_r); break;
+    case 2: key_scalars<pc_pallas_fr>(c, m, s, n0, fold_u, fold_m, out_l, out_r); break;
+  }
+}
+template <class C>
+static void glv_fold_batched(uint32_t* key, size_t half, const uint64_t* k_canon, uint32_t K) {
+  typedef typename pc::GlvOf<C>::T G;
+  constexpr int FN = C::FqP::N;
+  pc::GlvSplit sp = pc::glv_decompose<G>(k_canon);
+  std::vector<uint32_t> ws(half * 4 * FN);
+  pc::EcFoldGlvBody<C> body; body.key = key; body.half = (uint32_t)half; body.jac_out = ws.data();
+  body.n1.from_scalar(sp.k1); body.n2.from_scalar(sp.k2); body.neg1 = sp.neg1; body.neg2 = sp.neg2;
+  for (int i = 0; i < FN; i++) body.beta[i] = G::BETA_MONT[i];
+  CpuStepBackend be; be.launch(body, half);
+  pc::JacBatchAffineBody<C> nb{ws.data(), ws.data() + half * 3 * FN, key, (uint32_t)half, K};
+  be.launch(nb, (half + K - 1) / K);
+}
+extern "C" void emu_glv_fold_batched(int curve, uint32_t* key, size_t half, const uint64_t* k_canon, uint32_t K) {
+  switch (curve) {
+    case 0: glv_fold_batched<pc_curve_bls12_381>(key, half, k_canon, K); break;
+    case 1: glv_fold_batched<pc_curve_bn254>(key, half, k_canon, K); break;
+    case 2: glv_fold_batched<pc_curve_pallas>(key, half, k_canon, K); break;
+  }
+}
+
 extern "C" void emu_fixed_base(int curve, const uint32_t* g, const uint32_t* scalars_mont, size_t n, uint32_t* out) {
   CpuStepBackend be;
   switch (curve) {

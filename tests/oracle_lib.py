@@ -211,6 +211,42 @@ def ipa_rounds(curve, comm_key, coeffs, z, h_prime, challenges, threads=8):
     return l, r, fk, c
 
 
+def ipa_rounds_fs(curve, comm_key, coeffs, z, h_prime, round_challenge0, threads=8):
+    """The halving rounds with the reference's Fiat-Shamir challenges (ipa_pc/mod.rs:681-688), starting from
+    the challenge open() derived before the loop.  Returns (l, r, final_key, c, challenges)."""
+    n = len(coeffs)
+    lg = n.bit_length() - 1
+    nq = 2 * fq_limbs(curve)
+    l = np.zeros((lg, nq), dtype=np.uint64)
+    r = np.zeros((lg, nq), dtype=np.uint64)
+    fk = np.zeros(nq, dtype=np.uint64)
+    c = np.zeros(4, dtype=np.uint64)
+    ch = np.zeros((max(lg, 1), 4), dtype=np.uint64)
+    lib().orc_ipa_rounds_fs(CURVES[curve], p64(comm_key), p64(coeffs), C.c_size_t(n), p64(z), p64(h_prime),
+                            p64(np.ascontiguousarray(round_challenge0)), threads, p64(l), p64(r), p64(fk), p64(c), p64(ch))
+    return l, r, fk, c, ch[:lg]
+
+
+def ipa_first_challenge(curve, commitment_xy, point, value):
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_ipa_first_challenge(CURVES[curve], p64(np.ascontiguousarray(commitment_xy)), p64(np.ascontiguousarray(point)),
+                                  p64(np.ascontiguousarray(value)), p64(out))
+    return out
+
+
+def ser_point(curve, xy):
+    buf = (C.c_uint8 * 128)()
+    lib().orc_ser_point.restype = C.c_size_t
+    n = lib().orc_ser_point(CURVES[curve], p64(np.ascontiguousarray(xy)), buf)
+    return bytes(buf[:n])
+
+
+def blake2s(data):
+    out = (C.c_uint8 * 32)()
+    lib().orc_blake2s(bytes(data), C.c_size_t(len(data)), out)
+    return bytes(out)
+
+
 def ligero_dims(field_bits, poly_len, rho_inv=4, sec_param=128):
     a, b, t = C.c_size_t(), C.c_size_t(), C.c_size_t()
     rc = lib().orc_ligero_dims(field_bits, C.c_size_t(poly_len), C.c_size_t(rho_inv), sec_param,

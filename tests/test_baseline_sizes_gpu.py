@@ -127,8 +127,9 @@ def test_marlin_batch_64_polys_deg_2p20_bn254(ctx, table):
 
 
 def test_ipa_open_rounds_pallas_2p22(ctx):
-    """configs[3]: InnerProductArgPC over Pallas, d + 1 = 2^22: cm_commit (ipa_pc/mod.rs:54-72) and all 22
-    halving rounds of open (:664-711) against the oracle's restatement -- l_vec, r_vec, final_comm_key, c."""
+    """configs[3]: InnerProductArgPC over Pallas, d + 1 = 2^22: cm_commit (ipa_pc/mod.rs:54-72) and a whole open
+    (:475-723, hiding off: combination, Fiat-Shamir transcript, all 22 halving rounds) against the oracle's
+    restatement -- Proof{l_vec, r_vec, final_comm_key, c} bit for bit."""
     import torch
     from poly_commit_amd import ipa
     curve, n = "pallas", 1 << 22
@@ -137,16 +138,25 @@ def test_ipa_open_rounds_pallas_2p22(ctx):
     comm_key, h_prime = np.ascontiguousarray(key[:n]), np.ascontiguousarray(key[n])
     coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE22, n))
     point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B22, 1))[0]
-    ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A122, lg))
     # the Pedersen commitment itself (config 4's commit)
     srs = ctx.upload_srs(curve, comm_key)
     cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
     comm, _ = srs.msm(cdev, n=n, montgomery=True)
     assert (comm == O.msm_pippenger(curve, comm_key, O.f_from_mont(curve, 1, coeffs), CORES, 1)).all()
     srs.free()
-    want_l, want_r, want_key, want_c = O.ipa_rounds(curve, comm_key, coeffs, point, h_prime, ch, threads=CORES)
-    it = iter(range(lg))
-    l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, comm_key, cdev, n, point, h_prime, lambda L, R_: ch[next(it)])
+    # open(): one polynomial, opening challenge from the (caller's) sponge, random-oracle challenges from the
+    # transcript (ipa_pc/mod.rs:615-625, 681-688) -- the whole Proof{l_vec, r_vec, final_comm_key, c}
+    xi = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A122, 1))
+    (l, r, fk, c), rc0 = ipa.ipa_open(ctx, curve, comm_key, h_prime, [cdev.data_ptr()], [n], [comm], point, xi)
+    assert l.shape[0] == lg
+    # oracle: same combination (xi * p, xi * C), same first challenge, rounds with its own transcript
+    xi_i = O.fr_from_mont_array(curve, xi)[0]
+    comb = O.fr_mont_array(curve, [v * xi_i % _p(curve) for v in O.fr_from_mont_array(curve, coeffs)])
+    ccomm = O.points_to_array(curve, [R.ec_mul(curve, xi_i, O.array_to_points(curve, comm)[0])])[0]
+    want_rc0 = O.ipa_first_challenge(curve, ccomm, point, O.poly_eval(curve, comb, point))
+    assert (rc0 == want_rc0).all()
+    hp = O.points_to_array(curve, [R.ec_mul(curve, _fr_int(curve, want_rc0), O.array_to_points(curve, h_prime)[0])])[0]
+    want_l, want_r, want_key, want_c, _ = O.ipa_rounds_fs(curve, comm_key, comb, point, hp, want_rc0, threads=CORES)
     assert (l == want_l).all() and (r == want_r).all()
     assert (fk == want_key).all() and (c == want_c).all()
 

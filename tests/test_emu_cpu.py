@@ -340,3 +340,53 @@ def test_glv_split_and_fold_stepped(curve):
         k2 = sum(int(split[5 + i]) << (32 * i) for i in range(5)) * (-1 if split[11] else 1)
         assert (k1 + k2 * lam - k) % r == 0 and abs(k1).bit_length() <= 130 and abs(k2).bit_length() <= 130
         assert O.array_to_points(curve, key[:half]) == [R.ec_add(curve, pts[i], R.ec_mul(curve, k, pts[half + i])) for i in range(half)]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_glv_fold_with_batched_normalisation_stepped(curve):
+    """EcFoldGlvBody leaving Jacobian results + JacBatchAffineBody (one inversion per K points, Montgomery's
+    trick -- normalize_batch of ipa_pc/mod.rs:706-708), including an infinity result inside a batch."""
+    fr = R.CURVES[curve]["fr"]
+    r = R.FIELDS[fr]["p"]
+    half = 7
+    pts = R.gen_bases(curve, 2 * half)
+    k = R.gen_scalars(fr, 77, 1)[0]
+    pts[2] = R.ec_neg(curve, R.ec_mul(curve, k, pts[half + 2]))      # key[2] + k * key[half + 2] = infinity
+    pts[half + 4] = None                                             # infinity among the inputs
+    for K in (1, 3, 4, 16):
+        key = O.points_to_array(curve, pts)
+        emu().emu_glv_fold_batched(O.CURVES[curve], p32(key.view(np.uint32)), C.c_size_t(half), O.p64(O.ints_to_limbs([k], 4)[0]), K)
+        assert O.array_to_points(curve, key[:half]) == [R.ec_add(curve, pts[i], R.ec_mul(curve, k, pts[half + i])) for i in range(half)], K
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ipa_fixed_key_rounds_stepped(curve):
+    """The late halving rounds without folding the key (pc_hip_ipa_key_scalars): with s the per-base factors,
+    MSM(K0, out_l) / MSM(K0, out_r) are the round's key-side sums and MSM(K0, s) is the folded key."""
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    n0 = 8
+    K0 = R.gen_bases(curve, n0)
+    key = list(K0)
+    cs = R.gen_scalars(fr, 0x51, n0)
+    s = O.fr_mont_array(curve, [1] * n0)
+    ci = O.CURVES[curve]
+    m = n0
+    for u in R.gen_scalars(fr, 0x52, 3):
+        h = m // 2
+        c_arr = O.fr_mont_array(curve, cs[:m])
+        out_l, out_r = np.zeros((n0, 4), dtype=np.uint64), np.zeros((n0, 4), dtype=np.uint64)
+        emu().emu_ipa_key_scalars(ci, p32(c_arr.view(np.uint32)), m, p32(s.view(np.uint32)), n0, None, 0, p32(out_l.view(np.uint32)), p32(out_r.view(np.uint32)))
+        assert R.msm(curve, K0, O.fr_from_mont_array(curve, out_l)) == R.msm(curve, key[:h], cs[h:m])
+        assert R.msm(curve, K0, O.fr_from_mont_array(curve, out_r)) == R.msm(curve, key[h:m], cs[:h])
+        # the fold, on the real key and on the factors
+        ui = pow(u, -1, p)
+        for i in range(h):
+            cs[i] = (cs[i] + ui * cs[h + i]) % p
+            key[i] = R.ec_add(curve, key[i], R.ec_mul(curve, u, key[h + i]))
+        u_m = O.fr_mont_array(curve, [u])[0]
+        emu().emu_ipa_key_scalars(ci, None, 0, p32(s.view(np.uint32)), n0, p32(u_m.view(np.uint32)), m, None, None)
+        m = h
+        assert [R.msm(curve, [K0[j] for j in range(n0) if j % m == i], [O.fr_from_mont_array(curve, s)[j] for j in range(n0) if j % m == i])
+                for i in range(m)] == key[:m]
+    assert R.msm(curve, K0, O.fr_from_mont_array(curve, s)) == key[0]

@@ -42,3 +42,17 @@ def test_kzg10_host_layer_like_reference_tests():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 4      # host logic + three curves
+
+
+def test_host_blake2s_rfc7693_vector():
+    """CPU: the host mirror's Blake2s (host/transcript.hpp, the digest of the IPA transcript) against RFC 7693
+    appendix B -- the driver checks it before it touches a device."""
+    libdir = os.path.join(ROOT, "poly-commit_amd")
+    if not os.path.exists(os.path.join(libdir, "libpc_hip.so")):
+        import importlib
+        importlib.import_module("poly_commit_amd.build").build()
+    exe = os.path.join(ROOT, "tests", "cpp", "ipa_open_driver")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, exe + ".cpp", "-L" + libdir, "-lpc_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "blake2s OK" in r.stdout

@@ -1,16 +1,27 @@
-"""GPU parity for the InnerProductArgPC halving rounds (ipa_pc/mod.rs:664-711) against the
-oracle's restatement, with the round challenges supplied (the Fiat-Shamir hash stays on the
-host with the caller)."""
+"""GPU parity for InnerProductArgPC (ipa_pc/mod.rs) against the oracle's restatement: the halving rounds with
+supplied challenges, and whole openings -- combination, Fiat-Shamir transcript (Blake2s over ark-serialize
+bytes), rounds -- through both host layers above the C ABI (the C++ mirror and the Python harness)."""
+import os
+import struct
+import subprocess
+
 import numpy as np
 import pytest
 
 import oracle_lib as O
+import pyref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("curve,n", [("pallas", 1 << 10), ("pallas", 4), ("bls12_381", 1 << 8), ("bn254", 1 << 9)])
-def test_ipa_open_rounds(ctx, curve, n):
+# fkb: size from which the rounds keep the key fixed and fold per-base factors (pc_hip_ipa_key_scalars);
+# None = the default, 0 = never (every round folds the key with pc_hip_ec_fold), 64 = switch in the middle
+@pytest.mark.parametrize("curve,n,fkb", [("pallas", 1 << 10, None), ("pallas", 1 << 10, 0), ("pallas", 1 << 13, 64),
+                                         ("pallas", 1 << 14, 0), ("pallas", 4, None), ("bls12_381", 1 << 8, 16),
+                                         ("bls12_381", 1 << 13, 0), ("bn254", 1 << 9, None), ("bn254", 1 << 9, 0)])
+def test_ipa_open_rounds(ctx, curve, n, fkb):
     import torch
     from poly_commit_amd import ipa
     lg = n.bit_length() - 1
@@ -23,6 +34,76 @@ def test_ipa_open_rounds(ctx, curve, n):
                                                     np.ascontiguousarray(h_prime), ch)
     it = iter(range(lg))
     cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
-    l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, comm_key, cdev, n, point, h_prime, lambda L, R_: ch[next(it)])
+    l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, comm_key, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb)
     assert (l == want_l).all() and (r == want_r).all()
     assert (fk == want_key).all() and (c == want_c).all()
+
+
+def _open_inputs(curve, n, k=2):
+    key = O.gen_bases(curve, n + 1)
+    comm_key, h = np.ascontiguousarray(key[:n]), np.ascontiguousarray(key[n])
+    lens = [n - 3 * j for j in range(k)]
+    polys = [O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x0FE0 + j, m)) for j, m in enumerate(lens)]
+    comms = [O.msm_pippenger(curve, comm_key, O.f_from_mont(curve, 1, q), 8, 1) for q in polys]
+    xi = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x0FE9, k))
+    point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x0FEA, 1))[0]
+    return comm_key, h, polys, comms, xi, point
+
+
+def _oracle_open(curve, comm_key, h, polys, comms, xi, point):
+    """The same opening through the oracle: combination in Python big ints, transcript + rounds in oracle.cpp."""
+    fr = R.CURVES[curve]["fr"]
+    n = len(comm_key)
+    comb_i = R.fr_lincomb(fr, [O.fr_from_mont_array(curve, q) for q in polys], O.fr_from_mont_array(curve, xi))
+    comb_i += [0] * (n - len(comb_i))
+    ccomm = None
+    for cm, x in zip(comms, O.fr_from_mont_array(curve, xi)):
+        ccomm = R.ec_add(curve, ccomm, R.ec_mul(curve, x, O.array_to_points(curve, cm)[0]))
+    comb = O.fr_mont_array(curve, comb_i)
+    v = O.poly_eval(curve, comb, point)
+    rc0 = O.ipa_first_challenge(curve, O.points_to_array(curve, [ccomm])[0], point, v)
+    h_prime = O.points_to_array(curve, [R.ec_mul(curve, O.fr_from_mont_array(curve, rc0.reshape(1, 4))[0], O.array_to_points(curve, h)[0])])[0]
+    return O.ipa_rounds_fs(curve, comm_key, comb, point, h_prime, rc0, threads=os.cpu_count() or 8)
+
+
+@pytest.mark.parametrize("curve,n", [("pallas", 1 << 10), ("bn254", 1 << 6), ("bls12_381", 1 << 7)])
+def test_ipa_open_whole_proof_python_host(ctx, curve, n):
+    """Proof{l_vec, r_vec, final_comm_key, c} of InnerProductArgPC::open (ipa_pc/mod.rs:715-722), two polynomials,
+    random-oracle challenges from the transcript: the device path vs the oracle, bit for bit."""
+    import torch
+    from poly_commit_amd import ipa
+    comm_key, h, polys, comms, xi, point = _open_inputs(curve, n)
+    dev = [torch.from_numpy(q.view(np.int64).copy()).cuda() for q in polys]
+    (l, r, fk, c), _ = ipa.ipa_open(ctx, curve, comm_key, h, [d.data_ptr() for d in dev], [len(q) for q in polys], comms, point, xi)
+    wl, wr, wfk, wc, _ = _oracle_open(curve, comm_key, h, polys, comms, xi, point)
+    assert (l == wl).all() and (r == wr).all() and (fk == wfk).all() and (c == wc).all()
+
+
+@pytest.mark.parametrize("curve,n", [("pallas", 1 << 8), ("bn254", 1 << 5), ("bls12_381", 1 << 5)])
+def test_ipa_open_whole_proof_cpp_host_mirror(curve, n, tmp_path):
+    """The same through the C++ host mirror (host/ipa_pc.hpp: InnerProductArgPC::open, host/transcript.hpp):
+    what the Rust shim would do, in the language that builds here."""
+    comm_key, h, polys, comms, xi, point = _open_inputs(curve, n)
+    libdir = os.path.join(ROOT, "poly-commit_amd")
+    exe = os.path.join(ROOT, "tests", "cpp", "ipa_open_driver")
+    src = exe + ".cpp"
+    deps = [src, os.path.join(libdir, "libpc_hip.so")] + [os.path.join(libdir, "host", f) for f in os.listdir(os.path.join(libdir, "host"))]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + libdir, "-lpc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<III", O.CURVES[curve], n, len(polys)))
+        f.write(comm_key.tobytes()); f.write(h.tobytes())
+        for q in polys:
+            f.write(struct.pack("<I", len(q))); f.write(q.tobytes())
+        for cm in comms:
+            f.write(cm.tobytes())
+        f.write(point.tobytes()); f.write(xi.tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lg, nq = n.bit_length() - 1, 2 * O.fq_limbs(curve)
+    got = np.fromfile(fout, dtype=np.uint64)
+    assert got.size == (2 * lg + 1) * nq + 4
+    wl, wr, wfk, wc, _ = _oracle_open(curve, comm_key, h, polys, comms, xi, point)
+    assert (got[:lg * nq].reshape(lg, nq) == wl).all() and (got[lg * nq:2 * lg * nq].reshape(lg, nq) == wr).all()
+    assert (got[2 * lg * nq:(2 * lg + 1) * nq] == wfk).all() and (got[(2 * lg + 1) * nq:] == wc).all()
