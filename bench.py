@@ -82,9 +82,12 @@ def bench_ntt(args):
     poly_len = 1 << 24
     n_rows, n_cols, _ = O.ligero_dims(255 if curve != "bn254" else 254, poly_len, 4)
     log_n = (n_cols * 4 - 1).bit_length()
-    rows = n_rows // world                      # rows are independent: shard by rows, no collective
+    from poly_commit_amd import sharded
     ctx = pc.Context(local_rank)
     ctx.set_timing(True)
+    shard = sharded.ShardedRows(sharded.HipEngine(ctx, curve), rank, world)   # rows are independent: shard by rows, no collective
+    r_lo, r_hi = shard.row_range(n_rows)
+    rows = r_hi - r_lo
     co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0500 + rank, rows * n_cols))
     x = torch.from_numpy(co.view(np.int64)).cuda()
     y = torch.empty((rows << log_n, 4), dtype=torch.int64, device="cuda")
@@ -111,13 +114,13 @@ def bench_ntt(args):
     torch.cuda.synchronize()
     ph = np.zeros(2)
     for _ in range(args.warmup):
-        ctx.ntt_batch(curve, x.data_ptr(), log_n, out=y.data_ptr(), rows=rows, in_cols=n_cols)
+        shard.encode(x, rows, n_cols, log_n, y)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.ntt_batch(curve, x.data_ptr(), log_n, out=y.data_ptr(), rows=rows, in_cols=n_cols)
+        shard.encode(x, rows, n_cols, log_n, y)
         ph += np.array(ctx.last_ntt_phases_ms())
     torch.cuda.synchronize()
     if dist is not None:
@@ -168,32 +171,21 @@ def bench_batch(args):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     curve = "bn254" if args.curve == "bls12_381" else args.curve
+    from poly_commit_amd import sharded
     total = (1 << args.log_degree) + 1
-    per = (total + world - 1) // world
-    lo, hi = rank * per, min(total, (rank + 1) * per)
+    lo, hi = sharded.ShardedBatch.chunk_range(total, rank, world)
     n = hi - lo
     ctx = pc.Context(local_rank)
     ctx.set_timing(True)
-    bases = O.gen_bases(curve, n)                  # synthetic chunk (every rank the same points: throughput only)
-    srs = ctx.upload_srs(curve, bases)
-    if args.precompute:
-        srs.precompute()
-    for _ in range(3):                  # create every pipeline of the SRS (streams + workspace) before anything is timed
-        srs.msm(np.zeros((1, 4), dtype=np.uint64), n=0)     # empty MSM: creates the pipeline, launches nothing
+    job = sharded.ShardedBatch(sharded.HipEngine(ctx, curve), curve, rank, world, dist)
+    job.load_srs_chunk(O.gen_bases(curve, n), precompute=bool(args.precompute))   # synthetic chunk (every rank the same points: throughput only)
     polys = [torch.from_numpy(O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0100 + j, n)).view(np.int64)).cuda()
              for j in range(args.polys)]
-    ptrs, lens = [p.data_ptr() for p in polys], [n] * args.polys
+    lens = [n] * args.polys
     torch.cuda.synchronize()
 
     def step():
-        part = srs.msm_batch(ptrs, lens)
-        if dist is None:
-            return part
-        t = torch.from_numpy(part.reshape(-1).view(np.int64).copy()).cuda()
-        out = torch.empty(world * t.numel(), dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(out, t)
-        allp = out.cpu().numpy().view(np.uint64).reshape(world, args.polys, -1)
-        return np.stack([pc.points_sum(curve, np.ascontiguousarray(allp[:, j])) for j in range(args.polys)])
+        return job.commit_batch(polys, lens)
 
     for _ in range(args.warmup):
         step()
@@ -258,10 +250,13 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
     def step_resident(_k):
         # commit and open of one polynomial; up to `depth` results stay in flight so that the
         # latency-bound tail of one MSM overlaps the bucket accumulation of the next
+        # (N > 1: the open's exchange step -- shard evaluation + all_gather of one Fr per rank -- runs first, while
+        # the previous step's MSMs are still in flight, so the blocking collective does not drain the pipelines)
+        carry = job.open_prepare(coeffs, n)
         pending.append(job.commit_async(coeffs, n))
         if depth == 0:                       # strictly blocking calls: the commitment is back before the open starts
             pending.popleft().result()
-        pending.append(job.open_async(coeffs, n))
+        pending.append(job.open_async(coeffs, n, prepared=True, carry=carry))
         while len(pending) > depth:
             pending.popleft().result()
 

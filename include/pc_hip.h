@@ -263,6 +263,42 @@ int pc_hip_fixed_base_batch_mul(pc_ctx* ctx, pc_curve curve, const void* g_xy_ho
 /* Copy `count` resident affine points starting at `offset` back to the host (final_comm_key). */
 int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, void* out_xy);
 
+/* ---- One committer key over several GPUs of a node, driven from one process ----------------
+ * The reference has no multi-device path; this is the form a prover that holds ONE CommitterKey needs.  The key is
+ * cut into N contiguous chunks, one per device (chunk d also keeps the one power below it, so that commit and open
+ * address the same resident chunk).  Every call runs the complete single-device path on each chunk in parallel
+ * (one host thread per device) -- each device reduces its buckets to ONE point -- and adds the N partial points on
+ * the host (what pc_hip_points_sum does; N * 96 bytes, no device-to-device collective: raw bucket arrays never
+ * move).  Results are bit-identical to the single-device calls.  A device id may be listed more than once (tests on
+ * a one-GPU machine).  The one-process-per-GPU form of the same protocol over RCCL is poly-commit_amd/sharded.py. */
+typedef struct pc_group pc_group;
+typedef struct pc_group_srs pc_group_srs;
+int pc_hip_group_create(const int* device_ids, int n_devices, pc_group** out);
+void pc_hip_group_destroy(pc_group* g);
+int pc_hip_group_size(const pc_group* g);
+pc_ctx* pc_hip_group_ctx(pc_group* g, int i);
+/* `trim` for the sharded key (marlin_pc/mod.rs:80-169): upload chunk d to device d; precompute != 0 also builds
+ * each chunk's window table (pc_hip_srs_precompute). */
+int pc_hip_group_srs_upload(pc_group* g, pc_curve curve, const void* bases_host, size_t n, size_t stride_bytes,
+                            int precompute, pc_group_srs** out);
+void pc_hip_group_srs_free(pc_group_srs* srs);
+size_t pc_hip_group_srs_len(const pc_group_srs* srs);
+/* msm_bigint over the sharded key (kzg10/mod.rs:175-178; KZG10::commit): scalars on the host. */
+int pc_hip_group_msm(pc_group* g, const pc_group_srs* srs, size_t base_offset, const void* scalars_host,
+                     pc_scalar_form form, size_t n, void* out_xy, int* out_is_infinity);
+/* MarlinKZG10::commit's loop over k polynomials (marlin_pc/mod.rs:192-237; BASELINE configs[2]: 64 polynomials, SRS
+ * sharded): out_xy holds k points. */
+int pc_hip_group_msm_batch(pc_group* g, const pc_group_srs* srs, const void* const* scalars_host, const size_t* n,
+                           size_t k, pc_scalar_form form, void* out_xy, int* out_is_infinity);
+/* KZG10::open, hiding off (kzg10/mod.rs:287-310): witness polynomial + its MSM over the sharded key.  coeffs: n Fr
+ * (Montgomery, host), z: one Fr.  Per device one evaluation of its shard, the division carries composed on the
+ * host (N field elements), one division scan, one MSM.  out_value_host (optional): p(z). */
+int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* srs, const void* coeffs_host, size_t n, const void* z_host,
+                          void* out_proof_xy, int* out_is_infinity, void* out_value_host);
+/* pc_hip_ntt_batch with the rows split over the devices (rows are independent: linear_codes/mod.rs:131-135). */
+int pc_hip_group_ntt_batch(pc_group* g, pc_curve field_of, const void* in_host, size_t rows, size_t in_cols,
+                           unsigned log_n, void* out_host);
+
 #ifdef __cplusplus
 }
 #endif

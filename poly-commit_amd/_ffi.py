@@ -93,6 +93,21 @@ def load_library():
     lib.pc_hip_poly_div_scan.argtypes = [vp, ip, vp, ip, sz, vp, vp, vp, ip]
     lib.pc_hip_points_sum.argtypes = [ip, vp, sz, vp]
     lib.pc_hip_point_mul.argtypes = [ip, vp, vp, vp]
+    lib.pc_hip_group_create.argtypes = [C.POINTER(ip), ip, C.POINTER(vp)]
+    lib.pc_hip_group_destroy.argtypes = [vp]
+    lib.pc_hip_group_destroy.restype = None
+    lib.pc_hip_group_size.argtypes = [vp]
+    lib.pc_hip_group_ctx.argtypes = [vp, ip]
+    lib.pc_hip_group_ctx.restype = vp
+    lib.pc_hip_group_srs_upload.argtypes = [vp, ip, vp, sz, sz, ip, C.POINTER(vp)]
+    lib.pc_hip_group_srs_free.argtypes = [vp]
+    lib.pc_hip_group_srs_free.restype = None
+    lib.pc_hip_group_srs_len.argtypes = [vp]
+    lib.pc_hip_group_srs_len.restype = sz
+    lib.pc_hip_group_msm.argtypes = [vp, vp, sz, vp, ip, sz, vp, C.POINTER(ip)]
+    lib.pc_hip_group_msm_batch.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(sz), sz, ip, vp, C.POINTER(ip)]
+    lib.pc_hip_group_kzg_open.argtypes = [vp, vp, vp, sz, vp, vp, C.POINTER(ip), vp]
+    lib.pc_hip_group_ntt_batch.argtypes = [vp, ip, vp, sz, sz, C.c_uint, vp]
     _lib = lib
     return lib
 
@@ -429,3 +444,78 @@ def point_mul(curve, point_xy, scalar_mont):
     if rc != 0:
         raise PcHipError(rc, lib.pc_hip_strerror(rc).decode())
     return out
+
+
+class Group:
+    """N single-device contexts driven from one process (pc_hip_group_*): one committer key sharded in contiguous
+    chunks.  device_ids may repeat a device (tests on a one-GPU box)."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self.lib.pc_hip_group_create(ids, len(device_ids), C.byref(h))
+        if rc != 0:
+            raise PcHipError(rc, self.lib.pc_hip_strerror(rc).decode())
+        self.h, self.n_dev = h, len(device_ids)
+
+    def check(self, rc):
+        if rc != 0:
+            raise PcHipError(rc, self.lib.pc_hip_strerror(rc).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.pc_hip_group_destroy(self.h)
+            self.h = None
+
+    def upload_srs(self, curve, bases, precompute=False):
+        return GroupSrs(self, curve, bases, precompute)
+
+    def ntt_batch(self, curve, mat, log_n):
+        mat = np.ascontiguousarray(mat, dtype=np.uint64)
+        out = np.zeros((mat.shape[0], 1 << log_n, 4), dtype=np.uint64)
+        self.check(self.lib.pc_hip_group_ntt_batch(self.h, CURVES[curve], mat.ctypes.data, mat.shape[0], mat.shape[1], log_n, out.ctypes.data))
+        return out
+
+
+class GroupSrs:
+    def __init__(self, group, curve, bases, precompute=False):
+        self.g, self.curve = group, curve
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        h = C.c_void_p()
+        group.check(group.lib.pc_hip_group_srs_upload(group.h, CURVES[curve], bases.ctypes.data, bases.shape[0], 0, 1 if precompute else 0, C.byref(h)))
+        self.h, self.n = h, bases.shape[0]
+
+    def free(self):
+        if self.h:
+            self.g.lib.pc_hip_group_srs_free(self.h)
+            self.h = None
+
+    def msm(self, scalars, base_offset=0, montgomery=False):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(2 * FQ_BYTES[self.curve] // 8, dtype=np.uint64)
+        inf = C.c_int(0)
+        self.g.check(self.g.lib.pc_hip_group_msm(self.g.h, self.h, base_offset, scalars.ctypes.data,
+                                                 PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL, scalars.shape[0],
+                                                 out.ctypes.data, C.byref(inf)))
+        return out, bool(inf.value)
+
+    def msm_batch(self, polys, montgomery=True):
+        polys = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+        k = len(polys)
+        ptrs = (C.c_void_p * k)(*[p.ctypes.data for p in polys])
+        ns = (C.c_size_t * k)(*[p.shape[0] for p in polys])
+        out = np.zeros((k, 2 * FQ_BYTES[self.curve] // 8), dtype=np.uint64)
+        self.g.check(self.g.lib.pc_hip_group_msm_batch(self.g.h, self.h, ptrs, ns, k, PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
+                                                       out.ctypes.data, None))
+        return out
+
+    def kzg_open(self, coeffs_mont, z_mont):
+        coeffs_mont = np.ascontiguousarray(coeffs_mont, dtype=np.uint64)
+        z_mont = np.ascontiguousarray(z_mont, dtype=np.uint64)
+        out = np.zeros(2 * FQ_BYTES[self.curve] // 8, dtype=np.uint64)
+        val = np.zeros(4, dtype=np.uint64)
+        inf = C.c_int(0)
+        self.g.check(self.g.lib.pc_hip_group_kzg_open(self.g.h, self.h, coeffs_mont.ctypes.data, coeffs_mont.shape[0], z_mont.ctypes.data,
+                                                      out.ctypes.data, C.byref(inf), val.ctypes.data))
+        return out, val

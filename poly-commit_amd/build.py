@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["abi.hip", "hash_tu.hip",
+SOURCES = ["abi.hip", "group.hip", "hash_tu.hip",
            "curve_bls12_381.hip", "curve_bn254.hip", "curve_pallas.hip",
            "field_bls12_381.hip", "field_bn254.hip", "field_pallas.hip"]
 OBJ = os.path.join(CSRC, "_obj")

@@ -1,0 +1,254 @@
+// Multi-GPU entry points of the C ABI (include/pc_hip.h, "pc_hip_group_*"): one committer key sharded over the
+// GPUs of a node in contiguous chunks, driven from ONE process -- what a Rust prover holding a
+// single CommitterKey needs.  A group is N single-device contexts; every call fans out to one host thread per
+// device, each of which runs the complete single-device path on its chunk (full Pippenger -> ONE affine point),
+// and the N partial points are added on the host (pc_hip_points_sum): the exchange is N * 96 bytes, so no
+// device-to-device collective is involved -- partial BUCKET arrays are never moved (75 MB per GPU at 2^20).
+// The one-process-per-GPU form of the same protocol (torch.distributed / RCCL all_gather of the partial
+// points) is poly-commit_amd/sharded.py, which bench.py --gpus N uses.
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+#include <string.h>
+#include "../../include/pc_hip.h"
+#include "host_tail.hpp"
+
+struct pc_group {
+  std::vector<pc_ctx*> ctx;
+  std::string last_error;
+};
+
+struct pc_group_srs {
+  pc_group* g = nullptr;
+  pc_curve curve = PC_CURVE_BLS12_381;
+  size_t n = 0, per = 0, pb = 0;          // points, points per chunk, bytes per packed point
+  std::vector<pc_srs*> chunk;             // chunk d holds bases [lo(d) - halo(d), hi(d)),  halo(d) = d > 0
+  size_t lo(size_t d) const { return std::min(n, d * per); }
+  size_t hi(size_t d) const { return std::min(n, (d + 1) * per); }
+  size_t halo(size_t d) const { return d > 0 && lo(d) < n ? 1 : 0; }
+};
+
+namespace {
+
+size_t fq_bytes(pc_curve c) { return c == PC_CURVE_BLS12_381 ? 48 : 32; }
+
+// run fn(d) for every device on its own host thread; returns the first non-OK status
+template <class Fn>
+int fan_out(size_t n_dev, Fn fn) {
+  std::vector<int> rc(n_dev, PC_OK);
+  std::vector<std::thread> th;
+  for (size_t d = 1; d < n_dev; d++) th.emplace_back([&, d]() { rc[d] = fn(d); });
+  rc[0] = fn(0);
+  for (auto& t : th) t.join();
+  for (int r : rc) if (r != PC_OK) return r;
+  return PC_OK;
+}
+
+// Fr arithmetic for the division carries (a handful of elements per call)
+template <class FrP>
+struct FrHost {
+  typedef pc::host64::F64<FrP> F;
+  static F load(const void* p) { F f; memcpy(f.l, p, 32); return f; }
+  // carry into shard d = value of the shards above it: c_d = sum_{s > d} B_s z^((s - d - 1) per'), composed top down
+  static void carries(const std::vector<F>& B, const std::vector<size_t>& len, const F& z, std::vector<F>& carry) {
+    const size_t N = B.size();
+    carry.assign(N, F::zero());
+    F acc = F::zero();
+    for (size_t d = N; d-- > 0;) {
+      carry[d] = acc;
+      // acc = B_d + z^len_d * acc
+      F zp = F::one(), base = z;
+      for (size_t e = len[d]; e; e >>= 1) { if (e & 1) zp = zp.mul(base); base = base.mul(base); }
+      acc = B[d].add(zp.mul(acc));
+    }
+  }
+};
+
+template <class FrP>
+int open_carries(const std::vector<std::vector<uint64_t>>& evals, const std::vector<size_t>& len, const void* z_host,
+                 std::vector<std::vector<uint64_t>>& carry, uint64_t* value_out) {
+  typedef FrHost<FrP> H; typedef typename H::F F;
+  std::vector<F> B; for (auto& e : evals) B.push_back(H::load(e.data()));
+  std::vector<F> c;
+  H::carries(B, len, H::load(z_host), c);
+  carry.resize(B.size());
+  for (size_t d = 0; d < B.size(); d++) { carry[d].assign(4, 0); memcpy(carry[d].data(), c[d].l, 32); }
+  if (value_out) {   // p(z) = B_0 + z^len_0 * c_0
+    F zp = F::one(), base = H::load(z_host);
+    for (size_t e = len[0]; e; e >>= 1) { if (e & 1) zp = zp.mul(base); base = base.mul(base); }
+    F v = B[0].add(zp.mul(c[0]));
+    memcpy(value_out, v.l, 32);
+  }
+  return PC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_hip_group_create(const int* device_ids, int n_devices, pc_group** out) {
+  if (!out || !device_ids || n_devices <= 0) return PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  pc_group* g = new (std::nothrow) pc_group();
+  if (!g) return PC_ERR_OOM;
+  for (int i = 0; i < n_devices; i++) {
+    pc_ctx* c = nullptr;
+    int rc = pc_hip_init(device_ids[i], &c);
+    if (rc != PC_OK) { pc_hip_group_destroy(g); return rc; }
+    g->ctx.push_back(c);
+  }
+  *out = g;
+  return PC_OK;
+}
+
+void pc_hip_group_destroy(pc_group* g) {
+  if (!g) return;
+  for (pc_ctx* c : g->ctx) pc_hip_shutdown(c);
+  delete g;
+}
+
+int pc_hip_group_size(const pc_group* g) { return g ? (int)g->ctx.size() : 0; }
+pc_ctx* pc_hip_group_ctx(pc_group* g, int i) { return (g && i >= 0 && (size_t)i < g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+int pc_hip_group_srs_upload(pc_group* g, pc_curve curve, const void* bases_host, size_t n, size_t stride_bytes, int precompute,
+                            pc_group_srs** out) {
+  if (!g || !out || (!bases_host && n) || (int)curve < 0 || (int)curve > 2) return PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  const size_t pb = 2 * fq_bytes(curve);
+  if (stride_bytes == 0) stride_bytes = pb;
+  if (stride_bytes < pb) return PC_ERR_INVALID_ARG;
+  pc_group_srs* s = new (std::nothrow) pc_group_srs();
+  if (!s) return PC_ERR_OOM;
+  const size_t N = g->ctx.size();
+  s->g = g; s->curve = curve; s->n = n; s->pb = pb; s->per = (n + N - 1) / N; if (!s->per) s->per = 1;
+  s->chunk.assign(N, nullptr);
+  int rc = fan_out(N, [&](size_t d) {
+    const size_t lo = s->lo(d) - s->halo(d), hi = s->hi(d);
+    int r = pc_hip_srs_upload(g->ctx[d], curve, (const char*)bases_host + lo * stride_bytes, hi - lo, stride_bytes, PC_MEM_HOST, &s->chunk[d]);
+    if (r == PC_OK && precompute && hi > lo) r = pc_hip_srs_precompute(g->ctx[d], s->chunk[d], 0, 0);
+    return r;
+  });
+  if (rc != PC_OK) { pc_hip_group_srs_free(s); return rc; }
+  *out = s;
+  return PC_OK;
+}
+
+void pc_hip_group_srs_free(pc_group_srs* s) {
+  if (!s) return;
+  for (pc_srs* c : s->chunk) pc_hip_srs_free(c);
+  delete s;
+}
+
+size_t pc_hip_group_srs_len(const pc_group_srs* s) { return s ? s->n : 0; }
+
+// out = sum_{i < n} scalars[i] * bases[base_offset + i]
+int pc_hip_group_msm(pc_group* g, const pc_group_srs* s, size_t base_offset, const void* scalars_host, pc_scalar_form form, size_t n,
+                     void* out_xy, int* out_is_infinity) {
+  if (!g || !s || s->g != g || !out_xy || base_offset > s->n || (n && !scalars_host)) return PC_ERR_INVALID_ARG;
+  if (n > s->n - base_offset) n = s->n - base_offset;                 // msm_bigint: min(bases.len(), scalars.len())
+  const size_t N = g->ctx.size();
+  std::vector<uint8_t> parts(N * s->pb, 0);
+  int rc = fan_out(N, [&](size_t d) {
+    const size_t a = std::max(base_offset, s->lo(d)), b = std::min(base_offset + n, s->hi(d));
+    if (a >= b) return (int)PC_OK;                                     // partial = infinity (zeros)
+    return pc_hip_msm(g->ctx[d], s->chunk[d], a - s->lo(d) + s->halo(d), (const char*)scalars_host + (a - base_offset) * 32, form,
+                      PC_MEM_HOST, b - a, parts.data() + d * s->pb, nullptr);
+  });
+  if (rc != PC_OK) return rc;
+  rc = pc_hip_points_sum(s->curve, parts.data(), N, out_xy);
+  if (rc == PC_OK && out_is_infinity) { uint8_t acc = 0; for (size_t i = 0; i < s->pb; i++) acc |= ((const uint8_t*)out_xy)[i]; *out_is_infinity = acc == 0; }
+  return rc;
+}
+
+// MarlinKZG10::commit's loop over polynomials (marlin_pc/mod.rs:192-237) against the sharded key: every device runs the k
+// partial MSMs of its chunk as one pipelined batch; k * N partial points are folded on the host.
+int pc_hip_group_msm_batch(pc_group* g, const pc_group_srs* s, const void* const* scalars_host, const size_t* n, size_t k,
+                           pc_scalar_form form, void* out_xy, int* out_is_infinity) {
+  if (!g || !s || s->g != g || !out_xy || (k && (!scalars_host || !n))) return PC_ERR_INVALID_ARG;
+  const size_t N = g->ctx.size();
+  std::vector<uint8_t> parts(N * k * s->pb, 0);
+  int rc = fan_out(N, [&](size_t d) {
+    std::vector<const void*> ptr(k); std::vector<size_t> len(k), off(k);
+    for (size_t j = 0; j < k; j++) {
+      const size_t nj = std::min(n[j], s->n), a = std::min(nj, s->lo(d)), b = std::min(nj, s->hi(d));
+      ptr[j] = (const char*)scalars_host[j] + a * 32; len[j] = b - a; off[j] = s->halo(d);
+    }
+    return pc_hip_msm_batch(g->ctx[d], s->chunk[d], off.data(), ptr.data(), len.data(), k, form, PC_MEM_HOST, parts.data() + d * k * s->pb, nullptr);
+  });
+  if (rc != PC_OK) return rc;
+  std::vector<uint8_t> col(N * s->pb);
+  for (size_t j = 0; j < k && rc == PC_OK; j++) {
+    for (size_t d = 0; d < N; d++) memcpy(&col[d * s->pb], &parts[(d * k + j) * s->pb], s->pb);
+    uint8_t* o = (uint8_t*)out_xy + j * s->pb;
+    rc = pc_hip_points_sum(s->curve, col.data(), N, o);
+    if (out_is_infinity) { uint8_t acc = 0; for (size_t i = 0; i < s->pb; i++) acc |= o[i]; out_is_infinity[j] = acc == 0; }
+  }
+  return rc;
+}
+
+// KZG10::open (kzg10/mod.rs:287-310) of one polynomial of n coefficients against the sharded key, hiding off:
+// witness polynomial p / (x - z) (:217-240) as one division scan per device with the carry of the shards above it
+// (composed on the host from one evaluation per shard), then the MSM of the quotient chunk (:255-258).
+// out_value_host (optional): p(z).
+int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* s, const void* coeffs_host, size_t n, const void* z_host, void* out_proof_xy,
+                          int* out_is_infinity, void* out_value_host) {
+  if (!g || !s || s->g != g || !out_proof_xy || !z_host || (n && !coeffs_host) || n > s->n) return PC_ERR_INVALID_ARG;
+  const size_t N = g->ctx.size();
+  std::vector<void*> cdev(N, nullptr), qdev(N, nullptr);
+  std::vector<size_t> len(N, 0);
+  std::vector<std::vector<uint64_t>> evals(N, std::vector<uint64_t>(4, 0)), carry;
+  for (size_t d = 0; d < N; d++) len[d] = std::min(n, s->hi(d)) - std::min(n, s->lo(d));
+  auto cleanup = [&]() { for (size_t d = 0; d < N; d++) { pc_hip_free(g->ctx[d], cdev[d]); pc_hip_free(g->ctx[d], qdev[d]); } };
+  // 1. shards to the devices, one evaluation each
+  int rc = fan_out(N, [&](size_t d) {
+    if (!len[d]) return (int)PC_OK;
+    int r = pc_hip_malloc(g->ctx[d], len[d] * 32, &cdev[d]);
+    if (r == PC_OK) r = pc_hip_malloc(g->ctx[d], len[d] * 32, &qdev[d]);
+    if (r == PC_OK) r = pc_hip_memcpy_h2d(g->ctx[d], cdev[d], (const char*)coeffs_host + std::min(n, s->lo(d)) * 32, len[d] * 32);
+    if (r == PC_OK) r = pc_hip_poly_eval(g->ctx[d], s->curve, cdev[d], PC_MEM_DEVICE, len[d], z_host, evals[d].data());
+    return r;
+  });
+  // 2. carries (host: N field elements)
+  if (rc == PC_OK) {
+    switch (s->curve) {
+      case PC_CURVE_BLS12_381: rc = open_carries<pc_bls12_381_fr>(evals, len, z_host, carry, (uint64_t*)out_value_host); break;
+      case PC_CURVE_BN254: rc = open_carries<pc_bn254_fr>(evals, len, z_host, carry, (uint64_t*)out_value_host); break;
+      default: rc = open_carries<pc_pallas_fr>(evals, len, z_host, carry, (uint64_t*)out_value_host); break;
+    }
+  }
+  // 3. division with the carry, MSM of the quotient chunk: out[j] (coefficient j of this shard) pairs with power j - 1
+  std::vector<uint8_t> parts(N * s->pb, 0);
+  if (rc == PC_OK) rc = fan_out(N, [&](size_t d) {
+    if (!len[d]) return (int)PC_OK;
+    bool nz = false; for (uint64_t w : carry[d]) nz |= w != 0;
+    int r = pc_hip_poly_div_scan(g->ctx[d], s->curve, cdev[d], PC_MEM_DEVICE, len[d], z_host, nz ? carry[d].data() : nullptr, qdev[d], PC_MEM_DEVICE);
+    if (r != PC_OK) return r;
+    if (d == 0) {                     // q[i - 1] = out[i], i >= 1: skips out[0] = p(z), powers from 0
+      if (len[0] < 2) return (int)PC_OK;
+      return pc_hip_msm(g->ctx[0], s->chunk[0], 0, (const char*)qdev[0] + 32, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, len[0] - 1, parts.data(), nullptr);
+    }
+    return pc_hip_msm(g->ctx[d], s->chunk[d], 0, qdev[d], PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, len[d], parts.data() + d * s->pb, nullptr);   // halo base first
+  });
+  cleanup();
+  if (rc != PC_OK) return rc;
+  rc = pc_hip_points_sum(s->curve, parts.data(), N, out_proof_xy);
+  if (rc == PC_OK && out_is_infinity) { uint8_t acc = 0; for (size_t i = 0; i < s->pb; i++) acc |= ((const uint8_t*)out_proof_xy)[i]; *out_is_infinity = acc == 0; }
+  return rc;
+}
+
+// LinearEncode::compute_matrices' rows (linear_codes/mod.rs:131-135) are independent: rows split over the devices,
+// no exchange at all.
+int pc_hip_group_ntt_batch(pc_group* g, pc_curve field_of, const void* in_host, size_t rows, size_t in_cols, unsigned log_n, void* out_host) {
+  if (!g || (rows && (!in_host || !out_host))) return PC_ERR_INVALID_ARG;
+  const size_t N = g->ctx.size(), per = (rows + N - 1) / N;
+  const size_t out_cols = (size_t)1 << log_n;
+  return fan_out(N, [&](size_t d) {
+    const size_t a = std::min(rows, d * per), b = std::min(rows, (d + 1) * per);
+    if (a >= b) return (int)PC_OK;
+    return pc_hip_ntt_batch(g->ctx[d], field_of, (const char*)in_host + a * in_cols * 32, PC_MEM_HOST, b - a, in_cols, log_n,
+                            (char*)out_host + a * out_cols * 32, PC_MEM_HOST);
+  });
+}
+
+}  // extern "C"

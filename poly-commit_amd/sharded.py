@@ -101,6 +101,14 @@ class HipEngine:
     def points_sum(self, pts):
         return _ffi.points_sum(self.curve, pts)
 
+    def msm_batch(self, polys, lens):
+        """k device-resident scalar vectors against this rank's chunk (pc_hip_msm_batch) -> (k, 2*Fq) points."""
+        return self.srs.msm_batch([self._ptr(p) for p in polys], list(lens))
+
+    def ntt_rows(self, rows_buf, n_rows, in_cols, log_n, out_buf):
+        self.ctx.ntt_batch(self.curve, self._ptr(rows_buf), log_n, out=self._ptr(out_buf), rows=n_rows, in_cols=in_cols)
+        return out_buf
+
 
 class ShardedKzg:
     def __init__(self, engine, curve, rank=0, world=1, dist=None):
@@ -156,25 +164,77 @@ class ShardedKzg:
     def open(self, coeffs, n):
         return self.open_async(coeffs, n).result()
 
-    def open_async(self, coeffs, n):
+    def open_prepare(self, coeffs, n):
+        """The exchange step of a sharded open, separated from the enqueue so that a caller can run it while
+        earlier MSMs are still in flight (bench.py does: evaluation + all_gather of step k overlap the open
+        MSM of step k-1): carry into shard r = composition of the shards above it, c = B_s + z^n * c with
+        B_s = p_s(z) (an evaluation-only up-sweep; the full division then runs once, with the carry)."""
         if self.world == 1:
-            out = self.e.div_scan(coeffs, n, self.z, None)
-        else:
-            # carry into shard r = composition of the shards above it: c = B_s + z^n * c, with B_s = p_s(z)
-            # (an evaluation-only up-sweep; the full division then runs once, with the carry)
-            b = self._all_gather(self.e.poly_eval(coeffs, n, self.z))
-            z = _limbs_to_int(self.z) * pow(_R, -1, self.p) % self.p
-            zn_mont = pow(z, n, self.p) * _R % self.p          # Montgomery form of z^n
-            rinv = pow(_R, -1, self.p)
-            carry = 0
-            for s in range(self.world - 1, self.rank, -1):
-                carry = (_limbs_to_int(b[s]) + zn_mont * carry * rinv) % self.p   # Montgomery arithmetic
-            out = self.e.div_scan(coeffs, n, self.z, _int_to_limbs(carry) if carry else None)
+            return None
+        b = self._all_gather(self.e.poly_eval(coeffs, n, self.z))
+        z = _limbs_to_int(self.z) * pow(_R, -1, self.p) % self.p
+        zn_mont = pow(z, n, self.p) * _R % self.p          # Montgomery form of z^n
+        rinv = pow(_R, -1, self.p)
+        carry = 0
+        for s in range(self.world - 1, self.rank, -1):
+            carry = (_limbs_to_int(b[s]) + zn_mont * carry * rinv) % self.p   # Montgomery arithmetic
+        return _int_to_limbs(carry) if carry else None
+
+    def open_async(self, coeffs, n, prepared=False, carry=None):
+        if not prepared:
+            carry = self.open_prepare(coeffs, n)
+        out = self.e.div_scan(coeffs, n, self.z, carry)
         if self.rank == 0:
             pend = self._msm_async(out, n - 1, base_offset=1, elem_off=1)    # q[i-1] = out[i] pairs with power i-1
         else:
             pend = self._msm_async(out, n, base_offset=0)                    # out[j] pairs with power r*n + j - 1
         return _Future(self, pend)
+
+
+class ShardedBatch:
+    """BASELINE configs[2]: k polynomials committed against ONE SRS that is split into `world` contiguous chunks.
+    Every rank runs the k partial MSMs of its chunk as one pipelined batch; the k partial points per rank are
+    combined with one all_gather (k x 64..96 B per rank) + EC adds.  (MarlinKZG10::commit's loop,
+    marlin_pc/mod.rs:192-237; RCCL has no EC reduce op and raw bucket arrays are never exchanged.)"""
+
+    def __init__(self, engine, curve, rank=0, world=1, dist=None):
+        self.e, self.curve, self.rank, self.world, self.dist = engine, curve, rank, world, dist
+
+    @staticmethod
+    def chunk_range(total, rank, world):
+        per = (total + world - 1) // world
+        return min(total, rank * per), min(total, (rank + 1) * per)
+
+    def load_srs_chunk(self, bases, **kw):
+        self.e.load_srs(bases, **kw)
+
+    def commit_batch(self, polys, lens):
+        """polys: this rank's slices of the k coefficient vectors (engine buffers); returns (k, 2*Fq) points."""
+        part = self.e.msm_batch(polys, lens)
+        if self.dist is None or self.world == 1:
+            return part
+        import torch
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.from_numpy(part.reshape(-1).view(np.int64).copy()).to(dev)
+        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(out, t)
+        allp = out.cpu().numpy().view(np.uint64).reshape(self.world, len(polys), -1)
+        return np.stack([self.e.points_sum(np.ascontiguousarray(allp[:, j])) for j in range(len(polys))])
+
+
+class ShardedRows:
+    """BASELINE configs[4]: the rows of Ligero's coefficient matrix are independent (linear_codes/mod.rs:131-135):
+    rank r encodes rows [r * per, (r+1) * per); no collective on the data path."""
+
+    def __init__(self, engine, rank=0, world=1):
+        self.e, self.rank, self.world = engine, rank, world
+
+    def row_range(self, n_rows):
+        per = (n_rows + self.world - 1) // self.world
+        return min(n_rows, self.rank * per), min(n_rows, (self.rank + 1) * per)
+
+    def encode(self, rows_buf, n_rows_local, in_cols, log_n, out_buf=None):
+        return self.e.ntt_rows(rows_buf, n_rows_local, in_cols, log_n, out_buf)
 
 
 class _Future:

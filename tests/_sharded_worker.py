@@ -52,6 +52,12 @@ class OracleEngine:
     def points_sum(self, pts):
         return pc.points_sum(self.curve, pts)
 
+    def msm_batch(self, polys, lens):
+        return np.stack([self.msm(q, m, 0) for q, m in zip(polys, lens)])
+
+    def ntt_rows(self, rows_buf, n_rows, in_cols, log_n, out_buf):
+        return O.ntt_batch(self.curve, np.ascontiguousarray(rows_buf[:n_rows]), log_n, threads=1)
+
 
 def main():
     dist.init_process_group("gloo")
@@ -88,6 +94,47 @@ def main():
         rc1, want_c = O.kzg_commit(curve, powers, coeffs, 2)
         rc2, want_w = O.kzg_open(curve, powers, coeffs, z, 2)
         ok &= rc1 == 0 and rc2 == 0 and bool((comm == want_c).all()) and bool((proof == want_w).all())
+    # BASELINE configs[2] shape: k polynomials against one SRS in `world` contiguous chunks (bench.py --workload batch)
+    # and configs[4] shape: matrix rows split over the ranks, no collective (bench.py --workload ntt)
+    for curve in ("bn254",):
+        total, k = (700 if use_hip else 101), 5            # deliberately not a multiple of the world size
+        powers = O.gen_bases(curve, total)
+        polys = [O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xBA7C0 + j, total)) for j in range(k)]
+        lo, hi = sharded.ShardedBatch.chunk_range(total, rank, world)
+        eng = sharded.HipEngine(ctx, curve) if use_hip else OracleEngine(curve)
+        job = sharded.ShardedBatch(eng, curve, rank, world, dist)
+        job.load_srs_chunk(np.ascontiguousarray(powers[lo:hi]))
+        mine = [np.ascontiguousarray(q[lo:hi]) for q in polys]
+        if use_hip:
+            import torch
+            mine = [torch.from_numpy(q.view(np.int64)).cuda() for q in mine]
+        got = job.commit_batch(mine, [hi - lo] * k)
+        for j in range(k):
+            rc, want = O.kzg_commit(curve, powers, polys[j], 2)
+            ok &= rc == 0 and bool((got[j] == want).all())
+        n_rows, n_cols, log_n = 7, 16, 6
+        mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x2075, n_rows * n_cols)).reshape(n_rows, n_cols, 4)
+        rows = sharded.ShardedRows(eng, rank, world)
+        r_lo, r_hi = rows.row_range(n_rows)
+        want = O.ntt_batch(curve, mat, log_n, threads=1)
+        if r_hi > r_lo:
+            local = np.ascontiguousarray(mat[r_lo:r_hi])
+            if use_hip:
+                import torch
+                x = torch.from_numpy(local.view(np.int64)).cuda()
+                y = torch.empty(((r_hi - r_lo) << log_n, 4), dtype=torch.int64, device="cuda")
+                rows.encode(x, r_hi - r_lo, n_cols, log_n, y)
+                out = y.cpu().numpy().view(np.uint64).reshape(r_hi - r_lo, 1 << log_n, 4)
+            else:
+                out = rows.encode(local, r_hi - r_lo, n_cols, log_n)
+            ok &= bool((out == want[r_lo:r_hi]).all())
+        # every row is owned exactly once
+        owned = np.zeros(n_rows, dtype=np.int64)
+        owned[r_lo:r_hi] = 1
+        import torch
+        t = torch.from_numpy(owned)
+        dist.all_reduce(t)
+        ok &= bool((t.numpy() == 1).all())
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: {'OK' if ok else 'MISMATCH'}")

@@ -50,6 +50,12 @@ def test_no_gpu_means_error_not_fallback():
         pc.Context(0)
     assert lib.pc_hip_strerror(-4) == b"no HIP device"
     assert lib.pc_hip_strerror(0) == b"ok"
+    # the multi-GPU group is N single-device contexts: same answer
+    ids = (C.c_int * 2)(0, 1)
+    g = C.c_void_p()
+    assert lib.pc_hip_group_create(ids, 2, C.byref(g)) == -4 and not g.value
+    with pytest.raises(pc.PcHipError):
+        pc.Group([0, 0])
 
 
 def test_argument_validation_needs_no_device():

@@ -1,0 +1,58 @@
+"""Multi-GPU entry points of the C ABI (pc_hip_group_*): one committer key sharded over N contexts driven from one
+process.  On a one-GPU box the group lists device 0 several times -- the chunking, the halo base, the division
+carries and the fold of the partial points are exactly what N devices would run.  Results must be bit-identical to
+the oracle (and hence to the single-device path)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve,n,ndev,table", [("bls12_381", 5000, 3, False), ("bn254", 4097, 2, True), ("pallas", 1 << 12, 4, False),
+                                                ("bn254", 5, 3, False)])
+def test_group_commit_open_matches_oracle(curve, n, ndev, table):
+    import poly_commit_amd as pc
+    g = pc.Group([0] * ndev)
+    powers = O.gen_bases(curve, n)
+    srs = g.upload_srs(curve, powers, precompute=table)
+    coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x6A0 + n, n))
+    z = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x6B0, 1))[0]
+    comm, _ = srs.msm(coeffs, montgomery=True)
+    rc, want_c = O.kzg_commit(curve, powers, coeffs)
+    assert rc == 0 and (comm == want_c).all()
+    proof, value = srs.kzg_open(coeffs, z)
+    rc, want_w = O.kzg_open(curve, powers, coeffs, z)
+    assert rc == 0 and (proof == want_w).all()
+    assert (value == O.poly_eval(curve, coeffs, z)).all()
+    # a slice that starts inside chunk 1 and ends inside the last chunk; a polynomial shorter than the key
+    off, m = n // ndev + 1, n - n // ndev - 2
+    if m > 0:
+        s = O.gen_scalars(curve, 0x6C0, m)
+        got, _ = srs.msm(s, base_offset=off)
+        assert (got == O.msm_pippenger(curve, np.ascontiguousarray(powers[off:off + m]), s, 8, 1)).all()
+    short = np.ascontiguousarray(coeffs[: max(2, n // 2 - 1)])
+    proof, value = srs.kzg_open(short, z)
+    rc, want_w = O.kzg_open(curve, powers, short, z)
+    assert rc == 0 and (proof == want_w).all() and (value == O.poly_eval(curve, short, z)).all()
+    srs.free()
+    g.close()
+
+
+def test_group_batch_and_ntt_rows():
+    """configs[2] shape (k polynomials against one sharded SRS) and configs[4] shape (rows split over devices)."""
+    import poly_commit_amd as pc
+    curve, n, k = "bn254", 3000, 5
+    g = pc.Group([0, 0, 0])
+    powers = O.gen_bases(curve, n)
+    srs = g.upload_srs(curve, powers)
+    polys = [O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x700 + j, n - 7 * j)) for j in range(k)]
+    got = srs.msm_batch(polys)
+    for j in range(k):
+        rc, want = O.kzg_commit(curve, powers, polys[j])
+        assert rc == 0 and (got[j] == want).all(), j
+    srs.free()
+    mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x710, 7 * 64)).reshape(7, 64, 4)
+    assert (g.ntt_batch(curve, mat, 8) == O.ntt_batch(curve, mat, 8)).all()
+    g.close()
