@@ -180,6 +180,55 @@ struct Fd {
     return r;
   }
   __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
+
+  // Dedicated squaring: a^2 = sum_i a_i^2 2^(64 i) + sum_{i<j} a_i (2 a_j) 2^(32 (i+j)).  The doubled cross terms are
+  // taken from d = a << 1 (it fits N limbs: every modulus here leaves a spare top bit): row i multiplies a_i by the limbs of
+  // ((a >> 32 (i+1)) << 1), i.e. d_j for j >= i+2 and d_{i+1} without the bit that a_i shifted in.  N (N-1)/2 + N partial
+  // products instead of N^2 (78 vs 144 at 12 limbs), the same interleaved reduction, no doubling pass over the columns.
+  template <int K>
+  __device__ __forceinline__ void sq_column_lo(const uint32_t* d, const uint32_t* dm, uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi) const {
+    constexpr int NCROSS = (K + 1) / 2;                      // i < j, i + j = K, i = 0 .. NCROSS-1
+    constexpr int CNT = NCROSS + ((K & 1) ? 0 : 1) + nz_mod(1, K);
+    uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
+    int c = 0;
+    PC_UNROLL for (int i = 0; i < NCROSS; i++) { x[c] = l[i]; y[c] = (K - i == i + 1) ? dm[K - i] : d[K - i]; c++; }
+    if constexpr ((K & 1) == 0) { x[c] = l[K / 2]; y[c] = l[K / 2]; c++; }
+    PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
+    mac_n<CNT, true>(acc, hi, x, y);
+    m[K] = (uint32_t)acc * P::INV;
+    mac1(acc, hi, &m[K], &mod[0]);
+    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    if constexpr (K + 1 < N) sq_column_lo<K + 1>(d, dm, m, mod, acc, hi);
+  }
+  template <int K>
+  __device__ __forceinline__ void sq_column_hi(const uint32_t* d, const uint32_t* dm, const uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi,
+                                               uint32_t* t) const {
+    constexpr int I0 = K - N + 1;                            // i = I0 .. N-1 with j = K - i; cross terms: i < j  <=>  2 i < K
+    constexpr int NCROSS = (K + 1) / 2 - I0 > 0 ? (K + 1) / 2 - I0 : 0;
+    constexpr int DIAG = ((K & 1) == 0 && K / 2 < N) ? 1 : 0;
+    constexpr int CNT = NCROSS + DIAG + nz_mod(I0, N - 1);
+    uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
+    int c = 0;
+    PC_UNROLL for (int i = I0; i < I0 + NCROSS; i++) { x[c] = l[i]; y[c] = (K - i == i + 1) ? dm[K - i] : d[K - i]; c++; }
+    if constexpr (DIAG) { x[c] = l[K / 2]; y[c] = l[K / 2]; c++; }
+    PC_UNROLL for (int i = I0; i < N; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
+    mac_n<CNT, true>(acc, hi, x, y);
+    t[K - N] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    if constexpr (K + 1 < 2 * N) sq_column_hi<K + 1>(d, dm, m, mod, acc, hi, t);
+  }
+  __device__ __forceinline__ Fd sqr() const {
+    static_assert(P::BITS < 32 * N, "squaring assumes that 2a fits N limbs");
+    uint32_t d[N], dm[N], m[N], t[N + 1], mod[N];
+    PC_UNROLL for (int i = 0; i < N; i++) { mod[i] = P::MOD[i]; d[i] = (l[i] << 1) | (i ? l[i - 1] >> 31 : 0u); dm[i] = l[i] << 1; }
+    uint64_t acc = 0; uint32_t hi = 0;
+    sq_column_lo<0>(d, dm, m, mod, acc, hi);
+    sq_column_hi<N>(d, dm, m, mod, acc, hi, t);
+    Fd r;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
+    cond_sub(r.l, (uint32_t)acc);
+    return r;
+  }
 #else
   PC_HD Fd mul(const Fd& o) const {
     uint32_t t[N + 1];
@@ -211,7 +260,9 @@ struct Fd {
     return r;
   }
 #endif
+#if !defined(__HIP_DEVICE_COMPILE__)
   PC_HD Fd sqr() const { return mul(*this); }
+#endif
 
   // Montgomery <-> canonical
   PC_HD Fd from_mont() const {   // multiply by raw 1 => a * R^-1

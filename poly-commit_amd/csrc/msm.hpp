@@ -319,11 +319,17 @@ struct BucketLevelBody {
   PC_HD void operator()(uint32_t lane) const {
     const uint32_t a = lane / cnt, gidx = lane % cnt;
     const size_t stride = (size_t)cnt * Pt::WORDS;
+    // (the next point is loaded while the current one is added: the lanes of a wave read K * 192 bytes apart, so every
+    // load is a DRAM/L2 round trip of its own, and with one wave per SIMD nothing else hides it -- the SQ counters
+    // showed 47 % of this kernel's wave cycles in s_waitcnt)
     if (a == 0) {
       const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;
       Pt run = Pt::infinity(), acc = Pt::infinity();
+      Pt nxt = Pt::load(base + (size_t)(K - 1) * Pt::WORDS);
       for (uint32_t j = K; j-- > 0;) {
-        run.add(Pt::load(base + (size_t)j * Pt::WORDS));
+        const Pt cur = nxt;
+        if (j > 0) nxt = Pt::load(base + (size_t)(j - 1) * Pt::WORDS);
+        run.add(cur);
         if (j + weight_off > 0) acc.add(run);
       }
       run.store(out + (size_t)gidx * Pt::WORDS);
@@ -331,7 +337,12 @@ struct BucketLevelBody {
     } else {
       const uint32_t* base = old_in + (size_t)(a - 1) * cnt * K * Pt::WORDS + (size_t)gidx * K * Pt::WORDS;
       Pt acc = Pt::infinity();
-      for (uint32_t j = 0; j < K; j++) acc.add(Pt::load(base + (size_t)j * Pt::WORDS));
+      Pt nxt = Pt::load(base);
+      for (uint32_t j = 0; j < K; j++) {
+        const Pt cur = nxt;
+        if (j + 1 < K) nxt = Pt::load(base + (size_t)(j + 1) * Pt::WORDS);
+        acc.add(cur);
+      }
       acc.store(out + (size_t)(1 + a) * stride + (size_t)gidx * Pt::WORDS);
     }
   }

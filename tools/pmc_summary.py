@@ -1,13 +1,14 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as
-/opt/skills/guides/MI355X_MICROARCH.md prescribes) -> profiles/rNN_pmc_traffic.json.
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) merged into profiles/rNN_pmc_traffic.json under one key per workload.
 
-usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [old.json]
+usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <key>
+       key e.g. "bls12_381:2^24:table" (what bench.py looks up for roofline.traffic) or "ntt:bls12_381:2^24"
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-byte request,
-so reads are doubled (the guide's correction); WRITE_SIZE is taken as is.  Sections of `old.json`
-that these two passes do not produce (SQ counters of an earlier pass) are carried over."""
+so reads are doubled (the guide's correction); WRITE_SIZE is taken as is."""
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
@@ -25,26 +26,25 @@ def per_kernel(path, counter):
 
 
 def main():
-    fetch, write, out = sys.argv[1:4]
-    old = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else {}
+    fetch, write, out, key = sys.argv[1:5]
+    doc = json.load(open(out)) if os.path.exists(out) else {}
+    doc.setdefault("note", "FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts 64 B per "
+                           "128-B request, so reads are doubled; WRITE_SIZE taken as is.  The bucket-accumulation gather is 6 x 16 B per "
+                           "lane at random addresses (not the wide coalesced stream the 2x was calibrated on): treat as an upper estimate.  "
+                           "Source: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/gpu_run_*.sh).")
     fs, ws = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-    acc = next(k for k in fs if "k_accumulate" in k)
-    doc = {
-        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on: python bench.py "
-                  "--steps 2 --warmup 1 --no-cpu-baseline --inflight 0 (KZG commit+open, BLS12-381, 2^20, default = SRS window table)",
-        "note": "FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts 64 B per "
-                "128-B request, so reads are doubled; WRITE_SIZE taken as is. The bucket-accumulation gather is 6 x 16 B per "
-                "lane at random addresses (not the wide coalesced stream the 2x was calibrated on): treat as an estimate.",
-        "accumulate_fetch_KiB_per_launch_raw": fs[acc]["avg_per_launch_KiB"],
-        "accumulate_write_KiB_per_launch": ws[acc]["avg_per_launch_KiB"],
-        "accumulate_hbm_bytes_per_launch": (2 * fs[acc]["avg_per_launch_KiB"] + ws[acc]["avg_per_launch_KiB"]) * 1024,
-        "per_kernel_hbm": {"FETCH_SIZE": fs, "WRITE_SIZE": ws},
-    }
-    for k in ("accumulate_valu", "accumulate_valu_note", "per_kernel_sq"):
-        if k in old:
-            doc[k + "_table_free_run"] = old[k]
+    hbm = {k: (2 * fs[k]["avg_per_launch_KiB"] + ws.get(k, {"avg_per_launch_KiB": 0})["avg_per_launch_KiB"]) * 1024 for k in fs}
+    doc.setdefault("per_kernel_hbm_bytes_per_launch", {})[key] = {k: v for k, v in hbm.items() if v > 1e6}
+    doc.setdefault("per_kernel_raw_KiB", {})[key] = {"FETCH_SIZE": fs, "WRITE_SIZE": ws}
+    acc = [k for k in fs if "k_accumulate" in k]
+    if acc:
+        doc.setdefault("accumulate_hbm_bytes_per_launch", {})[key] = hbm[acc[0]]
+        print(key, acc[0], hbm[acc[0]] / 1e9, "GB/launch")
+    ntt = [k for k in fs if "k_ntt_pass" in k]
+    if ntt:
+        doc.setdefault("ntt_hbm_bytes_per_batch", {})[key] = sum(hbm[k] for k in ntt)
+        print(key, "ntt passes", sum(hbm[k] for k in ntt) / 1e9, "GB/batch")
     json.dump(doc, open(out, "w"), indent=1)
-    print(acc, doc["accumulate_hbm_bytes_per_launch"] / 1e9, "GB/launch")
 
 
 if __name__ == "__main__":
