@@ -62,6 +62,17 @@ const char* pc_hip_last_error(const pc_ctx* ctx);
 int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, size_t stride_bytes,
                       pc_mem where, pc_srs** out);
 void pc_hip_srs_free(pc_srs* srs);
+/* The same residency straight from ark-serialize bytes: `bytes` starts with a serialized Vec<G1Affine> -- u64 LE length,
+ * then the points, compressed or not -- which is how kzg10::UniversalParams begins (its CanonicalSerialize writes
+ * powers_of_g first: poly-commit/src/kzg10/data_structures.rs:57-77; deserialisation :80-112) and what an IPA key is
+ * (ipa_pc/data_structures.rs:17-36).  At most max_points points (0 = all) are decoded ON THE DEVICE (compressed points:
+ * y = (x^3 + b)^((p+1)/4), BLS12-381 and BN254) into a resident SRS; *out_bytes_consumed = 8 + len * point size, where
+ * the next field of the structure starts.  Every decoded point is checked to be on the curve (PC_ERR_INVALID_ARG
+ * otherwise); the subgroup check of Validate::Yes is the verifier-side `check()` and is not repeated here.
+ * Point encodings: host/transcript.hpp / csrc/serialize.hpp (ark-ec's generic short-Weierstrass flags; the zcash
+ * encoding for BLS12-381). */
+int pc_hip_srs_load_serialized(pc_ctx* ctx, pc_curve curve, const void* bytes, size_t n_bytes, int compressed,
+                               size_t max_points, pc_srs** out, size_t* out_points, size_t* out_bytes_consumed);
 /* Optional, once per committer key (same place as the upload, i.e. `trim`): build the window
  * table T[w][i] = 2^(c w) * bases[i] in HBM, (bits/c + 1) x the size of the SRS.  MSMs of at least
  * min_pairs pairs (0 = a quarter of the SRS) against this SRS then run with one bucket set shared

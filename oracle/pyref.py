@@ -402,6 +402,37 @@ def ser_point(curve, P):
     return bytes(out)
 
 
+def ser_point_compressed(curve, P):
+    """serialize_compressed of a G1 affine point (ark-ec generic SW / ark-bls12-381's zcash encoding)."""
+    fq = CURVES[curve]["fq"]
+    p = FIELDS[fq]["p"]
+    xb = (p.bit_length() + 7) // 8
+    yb = (p.bit_length() + 2 + 7) // 8
+    if curve == "bls12_381":
+        if P is None:
+            return bytes([0xC0]) + bytes(xb - 1)
+        out = bytearray(P[0].to_bytes(xb, "big"))
+        out[0] |= 0x80
+        if P[1] > (p - P[1]) % p:
+            out[0] |= 0x20
+        return bytes(out)
+    out = bytearray(yb)
+    if P is None:
+        out[-1] |= 0x40
+        return bytes(out)
+    out[:] = P[0].to_bytes(yb, "little")
+    if P[1] <= (p - P[1]) % p:
+        out[-1] |= 0x80
+    return bytes(out)
+
+
+def ser_g1_vec(curve, pts, compressed):
+    """ark-serialize of Vec<G1Affine>: u64 LE length, then the points -- the head of kzg10::UniversalParams
+    (kzg10/data_structures.rs:57-77)."""
+    f = ser_point_compressed if compressed else ser_point
+    return len(pts).to_bytes(8, "little") + b"".join(f(curve, P) for P in pts)
+
+
 def from_random_bytes(field, b):
     """Field::from_random_bytes: low 8*N bytes little-endian, bits above the modulus size cleared; None if >= p."""
     p = FIELDS[field]["p"]

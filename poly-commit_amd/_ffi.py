@@ -54,6 +54,7 @@ def load_library():
     lib.pc_hip_last_error.argtypes = [vp]
     lib.pc_hip_last_error.restype = C.c_char_p
     lib.pc_hip_srs_upload.argtypes = [vp, ip, vp, sz, sz, ip, C.POINTER(vp)]
+    lib.pc_hip_srs_load_serialized.argtypes = [vp, ip, vp, sz, ip, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     lib.pc_hip_srs_free.argtypes = [vp]
     lib.pc_hip_srs_precompute.argtypes = [vp, vp, C.c_uint, sz]
     lib.pc_hip_srs_free.restype = None
@@ -320,6 +321,17 @@ class Context:
 
     def upload_srs(self, curve, bases, n=None, stride_bytes=0):
         return Srs(self, curve, bases, n, stride_bytes)
+
+    def load_serialized_srs(self, curve, data, compressed, max_points=0):
+        """Resident SRS from the ark-serialize bytes of a Vec<G1Affine> (the head of kzg10::UniversalParams):
+        returns (Srs, bytes_consumed)."""
+        h, npts, used = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        self.check(self.lib.pc_hip_srs_load_serialized(self.h, CURVES[curve], buf, len(data), 1 if compressed else 0, max_points,
+                                                       C.byref(h), C.byref(npts), C.byref(used)))
+        srs = Srs.__new__(Srs)
+        srs.ctx, srs.curve, srs.h, srs.n = self, curve, h, npts.value
+        return srs, used.value
 
 
 class Srs:

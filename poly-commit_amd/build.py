@@ -12,8 +12,11 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["abi.hip", "group.hip", "hash_tu.hip",
            "curve_bls12_381.hip", "curve_bn254.hip", "curve_pallas.hip",
            "field_bls12_381.hip", "field_bn254.hip", "field_pallas.hip"]
-OBJ = os.path.join(CSRC, "_obj")
-OUT = os.path.join(HERE, "libpc_hip.so")
+# PC_HIP_VARIANT=name builds an alternative library libpc_hip_<name>.so (own object cache) from the same sources with
+# PC_HIP_CXXFLAGS -- kernel tuning experiments; load it with PC_HIP_LIB=<path>
+_VARIANT = os.environ.get("PC_HIP_VARIANT", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + _VARIANT if _VARIANT else ""))
+OUT = os.path.join(HERE, "libpc_hip" + ("_" + _VARIANT if _VARIANT else "") + ".so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -257,6 +257,38 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
   return PC_OK;
 }
 
+int pc_hip_srs_load_serialized(pc_ctx* ctx, pc_curve curve, const void* bytes, size_t n_bytes, int compressed, size_t max_points,
+                               pc_srs** out, size_t* out_points, size_t* out_bytes_consumed) {
+  if (!ctx || !out || !bytes || (int)curve < 0 || (int)curve > 2) return PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (n_bytes < 8) return PC_ERR_INVALID_ARG;
+  if (compressed && curve == PC_CURVE_PALLAS) return PC_ERR_UNSUPPORTED;      // p = 1 (mod 4): no (p+1)/4 square root
+  const size_t fb = (size_t)fq_bytes(curve);
+  const size_t bits = curve == PC_CURVE_BLS12_381 ? 381 : curve == PC_CURVE_BN254 ? 254 : 255;
+  const size_t yb = (bits + 2 + 7) / 8;
+  const size_t pbytes = curve == PC_CURVE_BLS12_381 ? (compressed ? fb : 2 * fb) : (compressed ? yb : fb + yb);
+  uint64_t len = 0; memcpy(&len, bytes, 8);                                    // Vec<T>: u64 little-endian length
+  if (len > (n_bytes - 8) / pbytes) return PC_ERR_INVALID_ARG;                 // truncated input
+  const size_t n = max_points && max_points < len ? max_points : (size_t)len;
+  if (n >= (1ull << 31)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  void* raw = nullptr; void* pts = nullptr;
+  uint32_t bad = 0;
+  int rc = guarded(ctx, [&]() {
+    raw = ctx->be.alloc(n * pbytes); pts = ctx->be.alloc((n ? n : 1) * 2 * fb);
+    if (n) {
+      ctx->be.copy_h2d(raw, (const char*)bytes + 8, n * pbytes);
+      bad = pc::curve_ops(curve).srs_decode(ctx->be, (const uint8_t*)raw, n, compressed, (uint32_t*)pts);
+    }
+    return (int)PC_OK;
+  });
+  if (rc == PC_OK && bad) { ctx->last_error = std::to_string(bad) + " serialized point(s) are not on the curve"; rc = PC_ERR_INVALID_ARG; }
+  if (rc == PC_OK) rc = pc_hip_srs_upload(ctx, curve, pts, n, 0, PC_MEM_DEVICE, out);
+  (void)guarded(ctx, [&]() { ctx->be.free(raw); ctx->be.free(pts); return (int)PC_OK; });
+  if (rc == PC_OK) { if (out_points) *out_points = n; if (out_bytes_consumed) *out_bytes_consumed = 8 + (size_t)len * pbytes; }
+  return rc;
+}
+
 void pc_hip_srs_free(pc_srs* srs) {
   if (!srs) return;
   if (srs->ctx) (void)hipSetDevice(srs->ctx->device);

@@ -6,6 +6,7 @@
 #include "hip_backend_msm.hpp"
 #include "ipa.hpp"
 #include "glv.hpp"
+#include "serialize.hpp"
 
 namespace pc {
 
@@ -73,6 +74,14 @@ struct CurveOpsImpl {
     for (int i = 0; i < AW; i++) body.g[i] = g[i];
     be.launch(body, n, 64); be.sync();
   }
+  static uint32_t srs_decode(HipBackend& be, const uint8_t* bytes_dev, size_t n, int compressed, uint32_t* out) {
+    uint32_t* bad = (uint32_t*)be.workspace(4);
+    be.memset(bad, 0, 4);
+    SrsDecodeBody<C> b{bytes_dev, (uint32_t)n, compressed ? 1u : 0u, C::FqP::BITS == 381 ? 1u : 0u, out, bad};
+    be.launch(b, n, 64);
+    uint32_t h = 0; be.copy_d2h(&h, bad, 4);
+    return h;
+  }
   static void points_sum(const uint32_t* pts, size_t count, uint32_t* out) {
     XyzzD<C> acc = XyzzD<C>::infinity();
     for (size_t i = 0; i < count; i++) acc.add_affine(AffD<C>::load(pts + i * AW));
@@ -93,7 +102,7 @@ struct CurveOpsImpl {
     acc.store_affine(out);
   }
   static CurveOps table() {
-    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &fixed_base, &points_sum, &point_mul};
+    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &fixed_base, &srs_decode, &points_sum, &point_mul};
   }
 };
 

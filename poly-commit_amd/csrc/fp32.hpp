@@ -277,16 +277,16 @@ struct Fd {
 
   // Fermat inverse a^(p-2); 0 -> 0.  Used once per MSM / per batch, never per element.
   PC_HD Fd inv() const {
-    uint32_t e[N];   // p - 2
-    uint64_t br = 2;
-    PC_UNROLL for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)P::MOD[i] - br;
-      e[i] = (uint32_t)t; br = (t >> 63);
-    }
+    // exponent p - 2, derived word by word from the constant modulus (a local copy of it indexed by the loop counter
+    // would live in scratch memory on the device); Pallas' p = ...00000001 borrows out of word 0
     Fd r = one();
-    for (int i = N * 32 - 1; i >= 0; i--) {
-      r = r.sqr();
-      if ((e[i >> 5] >> (i & 31)) & 1) r = r.mul(*this);
+    for (int w = N - 1; w >= 0; w--) {
+      uint32_t e = 0; uint64_t br = 2;
+      for (int i = 0; i <= w; i++) { const uint64_t t = (uint64_t)P::MOD[i] - br; e = (uint32_t)t; br = t >> 63; }
+      for (int b = 31; b >= 0; b--) {
+        r = r.sqr();
+        if ((e >> b) & 1) r = r.mul(*this);
+      }
     }
     return r;
   }

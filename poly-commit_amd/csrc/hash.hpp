@@ -47,6 +47,23 @@ struct Sha256 {
   }
   // four message bytes, first byte in the low 8 bits
   PC_HD void push_le32(uint32_t w) { buf[nbuf++] = bswap32(w); bytes += 4; if (nbuf == 16) compress(); }
+  // Whole 64-byte blocks / a tail of NT words with COMPILE-TIME buffer indices (buf[nbuf++] with a run-time nbuf
+  // puts the buffer into scratch memory on the device: for the 2 GiB of config 5 that was 1.9 GB of private-segment
+  // writes, rocprofv3 WRITE_SIZE).  Only valid while nbuf == 0.
+  PC_HD void absorb_block(const uint32_t* m) {
+    PC_UNROLL for (int k = 0; k < 16; k++) buf[k] = bswap32(m[k]);
+    bytes += 64; compress();
+  }
+  template <int NT>
+  PC_HD void finish_tail(const uint32_t* tail, uint32_t* out) {
+    static_assert(NT <= 13, "tail + padding + length must fit one block");
+    bytes += 4 * NT;
+    const uint64_t bits = bytes * 8;
+    PC_UNROLL for (int k = 0; k < 14; k++) buf[k] = k < NT ? bswap32(tail[k < NT ? k : 0]) : (k == NT ? 0x80000000u : 0u);
+    buf[14] = (uint32_t)(bits >> 32); buf[15] = (uint32_t)bits;
+    compress();
+    PC_UNROLL for (int i = 0; i < 8; i++) out[i] = bswap32(h[i]);
+  }
   // digest as 8 words whose little-endian memory image is the 32 digest bytes
   PC_HD void finish(uint32_t* out) {
     const uint64_t bits = bytes * 8;
@@ -92,6 +109,19 @@ struct Blake2s256 {
     if (nbuf == 16) { t += 64; compress(false); nbuf = 0; }   // a full buffer is only compressed once more input arrives
     buf[nbuf++] = w;
   }
+  // whole blocks that are NOT the last one / the last NT (>= 1) words, compile-time indices (see Sha256); nbuf == 0
+  PC_HD void absorb_block(const uint32_t* m) {
+    PC_UNROLL for (int k = 0; k < 16; k++) buf[k] = m[k];
+    t += 64; compress(false);
+  }
+  template <int NT>
+  PC_HD void finish_tail(const uint32_t* tail, uint32_t* out) {
+    static_assert(NT >= 1 && NT <= 16, "the last block holds 1..16 words");
+    t += 4 * NT;
+    PC_UNROLL for (int k = 0; k < 16; k++) buf[k] = k < NT ? tail[k < NT ? k : 0] : 0u;
+    compress(true);
+    PC_UNROLL for (int i = 0; i < 8; i++) out[i] = h[i];
+  }
   PC_HD void finish(uint32_t* out) {
     t += 4ull * nbuf;
     while (nbuf < 16) buf[nbuf++] = 0;
@@ -109,20 +139,36 @@ struct ColumnHashBody {
   const uint32_t* ext;   // rows x n_cols elements, row-major, Montgomery
   uint32_t rows, n_cols;
   uint32_t* out;         // n_cols x 8 words
+  PC_HD F row(uint32_t r, uint32_t j) const { return F::load(ext + ((size_t)r * n_cols + j) * FrP::N); }
   PC_HD void operator()(uint32_t j) const {
+    static_assert(FrP::N == 8, "32-byte scalar-field elements");
+    // Message words: [rows, 0] then 8 words per row, i.e. block b = 2 words carried over | row 2b | the first 6 words
+    // of row 2b+1; its last 2 words open block b+1.  Two rows per iteration keep every buffer index a constant.
     D d; d.init();
-    d.push_le32(rows); d.push_le32(0);                       // Vec length as u64 LE
-    // two rows in flight: the loads of rows r+1 and r+2 are issued before row r is converted and hashed
+    uint32_t carry[2] = {rows, 0u};                          // Vec length as u64 LE
+    // the loads of the next pair are issued before this pair is converted and hashed
     // (one wave per 64 columns leaves 2 waves per SIMD: without this the kernel waits on every load)
-    F nxt = rows ? F::load(ext + (size_t)j * FrP::N) : F::zero();
-    F nxt2 = rows > 1 ? F::load(ext + ((size_t)n_cols + j) * FrP::N) : F::zero();
-    for (uint32_t r = 0; r < rows; r++) {
-      F cur = nxt; nxt = nxt2;
-      if (r + 2 < rows) nxt2 = F::load(ext + ((size_t)(r + 2) * n_cols + j) * FrP::N);
-      F v = cur.from_mont();
-      PC_UNROLL for (int k = 0; k < FrP::N; k++) d.push_le32(v.l[k]);
+    F a = rows > 0 ? row(0, j) : F::zero(), b = rows > 1 ? row(1, j) : F::zero();
+    uint32_t r = 0;
+    for (; r + 2 <= rows; r += 2) {
+      const F ca = a.from_mont(), cb = b.from_mont();
+      if (r + 2 < rows) a = row(r + 2, j);
+      if (r + 3 < rows) b = row(r + 3, j);
+      uint32_t m[16];
+      m[0] = carry[0]; m[1] = carry[1];
+      PC_UNROLL for (int k = 0; k < 8; k++) m[2 + k] = ca.l[k];
+      PC_UNROLL for (int k = 0; k < 6; k++) m[10 + k] = cb.l[k];
+      carry[0] = cb.l[6]; carry[1] = cb.l[7];
+      d.absorb_block(m);
     }
-    uint32_t dig[8]; d.finish(dig);
+    uint32_t dig[8];
+    if (r < rows) {                                          // odd number of rows: 2 carried words + the last row
+      const F ca = a.from_mont();
+      uint32_t tail[10];
+      tail[0] = carry[0]; tail[1] = carry[1];
+      PC_UNROLL for (int k = 0; k < 8; k++) tail[2 + k] = ca.l[k];
+      d.template finish_tail<10>(tail, dig);
+    } else d.template finish_tail<2>(carry, dig);
     PC_UNROLL for (int k = 0; k < 8; k++) out[(size_t)j * 8 + k] = dig[k];
   }
 };

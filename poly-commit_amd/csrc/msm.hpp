@@ -100,6 +100,19 @@ struct ScalarDigits {
     if (w + 1 < (uint32_t)FrP::N) v |= (uint64_t)s[w + 1] << 32;
     return (uint32_t)(v >> b) & ((1u << c) - 1u);
   }
+  // f(w, bits [w c, (w+1) c)) for w = 0 .. Wd-1, in order.  The limbs are fed through a 64-bit shift register with
+  // COMPILE-TIME limb indices: bits_at()'s run-time index into s[] puts the scalar into scratch memory on the
+  // device (36 bytes per lane in the sort passes: a store and several loads per scalar through the private segment).
+  template <class F>
+  PC_HD void for_each_window(uint32_t c, uint32_t Wd, F f) const {
+    uint64_t buf = 0; uint32_t have = 0, w = 0;
+    const uint32_t mask = (1u << c) - 1u;
+    PC_UNROLL for (int i = 0; i < FrP::N; i++) {
+      buf |= (uint64_t)s[i] << have; have += 32;                 // have < c <= 24 before: no bit is lost
+      while (have >= c && w < Wd) { f(w, (uint32_t)buf & mask); buf >>= c; have -= c; w++; }
+    }
+    while (w < Wd) { f(w, (uint32_t)buf & mask); buf >>= c; w++; }   // the (short) top window(s), zero-extended
+  }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -115,12 +128,12 @@ struct DigitsHistBody {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
     uint32_t carry = 0, sub, j; g.split(i, sub, j);
     const uint32_t half = 1u << (g.c - 1);
-    for (uint32_t w = 0; w < g.Wd; w++) {
-      uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
+    sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
+      uint32_t raw = bits + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
       if (mag) atomic_inc_u32(hist + (size_t)g.key_window(w, sub) * g.nb_win + (mag - 1));
-    }
+    });
   }
 };
 
@@ -138,15 +151,15 @@ struct ScatterBody {
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
     uint32_t carry = 0, sub, j; g.split(i, sub, j);
     const uint32_t half = 1u << (g.c - 1);
-    for (uint32_t w = 0; w < g.Wd; w++) {
-      uint32_t raw = sd.bits_at(w * g.c, g.c) + carry;
+    sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
+      uint32_t raw = bits + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
       if (mag) {
         uint32_t pos = atomic_inc_u32(cursor + (size_t)g.key_window(w, sub) * g.nb_win + (mag - 1));
         entries[pos] = g.base_index(w, j) | (carry << 31);
       }
-    }
+    });
   }
 };
 

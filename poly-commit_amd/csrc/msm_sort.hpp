@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
     ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, sg.from_mont);
     uint32_t carry = 0, sub = 0, j = i;
     if (sg.m_sub) { sub = i / sg.m_sub; j = i - sub * sg.m_sub; }      // many-MSM mode: bucket set `sub`
-    for (uint32_t w = 0; w < sg.Wd; w++) {
-      uint32_t raw = sd.bits_at(w * sg.c, sg.c) + carry;
+    sd.for_each_window(sg.c, sg.Wd, [&](uint32_t w, uint32_t bits) {
+      uint32_t raw = bits + carry;
       carry = raw > half;
       uint32_t mag = carry ? (2 * half - raw) : raw;
       if (mag) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
         const uint32_t base = sg.tbl_stride ? w * sg.tbl_stride + sg.base_off + j : sg.base_off + j;
         if (SCATTER) records[pos] = make_uint2(base | (carry << 31), b - (cbin << fb));
       }
-    }
+    });
   }
   if (!SCATTER) {
     __syncthreads();

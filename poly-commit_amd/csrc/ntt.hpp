@@ -17,13 +17,18 @@
 // stages of a pass read theirs from a copy in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
 #include <vector>
 #include "fp32.hpp"
 #include "hip_backend.hpp"
 
 namespace pc {
 
-static constexpr int NTT_THREADS = 256;
+#ifndef PC_NTT_THREADS
+#define PC_NTT_THREADS 256
+#endif
+static constexpr int NTT_THREADS = PC_NTT_THREADS;   // lanes per tile (the LDS tile, not the VGPRs, bounds the workgroups per CU)
 static constexpr uint32_t NTT_TILE_MAX = 2048;   // elements per LDS tile (64 KiB of 32-byte elements)
 
 template <class FrP>
@@ -209,14 +214,28 @@ class NttPlan {
     if (lds_a > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_a<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     if (lds_b > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_b<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     uint32_t zskip = 0; while (zskip < lg1_ && in_cols <= ((size_t)N >> (zskip + 1))) zskip++;
+    // Row groups: pass B of a group of rows runs right after its pass A, while the group's intermediate (4 MiB per 2^17-point
+    // row) is still in the 256 MB memory-side cache, instead of after pass A of the whole batch (2 GiB for config 5) has
+    // pushed it out to HBM and back.  PC_HIP_NTT_GROUP = rows per group (0 = the whole batch in one go).
+    static const size_t group_env = []() { const char* e = getenv("PC_HIP_NTT_GROUP"); return e ? (size_t)atol(e) : (size_t)~0ull; }();
+    size_t group = group_env == (size_t)~0ull ? std::max<size_t>(1, ((size_t)128 << 20) / ((size_t)N * FrP::N * 4)) : group_env;
+    if (group == 0 || group > rows) group = rows;
+    const bool single = group == rows;      // phase brackets: [pass A, pass B] for one group; [whole batch, 0] when grouped
     be_.mark();
-    hipLaunchKernelGGL(k_ntt_pass_a<FrP>, dim3((unsigned)(rows * (N2 / C))), dim3(NTT_THREADS), lds_a, be_.stream, in,
-                       (uint32_t)in_cols, tmp_, W_, log_n_, lg1_, C, zskip);
-    PC_HIP_CHECK(hipGetLastError());
-    be_.mark();
-    hipLaunchKernelGGL(k_ntt_pass_b<FrP>, dim3((unsigned)(rows * (N1 / R))), dim3(NTT_THREADS), lds_b, be_.stream, tmp_, out, W_,
-                       log_n_, lg1_, R);
-    PC_HIP_CHECK(hipGetLastError());
+    for (size_t r0 = 0; r0 < rows; r0 += group) {
+      const size_t nr = std::min(group, rows - r0);
+      const uint32_t* gin = in + r0 * in_cols * FrP::N;
+      uint32_t* gtmp = tmp_ + r0 * (size_t)N * FrP::N;
+      uint32_t* gout = out + r0 * (size_t)N * FrP::N;
+      hipLaunchKernelGGL(k_ntt_pass_a<FrP>, dim3((unsigned)(nr * (N2 / C))), dim3(NTT_THREADS), lds_a, be_.stream, gin,
+                         (uint32_t)in_cols, gtmp, W_, log_n_, lg1_, C, zskip);
+      PC_HIP_CHECK(hipGetLastError());
+      if (single) be_.mark();
+      hipLaunchKernelGGL(k_ntt_pass_b<FrP>, dim3((unsigned)(nr * (N1 / R))), dim3(NTT_THREADS), lds_b, be_.stream, gtmp, gout, W_,
+                         log_n_, lg1_, R);
+      PC_HIP_CHECK(hipGetLastError());
+    }
+    if (!single) be_.mark();
     be_.mark();
   }
 

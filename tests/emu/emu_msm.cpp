@@ -11,6 +11,7 @@
 #include "../../poly-commit_amd/csrc/ipa.hpp"
 #include "../../poly-commit_amd/csrc/hash.hpp"
 #include "../../poly-commit_amd/csrc/glv.hpp"
+#include "../../poly-commit_amd/csrc/serialize.hpp"
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
@@ -266,6 +267,22 @@ extern "C" void emu_glv_fold_batched(int curve, uint32_t* key, size_t half, cons
     case 0: glv_fold_batched<pc_curve_bls12_381>(key, half, k_canon, K); break;
     case 1: glv_fold_batched<pc_curve_bn254>(key, half, k_canon, K); break;
     case 2: glv_fold_batched<pc_curve_pallas>(key, half, k_canon, K); break;
+  }
+}
+
+// ark-serialize bytes -> affine points (SrsDecodeBody), stepped
+template <class C>
+static uint32_t srs_decode(const uint8_t* in, uint32_t n, int compressed, uint32_t* out) {
+  uint32_t bad = 0;
+  pc::SrsDecodeBody<C> b{in, n, compressed ? 1u : 0u, C::FqP::BITS == 381 ? 1u : 0u, out, &bad};
+  CpuStepBackend be; be.launch(b, n);
+  return bad;
+}
+extern "C" uint32_t emu_srs_decode(int curve, const uint8_t* in, uint32_t n, int compressed, uint32_t* out) {
+  switch (curve) {
+    case 0: return srs_decode<pc_curve_bls12_381>(in, n, compressed, out);
+    case 1: return srs_decode<pc_curve_bn254>(in, n, compressed, out);
+    default: return srs_decode<pc_curve_pallas>(in, n, compressed, out);
   }
 }
 

@@ -24,7 +24,7 @@ def emu():
     if _emu is None:
         so = os.path.join(HERE, "emu", "libemu.so")
         srcs = [os.path.join(HERE, "emu", "emu_msm.cpp")] + [
-            os.path.join(HERE, "..", "poly-commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp")]
+            os.path.join(HERE, "..", "poly-commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp", "ipa.hpp", "glv.hpp", "serialize.hpp")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
         _emu = C.CDLL(so)
@@ -390,3 +390,25 @@ def test_ipa_fixed_key_rounds_stepped(curve):
         assert [R.msm(curve, [K0[j] for j in range(n0) if j % m == i], [O.fr_from_mont_array(curve, s)[j] for j in range(n0) if j % m == i])
                 for i in range(m)] == key[:m]
     assert R.msm(curve, K0, O.fr_from_mont_array(curve, s)) == key[0]
+
+
+@pytest.mark.parametrize("curve,compressed", [("bls12_381", False), ("bls12_381", True), ("bn254", False), ("bn254", True), ("pallas", False)])
+def test_srs_decode_ark_serialize_stepped(curve, compressed):
+    """CanonicalDeserialize of Vec<G1Affine> (the head of kzg10::UniversalParams, kzg10/data_structures.rs:80-112): the
+    device decoder (SrsDecodeBody, stepped on the CPU) against the Python big-int serialiser -- both roots, infinity,
+    and a corrupted point is counted as invalid."""
+    pts = R.gen_bases(curve, 6)
+    pts[1] = R.ec_neg(curve, pts[1])
+    pts[4] = None
+    data = R.ser_g1_vec(curve, pts, compressed)
+    body = np.frombuffer(data[8:], dtype=np.uint8).copy()
+    assert int.from_bytes(data[:8], "little") == 6
+    out = np.zeros((6, 2 * O.fq_limbs(curve)), dtype=np.uint64)
+    bad = emu().emu_srs_decode(O.CURVES[curve], body.ctypes.data_as(C.POINTER(C.c_uint8)), 6, 1 if compressed else 0, p32(out.view(np.uint32)))
+    assert bad == 0 and O.array_to_points(curve, out) == pts
+    # flip a low bit of the first x: (almost surely) no longer a point
+    body2 = body.copy()
+    body2[47 if curve == "bls12_381" else 0] ^= 1
+    bad = emu().emu_srs_decode(O.CURVES[curve], body2.ctypes.data_as(C.POINTER(C.c_uint8)), 6, 1 if compressed else 0, p32(out.view(np.uint32)))
+    if not compressed:
+        assert bad == 1

@@ -231,3 +231,39 @@ def test_golden_ligero_commit_lincomb_msm_many(ctx):
             assert pts[k] == (None if want is None else (int(want[0], 16), int(want[1], 16)))
         assert list(inf) == [w is None for w in case["results"]]
         srs.free()
+
+
+@pytest.mark.parametrize("curve,compressed", [("bls12_381", True), ("bls12_381", False), ("bn254", True), ("bn254", False), ("pallas", False)])
+def test_srs_from_ark_serialize_bytes(ctx, curve, compressed):
+    """pc_hip_srs_load_serialized: the head of a serialized kzg10::UniversalParams (Vec<G1Affine>: u64 length + points,
+    kzg10/data_structures.rs:57-112) decoded on the device into a resident SRS; a commitment over it equals the oracle's."""
+    import poly_commit_amd as pc
+    n = 300
+    pts = R.gen_bases(curve, n)
+    pts[7] = R.ec_neg(curve, pts[7])
+    data = R.ser_g1_vec(curve, pts, compressed) + b"\x01\x02\x03trailing fields of the structure"
+    srs, used = ctx.load_serialized_srs(curve, data, compressed)
+    assert srs.n == n and used == len(R.ser_g1_vec(curve, pts, compressed))
+    arr = O.points_to_array(curve, pts)
+    assert (srs.read(0, n) == arr).all()
+    s = O.gen_scalars(curve, 0x5E71A, n)
+    assert (srs.msm(s)[0] == O.msm_pippenger(curve, arr, s, 8, 1)).all()
+    srs.free()
+    # only the first 100 points (a committer key shorter than the ceremony)
+    srs, used2 = ctx.load_serialized_srs(curve, data, compressed, max_points=100)
+    assert srs.n == 100 and used2 == used and (srs.read(0, 100) == arr[:100]).all()
+    srs.free()
+    with pytest.raises(pc.PcHipError):                       # truncated
+        ctx.load_serialized_srs(curve, data[:used // 2], compressed)
+    bad = bytearray(data)
+    bad[8 + (47 if curve == "bls12_381" else 0)] ^= 1         # first x off by one: not on the curve / wrong point
+    if not compressed:
+        with pytest.raises(pc.PcHipError):
+            ctx.load_serialized_srs(curve, bytes(bad), compressed)
+
+
+def test_srs_compressed_pallas_is_unsupported(ctx):
+    import poly_commit_amd as pc
+    with pytest.raises(pc.PcHipError) as e:
+        ctx.load_serialized_srs("pallas", (1).to_bytes(8, "little") + bytes(33), True)
+    assert e.value.status == -6
