@@ -52,8 +52,13 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
 template <class C>
 void HipBackend::accumulate(const AccumulateBody<C>& body, size_t lanes) {
   if (lanes == 0) return;
-  hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, body, (uint32_t)lanes);
+  const unsigned wgs = (unsigned)((lanes + 255) / 256);
+  hipLaunchKernelGGL(k_accumulate<C>, dim3(wgs), dim3(256), 0, stream, body, (uint32_t)lanes);
   PC_HIP_CHECK(hipGetLastError());
+  if (wgs > 1) {
+    hipLaunchKernelGGL(k_accumulate_edges<C>, dim3((wgs - 1 + 63) / 64), dim3(64), 0, stream, body, (uint32_t)lanes);
+    PC_HIP_CHECK(hipGetLastError());
+  }
 }
 
 template <class C>

@@ -105,6 +105,30 @@ __global__ void __launch_bounds__(256) k_accumulate(AccumulateBody<C> b, uint32_
   if (valid) { b.pkeys[2 * t] = k0; b.pkeys[2 * t + 1] = k1; }
 }
 
+// The runs that a WORKGROUP edge cut (lane 255 of workgroup k / lane 0 of workgroup k+1) are the only cut runs the
+// in-workgroup merge above cannot see: one lane per edge does the same merge right after the accumulation.  With
+// uniformly distributed scalars this leaves the partial list empty, so the level-by-level segmented reduction behind
+// it has launches but no additions left (it still handles buckets spanning three or more chunks: skewed scalars).
+template <class C>
+__global__ void __launch_bounds__(64) k_accumulate_edges(AccumulateBody<C> b, uint32_t lanes) {
+  typedef XyzzD<C> Pt;
+  const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+  const uint64_t t64 = (uint64_t)(k + 1) * 256;           // first lane of workgroup k + 1
+  if (t64 >= lanes) return;
+  const uint32_t t = (uint32_t)t64, a = t - 1;
+  const uint32_t k1 = b.pkeys[2 * a + 1], k0 = b.pkeys[2 * t];
+  if (k1 == KEY_INVALID || k1 != k0) return;
+  uint32_t* slot = b.ppts + (size_t)(2 * t) * Pt::WORDS;
+  Pt f = Pt::load(slot);
+  f.add(Pt::load(b.ppts + (size_t)(2 * a + 1) * Pt::WORDS));
+  const uint32_t M = b.offsets[b.g.NB];
+  const uint64_t s64 = (uint64_t)t * b.g.T;
+  const uint32_t e = (M - (uint32_t)s64 > b.g.T) ? (uint32_t)s64 + b.g.T : M;
+  b.pkeys[2 * a + 1] = KEY_INVALID;
+  if (b.offsets[k0 + 1] <= e) { f.store(b.buckets + (size_t)k0 * Pt::WORDS); b.pkeys[2 * t] = KEY_INVALID; }
+  else f.store(slot);
+}
+
 // The tail of the segmented reduction: levels whose lane count fits one workgroup are walked
 // inside a single launch (lane u of level L = thread u, u + 1024, ...), with a workgroup barrier
 // between levels instead of a kernel boundary (~60 us each on an otherwise idle stream).
