@@ -25,10 +25,13 @@
 
 namespace pc {
 
+// Lanes per tile.  The 64 KiB LDS tile, not the VGPRs, bounds the workgroups per CU (two), so the occupancy is set here:
+// 512 lanes = 4 waves per SIMD at 104 VGPRs; 256 lanes left 2 waves per SIMD and 22-28 % of the wave cycles waiting on LDS
+// and global loads (measured: 6.01 -> 5.48 ms for the 2^24-coefficient batch).
 #ifndef PC_NTT_THREADS
-#define PC_NTT_THREADS 256
+#define PC_NTT_THREADS 512
 #endif
-static constexpr int NTT_THREADS = PC_NTT_THREADS;   // lanes per tile (the LDS tile, not the VGPRs, bounds the workgroups per CU)
+static constexpr int NTT_THREADS = PC_NTT_THREADS;
 static constexpr uint32_t NTT_TILE_MAX = 2048;   // elements per LDS tile (64 KiB of 32-byte elements)
 
 template <class FrP>
@@ -214,11 +217,12 @@ class NttPlan {
     if (lds_a > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_a<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     if (lds_b > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_b<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     uint32_t zskip = 0; while (zskip < lg1_ && in_cols <= ((size_t)N >> (zskip + 1))) zskip++;
-    // Row groups: pass B of a group of rows runs right after its pass A, while the group's intermediate (4 MiB per 2^17-point
-    // row) is still in the 256 MB memory-side cache, instead of after pass A of the whole batch (2 GiB for config 5) has
-    // pushed it out to HBM and back.  PC_HIP_NTT_GROUP = rows per group (0 = the whole batch in one go).
-    static const size_t group_env = []() { const char* e = getenv("PC_HIP_NTT_GROUP"); return e ? (size_t)atol(e) : (size_t)~0ull; }();
-    size_t group = group_env == (size_t)~0ull ? std::max<size_t>(1, ((size_t)128 << 20) / ((size_t)N * FrP::N * 4)) : group_env;
+    // Optional row groups (PC_HIP_NTT_GROUP = rows per group): pass B of a group runs right after its pass A, while the
+    // group's intermediate could still sit in the 256 MB memory-side cache.  Measured on config 5 (32 / 64 rows per group):
+    // 6.3 / 6.2 ms against 6.0 ms for the whole batch in one pair of launches -- the kernels are bound by the multiplier,
+    // not by the 1 TB/s they move, and the shorter launches only add tail effects.  Off by default.
+    static const size_t group_env = []() { const char* e = getenv("PC_HIP_NTT_GROUP"); return e ? (size_t)atol(e) : (size_t)0; }();
+    size_t group = group_env;
     if (group == 0 || group > rows) group = rows;
     const bool single = group == rows;      // phase brackets: [pass A, pass B] for one group; [whole batch, 0] when grouped
     be_.mark();
