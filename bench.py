@@ -348,12 +348,14 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
     bytes_per_launch = pairs_per_launch * PAIR_BYTES[curve]
     achieved = bytes_per_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
     ach_serial = n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 if acc_serial_ms > 0 else None
-    traffic = None
+    traffic = traffic_raw = None
     tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")       # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py);
     if os.path.exists(tf):                                            # keyed by size and table mode, null when not measured
         try:
             key = f"{curve}:2^{log_degree}:{'table' if args.precompute else 'table-free'}"
-            traffic = json.load(open(tf)).get("accumulate_hbm_bytes_per_launch", {}).get(key)
+            doc = json.load(open(tf))
+            traffic = doc.get("accumulate_hbm_bytes_per_launch", {}).get(key)
+            traffic_raw = doc.get("accumulate_fetch_raw_plus_write_bytes_per_launch", {}).get(key)
         except Exception:
             traffic = None
     res = {
@@ -367,6 +369,9 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
             ["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], sp[:6])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                     "traffic_note": "PMC FETCH_SIZE (doubled per the gfx950 note of MI355X_MICROARCH.md) + WRITE_SIZE per launch, separate "
+                                     "rocprofv3 passes of this workload (profiles/r02_pmc_traffic.json); undoubled: "
+                                     + (f"{traffic_raw:.4g} B" if traffic_raw else "n/a") + " -- for this kernel's 16-byte gathers the raw figure is the plausible one",
                      "kernel": "k_accumulate (bucket accumulation): average hipEvent bracket of its launches on the MSM "
                                "pipelines' streams inside the timed region",
                      "algorithmic_bytes_per_launch": bytes_per_launch,

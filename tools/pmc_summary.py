@@ -39,6 +39,8 @@ def main():
     acc = [k for k in fs if "k_accumulate" in k]
     if acc:
         doc.setdefault("accumulate_hbm_bytes_per_launch", {})[key] = hbm[acc[0]]
+        doc.setdefault("accumulate_fetch_raw_plus_write_bytes_per_launch", {})[key] = (
+            fs[acc[0]]["avg_per_launch_KiB"] + ws.get(acc[0], {"avg_per_launch_KiB": 0})["avg_per_launch_KiB"]) * 1024
         print(key, acc[0], hbm[acc[0]] / 1e9, "GB/launch")
     ntt = [k for k in fs if "k_ntt_pass" in k]
     if ntt:
