@@ -1,6 +1,7 @@
 // C ABI of the gfx950 backend (include/pc_hip.h).  Thin glue: context/SRS lifetime, buffer
 // staging, error translation.  The kernels live in the per-curve / per-field translation units
 // (curve_*.hip, field_*.hip) and are reached through the ops tables of pc_internal.hpp.
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -55,6 +56,8 @@ struct pc_srs {
   int next_lane = 0;
   // pc_hip_msm_many: window table of bases[base_offset .. base_offset + m) and the pipeline sized for B x m
   struct Many { size_t base_offset = 0, m = 0, B = 0; uint32_t* table = nullptr; MsmLane* lane = nullptr; } many;
+  // pc_hip_msm_batch over the window table: G polynomials of m coefficients per pass, one bucket set each (two pipelines)
+  struct BatchMany { size_t m = 0, G = 0; MsmLane* lanes[2] = {nullptr, nullptr}; } bm;
 };
 struct pc_job {
   pc_srs* srs = nullptr; int lane = 0;
@@ -149,8 +152,14 @@ static void drop_many(pc_srs* srs) {
   srs->many.table = nullptr; srs->many.m = srs->many.B = srs->many.base_offset = 0;
 }
 
+static void drop_batch_many(pc_srs* srs) {
+  for (int i = 0; i < 2; i++) { delete srs->bm.lanes[i]; srs->bm.lanes[i] = nullptr; }
+  srs->bm.m = srs->bm.G = 0;
+}
+
 // Forget the window table of an SRS (and the pipelines sized for it).  No job may be in flight.
 static void drop_table(pc_srs* srs) {
+  drop_batch_many(srs);
   if (!srs->table) return;
   for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
   (void)hipFree(srs->table); srs->table = nullptr;
@@ -301,6 +310,7 @@ void pc_hip_srs_free(pc_srs* srs) {
     delete srs->lanes[i];
   }
   if (srs->bases) (void)hipFree(srs->bases);
+  drop_batch_many(srs);
   if (srs->table) (void)hipFree(srs->table);
   drop_many(srs);
   delete srs;
@@ -382,6 +392,63 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
   if (!ctx || !srs || !out_xy || srs->ctx != ctx || (n_polys && (!scalars || !n))) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
+    // Equal-length polynomials against the window table of the key (MarlinKZG10::commit of a batch: config 3): G of them per
+    // pass through ONE sort / accumulate / reduce pipeline with a bucket set each (the many-MSM machinery of
+    // pc_hip_msm_many, over the key's own table).  The latency-bound reductions and the host tail are then paid once per G
+    // polynomials and are wide enough to be throughput-bound; two such pipelines alternate.
+    {
+      bool same = n_polys >= 2 && srs->table && where == PC_MEM_DEVICE && n[0] >= ((size_t)1 << 14) && n[0] >= srs->cfg.tbl_min_n;
+      const size_t b0 = base_offsets ? base_offsets[0] : 0;
+      for (size_t k = 0; same && k < n_polys; k++) same = n[k] == n[0] && (base_offsets ? base_offsets[k] : 0) == b0 && scalars[k];
+      if (same && b0 <= srs->n && n[0] <= srs->n - b0) {
+        static const size_t Gmax = []() { const char* e = getenv("PC_HIP_BATCH_G"); int v = e ? atoi(e) : 8; return (size_t)(v < 0 ? 0 : v); }();
+        const size_t m = n[0];
+        size_t G = std::min(Gmax, n_polys);
+        const uint32_t bits = pc::curve_ops(srs->curve).scalar_bits;
+        const uint32_t Wd = pc::msm_num_windows(bits, srs->cfg.tbl_c);
+        while (G >= 2 && ((uint64_t)G * m * Wd >= (1ull << 32) || ((uint64_t)G << (srs->cfg.tbl_c - 1)) >= (1ull << 31))) G /= 2;
+        if (G >= 2) {
+          pc_srs::BatchMany& B = srs->bm;
+          if (B.m != m || B.G != G) {
+            drop_batch_many(srs);
+            for (int i = 0; i < 2; i++) {
+              MsmLane* L = new MsmLane();
+              try { L->be.init(); L->runner = pc::curve_ops(srs->curve).make_runner(L->be, G * m, srs->cfg, (uint32_t)G); }
+              catch (...) { delete L; drop_batch_many(srs); throw; }
+              B.lanes[i] = L;
+            }
+            B.m = m; B.G = G;
+          }
+          for (int i = 0; i < PC_MSM_LANES; i++)       // nothing of the single-MSM pipelines may be in flight on this key's outputs
+            if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
+          const size_t pb = (size_t)srs->aw * 4;
+          std::vector<uint32_t> tmp[2]; tmp[0].resize(G * srs->aw); tmp[1].resize(G * srs->aw);
+          size_t pending_first[2] = {0, 0}, pending_cnt[2] = {0, 0};
+          auto drain = [&](int li) {
+            if (!pending_cnt[li]) return;
+            B.lanes[li]->runner->finish(tmp[li].data());
+            for (size_t k = 0; k < pending_cnt[li]; k++) {
+              uint8_t* o = (uint8_t*)out_xy + (pending_first[li] + k) * pb;
+              memcpy(o, tmp[li].data() + k * srs->aw, pb);
+              if (out_is_infinity) { uint32_t acc = 0; for (int w = 0; w < srs->aw; w++) acc |= tmp[li][k * srs->aw + w]; out_is_infinity[pending_first[li] + k] = acc == 0; }
+            }
+            pending_cnt[li] = 0;
+          };
+          int li = 0;
+          for (size_t first = 0; first < n_polys; first += G, li ^= 1) {
+            drain(li);
+            const size_t cnt = std::min(G, n_polys - first);
+            std::vector<uint64_t> ptrs(cnt);
+            for (size_t k = 0; k < cnt; k++) ptrs[k] = (uint64_t)(uintptr_t)scalars[first + k];
+            B.lanes[li]->be.timing = ctx->be.timing;
+            B.lanes[li]->runner->enqueue_vectors(srs->bases, (uint32_t)b0, ptrs.data(), cnt, m, form == PC_SCALARS_MONTGOMERY);
+            pending_first[li] = first; pending_cnt[li] = cnt;
+          }
+          drain(li); drain(li ^ 1);
+          return (int)PC_OK;
+        }
+      }
+    }
     // software pipeline over the lanes: polynomial k+1 accumulates while k's tail drains
     std::vector<pc_job> jobs(n_polys);
     for (size_t k = 0; k < n_polys; k++) {

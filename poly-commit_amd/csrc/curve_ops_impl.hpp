@@ -24,6 +24,10 @@ struct MsmRunnerT : MsmRunner {
     }
     plan.enqueue(bases, base_off, sdev, n, from_mont);
   }
+  void enqueue_vectors(const uint32_t* bases, uint32_t base_off, const uint64_t* ptrs_host, size_t count, size_t m, bool from_mont) override {
+    be.n_ev = 0; be.mark();
+    plan.enqueue_vectors(bases, base_off, ptrs_host, count, m, from_mont);
+  }
   void finish(uint32_t* out_host) override { plan.finish(out_host); }
 };
 

@@ -75,6 +75,12 @@ struct MsmGeom {
   uint32_t pt_stride;  // words between consecutive points of the array the accumulate kernel gathers from
   uint32_t m_sub;      // 0: one MSM.  else the n scalars are n / m_sub independent MSMs of m_sub pairs over the SAME
                        // bases (table mode only): sub-MSM s owns bucket set s, scalar i adds table[w][i mod m_sub]
+  const uint64_t* scalar_tab;   // many-MSM mode, optional: device array of one scalar-vector address per sub-MSM (the
+                                // polynomials of a batch lie in separate buffers); null: one contiguous n x Fr array
+  // address of scalar i = (sub, j)
+  PC_HD const uint32_t* scalar_at(const uint32_t* scalars, uint32_t i, uint32_t sub, uint32_t j, int fr_words) const {
+    return scalar_tab ? reinterpret_cast<const uint32_t*>(scalar_tab[sub]) + (size_t)j * fr_words : scalars + (size_t)i * fr_words;
+  }
   PC_HD uint32_t key_window(uint32_t w, uint32_t sub) const { return m_sub ? sub : tbl_stride ? 0u : w; }
   PC_HD uint32_t base_index(uint32_t w, uint32_t j) const { return tbl_stride ? w * tbl_stride + base_off + j : base_off + j; }
   // scalar i -> (sub-MSM, position inside it)
@@ -125,8 +131,8 @@ struct DigitsHistBody {
   const uint32_t* scalars;   // n x FrP::N
   uint32_t* hist;            // NB counters (zeroed)
   PC_HD void operator()(uint32_t i) const {
-    ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
     uint32_t carry = 0, sub, j; g.split(i, sub, j);
+    ScalarDigits<FrP> sd; sd.load(g.scalar_at(scalars, i, sub, j, FrP::N), g.from_mont);
     const uint32_t half = 1u << (g.c - 1);
     sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
       uint32_t raw = bits + carry;
@@ -148,8 +154,8 @@ struct ScatterBody {
   uint32_t* cursor;          // NB, initialised to the bucket offsets
   uint32_t* entries;         // M = offsets[NB] slots
   PC_HD void operator()(uint32_t i) const {
-    ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, g.from_mont);
     uint32_t carry = 0, sub, j; g.split(i, sub, j);
+    ScalarDigits<FrP> sd; sd.load(g.scalar_at(scalars, i, sub, j, FrP::N), g.from_mont);
     const uint32_t half = 1u << (g.c - 1);
     sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
       uint32_t raw = bits + carry;
@@ -621,6 +627,7 @@ class MsmPlan {
     void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_};
     for (void* p : ps) be_.free(p);
     be_.free_host(result_host_);
+    be_.free(tab_); be_.free_host(tab_host_); tab_ = nullptr; tab_host_ = nullptr;
     hist_ = offsets_ = cursor_ = entries_ = buckets_ = scalars_ = red_ = nullptr; pk_[0] = pk_[1] = pp_[0] = pp_[1] = nullptr;
     result_host_ = nullptr;
   }
@@ -638,13 +645,25 @@ class MsmPlan {
 
   // All device work of one MSM plus the asynchronous download of the <= W*levels partial
   // sums; returns as soon as everything is queued on the backend's stream.
-  void enqueue(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont) {
+  // many-MSM mode with the scalar vectors in separate device buffers: `count` <= subs vectors of m scalars each
+  // (sub-MSM k reads ptrs[k]); the bucket sets of the missing ones stay empty.
+  void enqueue_vectors(const uint32_t* bases_dev, uint32_t base_off, const uint64_t* ptrs_host, size_t count, size_t m, bool from_mont) {
+    if (!subs_ || count > subs_ || count * m > n_max_) throw MsmCapacityError("MsmPlan: batch exceeds the plan");
+    if (!tab_) { tab_ = (uint64_t*)be_.alloc((size_t)subs_ * 8); tab_host_ = (uint64_t*)be_.alloc_host((size_t)subs_ * 8); }
+    for (size_t k = 0; k < count; k++) tab_host_[k] = ptrs_host[k];
+    be_.copy_h2d(tab_, tab_host_, count * 8);
+    enqueue(bases_dev, base_off, nullptr, count * m, from_mont, m, tab_);
+  }
+
+  void enqueue(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont,
+               size_t m_sub = 0, const uint64_t* scalar_tab = nullptr) {
     pending_empty_ = (n == 0);
     if (n == 0) return;
     plan_geometry(n);
     MsmGeom g = g_;
     g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
-    g.m_sub = subs_ ? (uint32_t)(n / subs_) : 0u;
+    g.m_sub = subs_ ? (uint32_t)(m_sub ? m_sub : n / subs_) : 0u;
+    g.scalar_tab = scalar_tab;
     const size_t Mmax = n * g.Wd;
     uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / (g.tbl_stride ? cfg_.tbl_target_lanes : cfg_.target_lanes));
     if (T < min_T_) T = min_T_;
@@ -734,7 +753,7 @@ class MsmPlan {
     g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = subs_ ? subs_ : tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u; g_.m_sub = 0;
     g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.pt_stride = tbl ? cfg_.tbl_pt_stride : (uint32_t)AW;
-    g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b;
+    g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b; g_.scalar_tab = nullptr;
     uint32_t m = g_.nb_win; n_levels_ = 0;
     uint32_t kbits = 0; arr_exp_.clear();
     while (m > 1) {
@@ -787,6 +806,7 @@ class MsmPlan {
   uint32_t n_levels_; uint32_t lvl_K_[32]; uint32_t lvl_m_[32]; uint32_t lvl_bits_[32]; uint32_t lvl_narr_[32];
   std::vector<uint32_t> arr_exp_;   // log2 weight of every array after S at the last level
   uint32_t* result_host_ = nullptr;   // pinned
+  uint64_t* tab_ = nullptr; uint64_t* tab_host_ = nullptr;   // scalar-vector addresses of enqueue_vectors (device / pinned)
   bool pending_empty_ = true;
 };
 

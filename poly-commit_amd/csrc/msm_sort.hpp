@@ -23,12 +23,13 @@ struct SortGeom {
   uint32_t n, c, W, nb_win, NB, base_off, from_mont, Wd, tbl_stride, m_sub;
   uint32_t fine_bits, cb, ncw /* coarse bins per window */, NC /* total coarse bins */, S /* scalars per block */, nblocks;
   uint32_t top_w, top_fine_bits;   // the last window only uses 2^(tb-1) buckets: it gets its own (smaller) fine width
+  const uint64_t* scalar_tab;      // see MsmGeom
 };
 
 inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   SortGeom s;
   s.n = g.n; s.c = g.c; s.W = g.W; s.nb_win = g.nb_win; s.NB = g.NB; s.base_off = g.base_off; s.from_mont = g.from_mont;
-  s.Wd = g.Wd; s.tbl_stride = g.tbl_stride; s.m_sub = g.m_sub;
+  s.Wd = g.Wd; s.tbl_stride = g.tbl_stride; s.m_sub = g.m_sub; s.scalar_tab = g.scalar_tab;
   uint32_t bbits = g.c - 1;                               // bucket bits per window
   uint32_t cb_max = 0; while ((2u << cb_max) * g.W <= 32768u) cb_max++;
   uint32_t cb = bbits > 8 ? bbits - 8 : 0;
@@ -63,9 +64,10 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
   const uint32_t hi = (sg.n - lo > sg.S) ? lo + sg.S : sg.n;
   const uint32_t half = 1u << (sg.c - 1);
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    ScalarDigits<FrP> sd; sd.load(scalars + (size_t)i * FrP::N, sg.from_mont);
     uint32_t carry = 0, sub = 0, j = i;
     if (sg.m_sub) { sub = i / sg.m_sub; j = i - sub * sg.m_sub; }      // many-MSM mode: bucket set `sub`
+    ScalarDigits<FrP> sd;
+    sd.load(sg.scalar_tab ? reinterpret_cast<const uint32_t*>(sg.scalar_tab[sub]) + (size_t)j * FrP::N : scalars + (size_t)i * FrP::N, sg.from_mont);
     sd.for_each_window(sg.c, sg.Wd, [&](uint32_t w, uint32_t bits) {
       uint32_t raw = bits + carry;
       carry = raw > half;

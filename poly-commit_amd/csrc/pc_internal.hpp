@@ -19,6 +19,8 @@ namespace pc {
 struct MsmRunner {
   virtual ~MsmRunner() {}
   virtual void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) = 0;
+  // many-MSM runners only: `count` scalar vectors of m elements each in separate device buffers (a batch of polynomials)
+  virtual void enqueue_vectors(const uint32_t* bases, uint32_t base_off, const uint64_t* ptrs_host, size_t count, size_t m, bool from_mont) = 0;
   virtual void finish(uint32_t* out_host) = 0;
 };
 

@@ -139,6 +139,32 @@ static void run_many(const uint32_t* bases, size_t m, const uint32_t* scalars, s
   pc::MsmPlan<C, CpuStepBackend> plan(be, B * m, cfg, (uint32_t)B);
   plan.run(bases, 0, scalars, B * m, from_mont != 0, out);
 }
+// the same with the scalar vectors in separate buffers and fewer vectors than bucket sets (pc_hip_msm_batch's fast path)
+template <class C>
+static void run_many_vectors(const uint32_t* bases, size_t n_srs, size_t base_off, size_t m, const uint32_t* const* vecs, size_t count, size_t B, int c,
+                             int from_mont, uint32_t* out) {
+  CpuStepBackend be;
+  constexpr int AW = 2 * pc::Fd<typename C::FqP>::N;
+  const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, (uint32_t)c);
+  std::vector<uint32_t> table((size_t)Wd * n_srs * AW);
+  { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data(), (uint32_t)AW}; be.launch(b, n_srs); }
+  pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_pt_stride = AW; cfg.tbl_min_n = 1;
+  cfg.tbl_K0 = 4; cfg.K1 = 16; cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3;
+  pc::MsmPlan<C, CpuStepBackend> plan(be, B * m, cfg, (uint32_t)B);
+  std::vector<uint64_t> ptrs(count);
+  for (size_t k = 0; k < count; k++) ptrs[k] = (uint64_t)(uintptr_t)vecs[k];
+  plan.enqueue_vectors(bases, (uint32_t)base_off, ptrs.data(), count, m, from_mont != 0);
+  plan.finish(out);
+}
+extern "C" void emu_msm_many_vectors(int curve, const uint32_t* bases, size_t n_srs, size_t base_off, size_t m, const uint32_t* const* vecs, size_t count,
+                                     size_t B, int c, int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: run_many_vectors<pc_curve_bls12_381>(bases, n_srs, base_off, m, vecs, count, B, c, from_mont, out); break;
+    case 1: run_many_vectors<pc_curve_bn254>(bases, n_srs, base_off, m, vecs, count, B, c, from_mont, out); break;
+    case 2: run_many_vectors<pc_curve_pallas>(bases, n_srs, base_off, m, vecs, count, B, c, from_mont, out); break;
+  }
+}
+
 extern "C" void emu_msm_many(int curve, const uint32_t* bases, size_t m, const uint32_t* scalars, size_t B, int c, int K0,
                              int from_mont, uint32_t* out) {
   switch (curve) {

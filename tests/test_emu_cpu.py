@@ -412,3 +412,21 @@ def test_srs_decode_ark_serialize_stepped(curve, compressed):
     bad = emu().emu_srs_decode(O.CURVES[curve], body2.ctypes.data_as(C.POINTER(C.c_uint8)), 6, 1 if compressed else 0, p32(out.view(np.uint32)))
     if not compressed:
         assert bad == 1
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_batch_over_key_table_stepped(curve):
+    """pc_hip_msm_batch's fast path: several polynomials of equal length in SEPARATE buffers go through one many-MSM
+    pass over the key's own window table (bucket set k = polynomial k), here with fewer polynomials than bucket sets,
+    a base offset and Montgomery scalars."""
+    n_srs, off, m, B, count, c = 60, 7, 40, 4, 3, 6
+    b = O.gen_bases(curve, n_srs)
+    vecs = [O.gen_scalars(curve, 0x7A0 + k, m) for k in range(count)]
+    mont = [O.f_to_mont(curve, 1, v) for v in vecs]
+    arr = (C.c_void_p * count)(*[v.ctypes.data for v in mont])
+    out = np.zeros((B, 2 * O.fq_limbs(curve)), dtype=np.uint64)
+    emu().emu_msm_many_vectors(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(n_srs), C.c_size_t(off), C.c_size_t(m), arr, C.c_size_t(count),
+                               C.c_size_t(B), c, 1, p32(out.view(np.uint32)))
+    for k in range(count):
+        assert (out[k] == O.msm_naive(curve, np.ascontiguousarray(b[off:off + m]), vecs[k])).all(), k
+    assert not out[count:].any()

@@ -397,3 +397,27 @@ def test_msm_many_and_precompute_argument_errors(ctx):
     assert lib.pc_hip_srs_precompute(ctx.h, srs.h, 24, 0) == -1
     assert lib.pc_hip_srs_precompute(None, srs.h, 0, 0) == -1
     srs.free()
+
+
+@pytest.mark.parametrize("curve,k", [("bn254", 11), ("bls12_381", 3)])
+def test_msm_batch_fast_path_over_window_table(ctx, curve, k):
+    """pc_hip_msm_batch with equal-length device-resident polynomials and a window table: groups of 8 polynomials per
+    many-MSM pass (here 8 + 3, resp. one group of 3), a base offset, against the oracle -- and the same batch on the
+    per-polynomial path (no table) gives the same points."""
+    import torch
+    n_srs, off, m = 40000, 5, 30000
+    b = O.gen_bases(curve, n_srs)
+    host = [O.gen_scalars(curve, 0x8B0 + j, m) for j in range(k)]
+    dev = [torch.from_numpy(O.f_to_mont(curve, 1, h).view(np.int64)).cuda() for h in host]
+    srs = ctx.upload_srs(curve, b)
+    slow = srs.msm_batch([t.data_ptr() for t in dev], [m] * k, base_offsets=[off] * k)
+    srs.precompute(min_pairs=1)
+    fast = srs.msm_batch([t.data_ptr() for t in dev], [m] * k, base_offsets=[off] * k)
+    assert (fast == slow).all()
+    for j in (0, k // 2, k - 1):
+        assert (fast[j] == O.msm_pippenger(curve, np.ascontiguousarray(b[off:off + m]), host[j], 8, 1)).all(), j
+    # unequal lengths fall back to the per-polynomial pipelines
+    lens = [m - j for j in range(k)]
+    mixed = srs.msm_batch([t.data_ptr() for t in dev], lens, base_offsets=[off] * k)
+    assert (mixed[k - 1] == O.msm_pippenger(curve, np.ascontiguousarray(b[off:off + lens[-1]]), host[-1][:lens[-1]], 8, 1)).all()
+    srs.free()
