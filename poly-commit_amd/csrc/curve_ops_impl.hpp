@@ -1,7 +1,9 @@
 // Instantiation of everything templated on one curve; each curve_<name>.hip includes this header and
 // defines one CurveOps table (pc_internal.hpp).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "pc_internal.hpp"
 #include "hip_backend_msm.hpp"
 #include "ipa.hpp"
@@ -33,9 +35,10 @@ struct MsmRunnerT : MsmRunner {
 
 template <class C>
 void build_window_table(HipBackend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride) {
-  WindowTableBody<C> b{bases, n, c, Wd, table, stride};
-  be.launch(b, n, 64);
-  be.sync();
+  // PC_HIP_TABLE_BUILD=serial: one lane per base walking its chain and inverting at every window (the round-1 build)
+  static const bool serial = []() { const char* e = getenv("PC_HIP_TABLE_BUILD"); return e && !strcmp(e, "serial"); }();
+  if (serial) { WindowTableBody<C> b{bases, n, c, Wd, table, stride}; be.launch(b, n, 64); be.sync(); }
+  else build_window_table_batched<C>(be, bases, n, c, Wd, table, stride);
 }
 
 // key[i] = affine(key[i] + u * key[half + i]): GLV split of the shared challenge on the host, one ladder per lane
@@ -74,9 +77,42 @@ struct CurveOpsImpl {
     ec_fold_run<C>(be, key, half, u_mont);
   }
   static void fixed_base(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out) {
-    FixedBaseMulBody<C> body; body.scalars = scalars; body.out = out;
-    for (int i = 0; i < AW; i++) body.g[i] = g[i];
-    be.launch(body, n, 64); be.sync();
+    if (n < 4096) {          // a handful of scalars: the per-lane ladder, no table
+      FixedBaseMulBody<C> body; body.scalars = scalars; body.out = out;
+      for (int i = 0; i < AW; i++) body.g[i] = g[i];
+      be.launch(body, n, 64); be.sync();
+      return;
+    }
+    // window table of the fixed base on the host: T[w][d-1] = d * 2^(8 w) * g, d = 1..128 (one inversion for all of it)
+    typedef host64::Xyzz64<C> P64;
+    constexpr int FW = C::FqP::N, XW = XyzzD<C>::WORDS;
+    const uint32_t Wd = msm_num_windows(C::FrP::BITS, FIXED_BASE_C), half = 1u << (FIXED_BASE_C - 1);
+    std::vector<uint32_t> xyzz((size_t)Wd * half * XW), tbl((size_t)Wd * half * AW);
+    P64 base = P64::infinity();
+    bool inf = true; for (int i = 0; i < AW; i++) inf &= g[i] == 0;
+    if (!inf) { base.X = P64::Fq::load(g); base.Y = P64::Fq::load(g + FW); base.ZZ = P64::Fq::one(); base.ZZZ = P64::Fq::one(); }
+    for (uint32_t w = 0; w < Wd; w++) {
+      P64 cur = base;
+      for (uint32_t d = 0; d < half; d++) {
+        cur.X.store(&xyzz[((size_t)w * half + d) * XW]); cur.Y.store(&xyzz[((size_t)w * half + d) * XW + FW]);
+        cur.ZZ.store(&xyzz[((size_t)w * half + d) * XW + 2 * FW]); cur.ZZZ.store(&xyzz[((size_t)w * half + d) * XW + 3 * FW]);
+        cur.add(base);
+      }
+      for (uint32_t k = 0; k < FIXED_BASE_C; k++) base = base.dbl();
+    }
+    host64::batch_to_affine<C>(xyzz.data(), (size_t)Wd * half, tbl.data());
+    // device: table | XYZZ results | prefix products
+    const size_t tb = tbl.size() * 4, rb = n * (size_t)XW * 4, sb = n * (size_t)FW * 4;
+    uint8_t* ws = (uint8_t*)be.workspace(tb + rb + sb);
+    uint32_t* dtbl = (uint32_t*)ws; uint32_t* dres = (uint32_t*)(ws + tb); uint32_t* dscr = (uint32_t*)(ws + tb + rb);
+    be.copy_h2d(dtbl, tbl.data(), tb);
+    be.sync();                                   // the host vectors go out of scope below
+    FixedBaseTableMulBody<C> body{scalars, dtbl, Wd, dres};
+    be.launch(body, n, 64);
+    const uint32_t K = 16;
+    XyzzBatchAffineBody<C> nb{dres, dscr, out, (uint32_t)n, K};
+    be.launch(nb, (n + K - 1) / K, 64);
+    be.sync();
   }
   static uint32_t srs_decode(HipBackend& be, const uint8_t* bytes_dev, size_t n, int compressed, uint32_t* out) {
     uint32_t* bad = (uint32_t*)be.workspace(4);

@@ -164,6 +164,7 @@ struct JacBatchAffineBody {
   uint32_t* scratch;        // n x Fq
   uint32_t* out;            // n affine points, (0,0) = infinity
   uint32_t n, K;
+  uint32_t out_stride = AW; // words between consecutive output points (>= AW)
   PC_HD void operator()(uint32_t t) const {
     const uint32_t s = t * K, e = (n - s > K) ? s + K : n;
     Fq run = Fq::one();
@@ -183,7 +184,7 @@ struct JacBatchAffineBody {
         const Fq zi2 = zi.sqr();
         a.x = Fq::load(p).mul(zi2); a.y = Fq::load(p + FN).mul(zi2).mul(zi);
       }
-      a.store(out + (size_t)j * AW);
+      a.store(out + (size_t)j * out_stride);
     }
   }
 };

@@ -15,7 +15,7 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   if (sort_mode < 0) { const char* e = getenv("PC_HIP_SORT"); sort_mode = (e && !strcmp(e, "atomic")) ? 0 : 1; }
   if (sort_mode == 0) { sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return; }
   SortGeom sg = make_sort_geom(g, C::FrP::BITS);
-  if (sg.fine_bits > 10 || sg.NC > 16384) {   // c > 22, or more bucket sets than the LDS histogram holds
+  if (sg.fine_bits > 11 || sg.NC > 16384) {   // wider than the fine pass's LDS histogram, or more bucket sets than the coarse one holds
     sort_entries_atomic<C>(*this, g, scalars, hist, offsets, cursor, entries); return;
   }
   // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)

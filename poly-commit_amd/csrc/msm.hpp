@@ -457,6 +457,54 @@ struct WindowTableBody {
   }
 };
 
+// The same table with one inversion per 16 points instead of one per point: the doubling chains of all bases advance
+// window by window (Jacobian state in a scratch buffer), and each window's n points are normalised by
+// JacBatchAffineBody (Montgomery's trick along a lane's run).  ~1750 instead of ~5700 field products per base at
+// c = 22: 2.05 s -> 0.7 s for the 19 GB table of a 2^24-point BLS12-381 key.
+template <class C>
+struct TableInitBody {          // table[0][i] = P_i, state[i] = P_i (Jacobian)
+  static constexpr int FN = Fd<typename C::FqP>::N, AW = 2 * FN;
+  const uint32_t* bases; uint32_t* table; uint32_t stride; uint32_t* state;
+  PC_HD void operator()(uint32_t i) const {
+    const AffD<C> p = AffD<C>::load(bases + (size_t)i * AW);
+    p.store(table + (size_t)i * stride);
+    uint32_t* o = state + (size_t)i * 3 * FN;
+    if (p.is_inf()) { Fd<typename C::FqP>::zero().store(o); Fd<typename C::FqP>::zero().store(o + FN); Fd<typename C::FqP>::zero().store(o + 2 * FN); }
+    else { p.x.store(o); p.y.store(o + FN); Fd<typename C::FqP>::one().store(o + 2 * FN); }
+  }
+};
+template <class C>
+struct TableDoubleBody {        // state[i] = 2^c * state[i]
+  typedef Fd<typename C::FqP> Fq;
+  static constexpr int FN = Fq::N;
+  uint32_t* state; uint32_t c;
+  PC_HD void operator()(uint32_t i) const {
+    uint32_t* o = state + (size_t)i * 3 * FN;
+    JacD<C> a; a.X = Fq::load(o); a.Y = Fq::load(o + FN); a.Z = Fq::load(o + 2 * FN);
+    for (uint32_t k = 0; k < c; k++) a = a.dbl();
+    if (a.is_inf()) { Fq::zero().store(o); Fq::zero().store(o + FN); Fq::zero().store(o + 2 * FN); }
+    else { a.X.store(o); a.Y.store(o + FN); a.Z.store(o + 2 * FN); }
+  }
+};
+template <class C, class Backend>
+void build_window_table_batched(Backend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride,
+                                uint32_t K = 16) {
+  constexpr int FN = Fd<typename C::FqP>::N;
+  if (!n) return;
+  uint32_t* state = (uint32_t*)be.alloc((size_t)n * 4 * FN * 4);      // Jacobian state | prefix products
+  try {
+    uint32_t* scratch = state + (size_t)n * 3 * FN;
+    { TableInitBody<C> b{bases, table, stride, state}; be.launch(b, n); }
+    for (uint32_t w = 1; w < Wd; w++) {
+      { TableDoubleBody<C> b{state, c}; be.launch(b, n); }
+      JacBatchAffineBody<C> nb{state, scratch, table + (size_t)w * n * stride, n, K, stride};
+      be.launch(nb, (n + K - 1) / K);
+    }
+    be.sync();
+  } catch (...) { be.free(state); throw; }
+  be.free(state);
+}
+
 // window width for the table mode: n * (bits/c + 1) mixed adds against ~3 * 2^(c-1) reduction adds
 inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255) {
   uint32_t best = 8; double best_cost = 1e300;

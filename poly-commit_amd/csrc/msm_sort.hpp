@@ -15,6 +15,7 @@
 // accumulate kernel consumes; the order inside a bucket is irrelevant (the sum is commutative).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "msm.hpp"
 
 namespace pc {
@@ -32,7 +33,11 @@ inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   s.Wd = g.Wd; s.tbl_stride = g.tbl_stride; s.m_sub = g.m_sub; s.scalar_tab = g.scalar_tab;
   uint32_t bbits = g.c - 1;                               // bucket bits per window
   uint32_t cb_max = 0; while ((2u << cb_max) * g.W <= 32768u) cb_max++;
-  uint32_t cb = bbits > 8 ? bbits - 8 : 0;
+  // fine width: buckets per coarse bin = 2^fine (<= 2048, the LDS histogram of the fine pass).  Fewer, larger coarse bins
+  // make the runs a workgroup appends to a bin longer (its 8-byte records then complete 32-byte sectors while they are
+  // still in L2); PC_HIP_FINE_BITS overrides (tuning).
+  static const uint32_t fine_target = []() { const char* e = getenv("PC_HIP_FINE_BITS"); int v = e ? atoi(e) : 8; return (uint32_t)(v < 4 ? 4 : v > 11 ? 11 : v); }();
+  uint32_t cb = bbits > fine_target ? bbits - fine_target : 0;
   if (cb > cb_max) cb = cb_max;
   s.cb = cb; s.fine_bits = bbits - cb; s.ncw = 1u << cb; s.NC = g.W * s.ncw;
   // The top window holds tb = bits - (W-1)*c scalar bits, i.e. only 2^tb of its 2^(c-1) buckets are reachable.
@@ -118,7 +123,7 @@ static __global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32
 
 static __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
                                                   uint32_t* offsets) {
-  __shared__ uint32_t h[2048];        // [0, F): counts / cursors; [F, 2F): scan ping-pong
+  __shared__ uint32_t h[4096];        // [0, F): counts / cursors; [F, 2F): scan ping-pong   (F <= 2048)
   const uint32_t k = blockIdx.x, start = binbase[k], end = binbase[k + 1];
   const uint32_t w = k / sg.ncw, cbin = k % sg.ncw;
   const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;

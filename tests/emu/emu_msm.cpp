@@ -296,6 +296,50 @@ extern "C" void emu_glv_fold_batched(int curve, uint32_t* key, size_t half, cons
   }
 }
 
+// the batched window-table build against the one-lane-per-base build (both are what the GPU runs)
+template <class C>
+static int table_builds_agree(const uint32_t* bases, uint32_t n, uint32_t c, uint32_t stride, uint32_t K) {
+  const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, c);
+  std::vector<uint32_t> a((size_t)Wd * n * stride, 0xabababab), b((size_t)Wd * n * stride, 0xabababab);
+  CpuStepBackend be;
+  { pc::WindowTableBody<C> body{bases, n, c, Wd, a.data(), stride}; be.launch(body, n); }
+  pc::build_window_table_batched<C>(be, bases, n, c, Wd, b.data(), stride, K);
+  return a == b;
+}
+extern "C" int emu_table_builds_agree(int curve, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t stride, uint32_t K) {
+  switch (curve) {
+    case 0: return table_builds_agree<pc_curve_bls12_381>(bases, n, c, stride, K);
+    case 1: return table_builds_agree<pc_curve_bn254>(bases, n, c, stride, K);
+    default: return table_builds_agree<pc_curve_pallas>(bases, n, c, stride, K);
+  }
+}
+
+// fixed-base window-table multiplication + XYZZ batch normalisation, stepped (table built with the device bodies' host twins)
+template <class C>
+static void fixed_base_table(const uint32_t* g, const uint32_t* scalars_mont, size_t n, uint32_t K, uint32_t* out) {
+  constexpr int AW = 2 * pc::Fd<typename C::FqP>::N, XW = pc::XyzzD<C>::WORDS, FW = pc::Fd<typename C::FqP>::N;
+  const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, pc::FIXED_BASE_C), half = 1u << (pc::FIXED_BASE_C - 1);
+  std::vector<uint32_t> tbl((size_t)Wd * half * AW), res(n * XW), scr(n * FW);
+  pc::XyzzD<C> base = pc::XyzzD<C>::from_affine(pc::AffD<C>::load(g));
+  for (uint32_t w = 0; w < Wd; w++) {
+    pc::XyzzD<C> cur = base;
+    for (uint32_t d = 0; d < half; d++) { cur.to_affine().store(&tbl[((size_t)w * half + d) * AW]); cur.add(base); }
+    for (uint32_t k = 0; k < pc::FIXED_BASE_C; k++) base = base.dbl();
+  }
+  CpuStepBackend be;
+  pc::FixedBaseTableMulBody<C> body{scalars_mont, tbl.data(), Wd, res.data()};
+  be.launch(body, n);
+  pc::XyzzBatchAffineBody<C> nb{res.data(), scr.data(), out, (uint32_t)n, K};
+  be.launch(nb, (n + K - 1) / K);
+}
+extern "C" void emu_fixed_base_table(int curve, const uint32_t* g, const uint32_t* scalars_mont, size_t n, uint32_t K, uint32_t* out) {
+  switch (curve) {
+    case 0: fixed_base_table<pc_curve_bls12_381>(g, scalars_mont, n, K, out); break;
+    case 1: fixed_base_table<pc_curve_bn254>(g, scalars_mont, n, K, out); break;
+    case 2: fixed_base_table<pc_curve_pallas>(g, scalars_mont, n, K, out); break;
+  }
+}
+
 // ark-serialize bytes -> affine points (SrsDecodeBody), stepped
 template <class C>
 static uint32_t srs_decode(const uint8_t* in, uint32_t n, int compressed, uint32_t* out) {

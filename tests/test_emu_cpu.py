@@ -430,3 +430,34 @@ def test_msm_batch_over_key_table_stepped(curve):
     for k in range(count):
         assert (out[k] == O.msm_naive(curve, np.ascontiguousarray(b[off:off + m]), vecs[k])).all(), k
     assert not out[count:].any()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_fixed_base_window_table_mul_stepped(curve):
+    """`g.batch_mul(scalars)` (KZG10::setup, kzg10/mod.rs:76,83) with the fixed-base window table: signed radix-256
+    digits, one mixed addition per window, XYZZ results normalised K at a time -- against Python big ints, including
+    0, 1, r - 1 and scalars whose top window only receives the recoding carry."""
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    G = R.gen_bases(curve, 4)[3]
+    ks = [0, 1, 2, 127, 128, 129, 255, 256, p - 1, p - 2, (1 << 200) - 1, 0x8080808080808080, (p >> 1) | 0xFF] + R.gen_scalars(fr, 0xF1, 9)
+    ks = [k % p for k in ks]
+    sc = O.fr_mont_array(curve, ks)
+    g = O.points_to_array(curve, [G])[0]
+    want = [R.ec_mul(curve, k, G) for k in ks]
+    for K in (1, 5, 16):
+        out = np.zeros((len(ks), 2 * O.fq_limbs(curve)), dtype=np.uint64)
+        emu().emu_fixed_base_table(O.CURVES[curve], p32(g.view(np.uint32)), p32(sc.view(np.uint32)), C.c_size_t(len(ks)), K, p32(out.view(np.uint32)))
+        assert O.array_to_points(curve, out) == want, K
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_window_table_batched_build_equals_serial_build(curve):
+    """pc_hip_srs_precompute's table: the window-by-window build with batched normalisation writes exactly what the
+    one-lane-per-base build writes (incl. an infinity base and padded entries), for two window widths."""
+    n = 11
+    b = O.gen_bases(curve, n)
+    b[4] = 0
+    aw = b.shape[1] * 2
+    for c, stride, K in ((13, aw, 4), (22, aw + 8, 16)):
+        assert emu().emu_table_builds_agree(O.CURVES[curve], p32(b.view(np.uint32)), n, c, stride, K) == 1, (c, stride)
