@@ -1,6 +1,12 @@
 set -x
 mkdir -p gpurun_out
 make -s -C oracle
+if ! timeout -k 10 300 python -m pytest tests/test_msm_gpu.py -m gpu -q -x -k "window_table" > gpurun_out/f_sanity.log 2>&1; then
+  tail -30 gpurun_out/f_sanity.log
+  PC_HIP_TABLE_BUILD=serial timeout -k 10 300 python -m pytest tests/test_msm_gpu.py -m gpu -q -x -k "window_table" 2>&1 | tail -5
+  exit 1
+fi
+tail -3 gpurun_out/f_sanity.log
 timeout -k 10 1500 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/f_pytest.log 2>&1; tail -8 gpurun_out/f_pytest.log
 for fb in 8 9 10 11; do
   PC_HIP_FINE_BITS=$fb timeout -k 10 300 python bench.py --no-cpu-baseline --no-h2d > gpurun_out/f_fb$fb.json 2>/dev/null
