@@ -33,8 +33,11 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
     PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  // a large LDS histogram leaves one workgroup per CU: make it 16 waves so latency stays hidden
-  const int sort_threads = lds > 32 * 1024 ? 1024 : 256;
+  // 512 workgroups cover the chip twice at most: with 256 lanes each that is 2 waves per SIMD for two passes that are bound
+  // by DRAM latency (a scalar load, ~13 LDS atomics and as many 8-byte stores per lane and iteration).  16 waves per workgroup
+  // give 8 per SIMD; the LDS histogram (<= 64 KiB) still allows two workgroups per CU.  PC_HIP_SORT_THREADS overrides (tuning).
+  static const int threads_env = []() { const char* e = getenv("PC_HIP_SORT_THREADS"); return e ? atoi(e) : 0; }();
+  const int sort_threads = threads_env ? threads_env : (lds > 32 * 1024 || g.n >= 65536) ? 1024 : 256;
   hipLaunchKernelGGL((k_sort_pass<C, false>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)nullptr, (uint2*)nullptr);
   PC_HIP_CHECK(hipGetLastError());
   mark();   // 1: digits + coarse histogram

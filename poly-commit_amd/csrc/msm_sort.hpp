@@ -130,7 +130,16 @@ static __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uin
   const uint32_t F = 1u << fb;
   for (uint32_t f = threadIdx.x; f < F; f += 256) h[f] = 0;
   __syncthreads();
-  for (uint32_t r = start + threadIdx.x; r < end; r += 256) atomicAdd(&h[records[r].y], 1u);
+  // (four records in flight per lane: one load per iteration left the pass waiting on DRAM latency -- a bin is walked by
+  // one workgroup, ~100 iterations per lane at 2^24)
+  {
+    uint32_t r = start + threadIdx.x;
+    for (; r + 768 < end; r += 1024) {
+      const uint32_t f0 = records[r].y, f1 = records[r + 256].y, f2 = records[r + 512].y, f3 = records[r + 768].y;
+      atomicAdd(&h[f0], 1u); atomicAdd(&h[f1], 1u); atomicAdd(&h[f2], 1u); atomicAdd(&h[f3], 1u);
+    }
+    for (; r < end; r += 256) atomicAdd(&h[records[r].y], 1u);
+  }
   __syncthreads();
   // inclusive Hillis-Steele scan over F counters, ping-pong between h[0..F) and h[F..2F)
   uint32_t src = 0;
@@ -158,10 +167,18 @@ static __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uin
     if (k + 1 == sg.NC && threadIdx.x == 0) offsets[sg.NB] = end;
   }
   __syncthreads();
-  for (uint32_t r = start + threadIdx.x; r < end; r += 256) {
-    uint2 rec = records[r];
-    uint32_t pos = atomicAdd(&h[rec.y], 1u);
-    entries[pos] = rec.x;
+  {
+    uint32_t r = start + threadIdx.x;
+    for (; r + 768 < end; r += 1024) {
+      const uint2 a = records[r], b = records[r + 256], c = records[r + 512], d = records[r + 768];
+      const uint32_t pa = atomicAdd(&h[a.y], 1u), pb = atomicAdd(&h[b.y], 1u), pc = atomicAdd(&h[c.y], 1u), pd = atomicAdd(&h[d.y], 1u);
+      entries[pa] = a.x; entries[pb] = b.x; entries[pc] = c.x; entries[pd] = d.x;
+    }
+    for (; r < end; r += 256) {
+      uint2 rec = records[r];
+      uint32_t pos = atomicAdd(&h[rec.y], 1u);
+      entries[pos] = rec.x;
+    }
   }
 }
 
