@@ -47,7 +47,7 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   mark();   // 2: scans
   hipLaunchKernelGGL((k_sort_pass<C, true>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)binbase, records);
   PC_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_sort_fine, dim3(sg.NC), dim3(256), 0, stream, sg, (const uint32_t*)binbase, (const uint2*)records, entries, offsets);
+  hipLaunchKernelGGL(k_sort_fine, dim3(sg.NC), dim3(FT), 0, stream, sg, (const uint32_t*)binbase, (const uint2*)records, entries, offsets);
   PC_HIP_CHECK(hipGetLastError());
   mark();   // 3: coarse scatter + fine sort
 }

@@ -121,30 +121,34 @@ static __global__ void __launch_bounds__(256) k_sort_binscan(uint32_t* G, uint32
   if (blockIdx.x == 0 && threadIdx.x == 0) bintotal[NC] = 0;
 }
 
-static __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
+#ifndef PC_SORT_FINE_THREADS
+#define PC_SORT_FINE_THREADS 256
+#endif
+static constexpr uint32_t FT = PC_SORT_FINE_THREADS;      // lanes of the fine pass (one workgroup per coarse bin)
+static __global__ void __launch_bounds__(PC_SORT_FINE_THREADS) k_sort_fine(SortGeom sg, const uint32_t* binbase, const uint2* records, uint32_t* entries,
                                                   uint32_t* offsets) {
   __shared__ uint32_t h[4096];        // [0, F): counts / cursors; [F, 2F): scan ping-pong   (F <= 2048)
   const uint32_t k = blockIdx.x, start = binbase[k], end = binbase[k + 1];
   const uint32_t w = k / sg.ncw, cbin = k % sg.ncw;
   const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
   const uint32_t F = 1u << fb;
-  for (uint32_t f = threadIdx.x; f < F; f += 256) h[f] = 0;
+  for (uint32_t f = threadIdx.x; f < F; f += FT) h[f] = 0;
   __syncthreads();
   // (four records in flight per lane: one load per iteration left the pass waiting on DRAM latency -- a bin is walked by
   // one workgroup, ~100 iterations per lane at 2^24)
   {
     uint32_t r = start + threadIdx.x;
-    for (; r + 768 < end; r += 1024) {
-      const uint32_t f0 = records[r].y, f1 = records[r + 256].y, f2 = records[r + 512].y, f3 = records[r + 768].y;
+    for (; r + 3 * FT < end; r += 4 * FT) {
+      const uint32_t f0 = records[r].y, f1 = records[r + FT].y, f2 = records[r + 2 * FT].y, f3 = records[r + 3 * FT].y;
       atomicAdd(&h[f0], 1u); atomicAdd(&h[f1], 1u); atomicAdd(&h[f2], 1u); atomicAdd(&h[f3], 1u);
     }
-    for (; r < end; r += 256) atomicAdd(&h[records[r].y], 1u);
+    for (; r < end; r += FT) atomicAdd(&h[records[r].y], 1u);
   }
   __syncthreads();
   // inclusive Hillis-Steele scan over F counters, ping-pong between h[0..F) and h[F..2F)
   uint32_t src = 0;
   for (uint32_t d = 1; d < F; d <<= 1) {
-    for (uint32_t f = threadIdx.x; f < F; f += 256) {
+    for (uint32_t f = threadIdx.x; f < F; f += FT) {
       uint32_t v = h[src + f];
       if (f >= d) v += h[src + f - d];
       h[(src ^ F) + f] = v;
@@ -154,27 +158,27 @@ static __global__ void __launch_bounds__(256) k_sort_fine(SortGeom sg, const uin
   }
   // exclusive offsets -> CSR row pointers of this bin's buckets, and the placement cursors
   const uint32_t key0 = w * sg.nb_win + (cbin << fb);
-  uint32_t excl[8];                   // F / 256 <= 8 values per lane
+  uint32_t excl[2048 / FT];           // F / FT values per lane
   uint32_t q = 0;
-  for (uint32_t f = threadIdx.x; f < F; f += 256, q++) excl[q] = start + (f ? h[src + f - 1] : 0u);
+  for (uint32_t f = threadIdx.x; f < F; f += FT, q++) excl[q] = start + (f ? h[src + f - 1] : 0u);
   __syncthreads();
   q = 0;
-  for (uint32_t f = threadIdx.x; f < F; f += 256, q++) { h[f] = excl[q]; offsets[key0 + f] = excl[q]; }
+  for (uint32_t f = threadIdx.x; f < F; f += FT, q++) { h[f] = excl[q]; offsets[key0 + f] = excl[q]; }
   if (cbin + 1 == sg.ncw) {
     // buckets of this window beyond the last bin's range (top window only) are empty: their row
     // pointers equal the end of the window
-    for (uint32_t kk = key0 + F + threadIdx.x; kk < (w + 1) * sg.nb_win; kk += 256) offsets[kk] = end;
+    for (uint32_t kk = key0 + F + threadIdx.x; kk < (w + 1) * sg.nb_win; kk += FT) offsets[kk] = end;
     if (k + 1 == sg.NC && threadIdx.x == 0) offsets[sg.NB] = end;
   }
   __syncthreads();
   {
     uint32_t r = start + threadIdx.x;
-    for (; r + 768 < end; r += 1024) {
-      const uint2 a = records[r], b = records[r + 256], c = records[r + 512], d = records[r + 768];
+    for (; r + 3 * FT < end; r += 4 * FT) {
+      const uint2 a = records[r], b = records[r + FT], c = records[r + 2 * FT], d = records[r + 3 * FT];
       const uint32_t pa = atomicAdd(&h[a.y], 1u), pb = atomicAdd(&h[b.y], 1u), pc = atomicAdd(&h[c.y], 1u), pd = atomicAdd(&h[d.y], 1u);
       entries[pa] = a.x; entries[pb] = b.x; entries[pc] = c.x; entries[pd] = d.x;
     }
-    for (; r < end; r += 256) {
+    for (; r < end; r += FT) {
       uint2 rec = records[r];
       uint32_t pos = atomicAdd(&h[rec.y], 1u);
       entries[pos] = rec.x;

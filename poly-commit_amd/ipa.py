@@ -121,6 +121,7 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     n0, s_dev, al, ar = 0, None, None, None
     while n > 1:
         h = n // 2
+        t_round = time.perf_counter()
         if not n0 and n <= fixed_key_below:
             # from here on the resident key key[0..n0) stays fixed; the folds act on the per-base factors s
             n0 = n
@@ -158,6 +159,8 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
                 ctx.ipa_key_scalars(curve, None, 0, s_dev.data_ptr(), n0, fold_u=u, fold_m=n)   # the same fold, on the factors
             else:
                 srs.ec_fold(h, u)                                           # key_l += u key_r, normalised
+        if timings is not None:
+            timings.setdefault("per_round_ms", []).append(round((time.perf_counter() - t_round) * 1e3, 3))
         n = h
     if n0:
         final_key = srs.msm(s_dev.data_ptr(), n=n0, base_offset=0, montgomery=True)[0]   # sum_j s_j K0_j

@@ -9,6 +9,7 @@ import poly_commit_amd as pc
 from poly_commit_amd import ipa
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+fkb = (1 << int(sys.argv[2])) if len(sys.argv) > 2 else None        # log2 of the size from which the key stays fixed (default: ipa.FIXED_KEY_BELOW)
 curve = "pallas"
 n = 1 << log_n
 ctx = pc.Context(0)
@@ -26,8 +27,9 @@ srs.free()
 it = iter(range(log_n))
 t = time.perf_counter()
 tm = {}
-ipa.ipa_open_rounds(ctx, curve, key[:n], cdev, n, point, key[n], lambda L, R_: ch[next(it)], timings=tm)
+ipa.ipa_open_rounds(ctx, curve, key[:n], cdev, n, point, key[n], lambda L, R_: ch[next(it)], timings=tm, fixed_key_below=fkb)
+per_round = tm.pop("per_round_ms", [])
 t_open = time.perf_counter() - t
 print(json.dumps({"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: commit MSM + {log_n} halving rounds (challenges supplied)",
                   "commit_ms": t_commit * 1e3, "open_rounds_ms": t_open * 1e3,
-                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open, "open_breakdown_ms": {k: round(v, 1) for k, v in tm.items()}}))
+                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open, "fixed_key_below": fkb or ipa.FIXED_KEY_BELOW, "open_breakdown_ms": {k: round(v, 1) for k, v in tm.items()}, "per_round_ms": per_round}))
