@@ -545,8 +545,11 @@ struct SubFoldBody {
 struct MsmConfig {
   uint32_t c = 0;            // 0 = choose from n
   uint32_t T = 0;            // 0 = choose from n*W
-  uint32_t T2 = 4;           // seg-reduce level 1 chunk: short chains beat fewer launches (measured 4 < 8 < 64)
-  uint32_t T2b = 4;          // deeper levels
+  // seg-reduce chunk lengths.  Round 1 measured 4 < 8 < 64 when every workgroup edge left a partial to reduce; since the
+  // edge merge (k_accumulate_edges) the list is empty for uniformly distributed scalars and the levels are launches without
+  // work: chunks of 8 halve their number (skewed scalars pay chains of up to 8 instead of 4 additions per level)
+  uint32_t T2 = 8;
+  uint32_t T2b = 8;          // deeper levels
   uint32_t K0 = 8;           // bucket-reduce group size of the wide levels (serial chains; measured 8 < 4 << 16)
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
