@@ -14,8 +14,8 @@ timeout -k 10 600 python bench.py --workload ntt > gpurun_out/d_bench_ntt.json 2
 timeout -k 10 600 python bench.py --workload batch > gpurun_out/d_bench_batch.json 2>/dev/null
 timeout -k 10 300 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_out/d_ipa_2p22.json
 timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/d_lincomb.json
-PC_HIP_TBL_LANES=262144 timeout -k 10 300 python bench.py --secondary-log-degree 0 --no-h2d --no-cpu-baseline > gpurun_out/d_exp_lanes18.json 2>/dev/null
-PC_HIP_TBL_LANES=524288 timeout -k 10 300 python bench.py --secondary-log-degree 0 --no-h2d --no-cpu-baseline > gpurun_out/d_exp_lanes19.json 2>/dev/null
+
+
 cd /tmp && export TMPDIR=/tmp
 B24="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --inflight 0 --secondary-log-degree 0"
 B20="python $R/bench.py --log-degree 20 --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --inflight 0 --secondary-log-degree 0"
@@ -39,7 +39,7 @@ cd $R
 find gpurun_out -name "*.csv" -size +30M -delete 2>/dev/null
 python - <<'PY'
 import json
-for f in ("d_bench_n1", "d_bench_n1_inflight0", "d_bench_n1_notable", "d_exp_lanes18", "d_exp_lanes19"):
+for f in ("d_bench_n1", "d_bench_n1_inflight0", "d_bench_n1_notable"):
     try:
         d = json.load(open(f"gpurun_out/{f}.json")); s = d.get("secondary")
         print(f, "2^24", round(d["ms_per_step"], 2), round(d["blocking_msm_ms"], 2), {k: round(v, 2) for k, v in d["msm_phase_ms"].items()},
