@@ -118,6 +118,9 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
 /* Kernel-only timing of the last MSM issued on this ctx, in milliseconds, by phase
  * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py. */
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
+/* Geometry the last completed MSM ran with: {window bits c, signed digits per scalar (= mixed additions per pair),
+ * buckets, 1 if the window table was used}.  For bench.py's arithmetic roofline. */
+int pc_hip_last_msm_shape(const pc_ctx* ctx, uint32_t out[4]);
 
 
 /* Device buffers for callers that do not link a HIP runtime themselves (the Rust shim, the C++ host

@@ -75,6 +75,7 @@ def load_library():
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
     lib.pc_hip_set_timing.argtypes = [vp, ip]
     lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pc_hip_last_msm_shape.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
@@ -158,6 +159,12 @@ class Context:
         out = (C.c_float * 8)()
         self.check(self.lib.pc_hip_last_msm_phases_ms(self.h, out))
         return list(out)
+
+    def last_msm_shape(self):
+        """{window bits, signed digits per scalar, buckets, window table used} of the last completed MSM."""
+        out = (C.c_uint32 * 4)()
+        self.check(self.lib.pc_hip_last_msm_shape(self.h, out))
+        return {"window_bits": out[0], "digits_per_scalar": out[1], "buckets": out[2], "window_table": bool(out[3])}
 
     def ntt_batch(self, curve, mat, log_n, out=None, rows=None, in_cols=None):
         """rows x in_cols Fr (Montgomery) -> rows x 2^log_n, natural order.  numpy in -> numpy out;

@@ -39,6 +39,7 @@ struct pc_ctx {
   std::string last_error;
   pc::MsmConfig msm_cfg;
   float phases[8] = {0};
+  uint32_t shape[4] = {0};
 };
 
 // Independent pipelines per SRS (stream + workspace each), used round-robin; a pipeline that still
@@ -118,6 +119,7 @@ static void complete_job(pc_ctx* ctx, pc_job* job) {
     *job->out_inf = acc == 0;
   }
   for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
+  L->runner->shape(ctx->shape);
   if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
   job->status = PC_OK;
 }
@@ -520,6 +522,7 @@ int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* sc
       for (size_t k = 0; k < n_msms; k++) { uint32_t acc = 0; for (int i = 0; i < srs->aw; i++) acc |= o[k * srs->aw + i]; out_is_infinity[k] = acc == 0; }
     }
     for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
+  L->runner->shape(ctx->shape);
     if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
     return (int)PC_OK;
   });
@@ -530,6 +533,12 @@ int pc_hip_set_timing(pc_ctx* ctx, int on) { if (!ctx) return PC_ERR_INVALID_ARG
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]) {
   if (!ctx || !out) return PC_ERR_INVALID_ARG;
   for (int i = 0; i < 8; i++) out[i] = ctx->phases[i];
+  return PC_OK;
+}
+
+int pc_hip_last_msm_shape(const pc_ctx* ctx, uint32_t out[4]) {
+  if (!ctx || !out) return PC_ERR_INVALID_ARG;
+  for (int i = 0; i < 4; i++) out[i] = ctx->shape[i];
   return PC_OK;
 }
 

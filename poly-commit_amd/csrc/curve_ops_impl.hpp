@@ -31,6 +31,10 @@ struct MsmRunnerT : MsmRunner {
     plan.enqueue_vectors(bases, base_off, ptrs_host, count, m, from_mont);
   }
   void finish(uint32_t* out_host) override { plan.finish(out_host); }
+  void shape(uint32_t out[4]) const override {
+    const MsmGeom& g = plan.last_geom();
+    out[0] = g.c; out[1] = g.Wd; out[2] = g.NB; out[3] = g.tbl_stride ? 1u : 0u;
+  }
 };
 
 template <class C>

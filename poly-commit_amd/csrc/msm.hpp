@@ -685,6 +685,7 @@ class MsmPlan {
 
   const MsmGeom& geom() const { return g_; }
   uint32_t* scalar_staging() { return scalars_; }
+  const MsmGeom& last_geom() const { return g_; }
 
   // bases_dev: resident SRS; scalars_dev: n x FrP::N words on the device.
   // Writes the affine result (AW words, Montgomery; (0,0) = infinity) to out_host.

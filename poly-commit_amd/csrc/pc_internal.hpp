@@ -22,6 +22,8 @@ struct MsmRunner {
   // many-MSM runners only: `count` scalar vectors of m elements each in separate device buffers (a batch of polynomials)
   virtual void enqueue_vectors(const uint32_t* bases, uint32_t base_off, const uint64_t* ptrs_host, size_t count, size_t m, bool from_mont) = 0;
   virtual void finish(uint32_t* out_host) = 0;
+  // geometry of the last enqueue: {window bits c, signed digits per scalar, buckets, 1 if the window table was used}
+  virtual void shape(uint32_t out[4]) const = 0;
 };
 
 struct NttRunner {
