@@ -102,7 +102,7 @@ def bench_ntt(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     curve = args.curve
@@ -194,7 +194,7 @@ def bench_batch(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     curve = "bn254" if args.curve == "bls12_381" else args.curve

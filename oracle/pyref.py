@@ -571,3 +571,69 @@ def fr_lincomb(field, polys, xi):
         for i, v in enumerate(q):
             out[i] = (out[i] + c * v) % p
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# InnerProductArgPC verifier (an independent line of evidence for the prover restated above: a proof made by
+# `ipa_open` -- or by the device path -- must satisfy the reference's own check equations)
+# ---------------------------------------------------------------------------------------
+def succinct_check_coeffs(field, challenges):
+    """SuccinctCheckPolynomial::compute_coeffs (ipa_pc/data_structures.rs:204-220)."""
+    p = FIELDS[field]["p"]
+    log_d = len(challenges)
+    coeffs = [1] * (1 << log_d)
+    for i, ch in enumerate(challenges, start=1):
+        elem_degree = 1 << (log_d - i)
+        for start in range(elem_degree, len(coeffs), 2 * elem_degree):
+            for off in range(elem_degree):
+                coeffs[start + off] = coeffs[start + off] * ch % p
+    return coeffs
+
+
+def succinct_check_eval(field, challenges, point):
+    """SuccinctCheckPolynomial::evaluate (ipa_pc/data_structures.rs:223-236)."""
+    p = FIELDS[field]["p"]
+    log_d = len(challenges)
+    prod = 1
+    for i, ch in enumerate(challenges, start=1):
+        elem = pow(point, 1 << (log_d - i), p)
+        prod = prod * (1 + elem * ch) % p
+    return prod
+
+
+def ipa_succinct_check(curve, h, comms, point, values, proof, opening_challenges):
+    """InnerProductArgPC::succinct_check without hiding and degree bounds (ipa_pc/mod.rs:91-203).
+    proof = (l_vec, r_vec, final_comm_key, c).  Returns the round challenges, or None when the equation fails."""
+    fr = CURVES[curve]["fr"]
+    p = FIELDS[fr]["p"]
+    l_vec, r_vec, final_key, c = proof
+    combined_comm, combined_v = None, 0
+    for comm, value, xi in zip(comms, values, opening_challenges):                    # :116-131
+        combined_v = (combined_v + xi * value) % p
+        combined_comm = ec_add(curve, combined_comm, ec_mul(curve, xi, comm))
+    rc = random_oracle_challenge(fr, ser_point(curve, combined_comm) + ser_field(fr, point) + ser_field(fr, combined_v))
+    h_prime = ec_mul(curve, rc, h)                                                    # :163
+    round_comm = ec_add(curve, combined_comm, ec_mul(curve, combined_v, h_prime))     # :165
+    chal = []
+    for l, r in zip(l_vec, r_vec):                                                    # :170-184
+        rc = random_oracle_challenge(fr, ser_field(fr, rc) + ser_point(curve, l) + ser_point(curve, r))
+        chal.append(rc)
+        round_comm = ec_add(curve, round_comm, ec_add(curve, ec_mul(curve, pow(rc, -1, p), l), ec_mul(curve, rc, r)))
+    v_prime = succinct_check_eval(fr, chal, point) * c % p                            # :187
+    check_elem = ec_add(curve, ec_mul(curve, c, final_key), ec_mul(curve, v_prime, h_prime))    # :190-195
+    if round_comm != check_elem:
+        return None
+    return chal
+
+
+def ipa_check(curve, comm_key, h, comms, point, values, proof, opening_challenges):
+    """InnerProductArgPC::check (ipa_pc/mod.rs:725-773): the succinct check, then final_comm_key against the MSM of
+    the key with the check polynomial's coefficients."""
+    log_d = ark_log2(len(comm_key))
+    if len(proof[0]) != len(proof[1]) or len(proof[0]) != log_d:
+        raise ValueError("IncorrectInputLength")
+    chal = ipa_succinct_check(curve, h, comms, point, values, proof, opening_challenges)
+    if chal is None:
+        return False
+    fr = CURVES[curve]["fr"]
+    return msm(curve, comm_key, succinct_check_coeffs(fr, chal)) == proof[2]

@@ -73,8 +73,16 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t 
 // neighbouring lanes: lane t hands its last-run sum to lane t+1 through LDS, lane t+1 adds it to
 // its first-run partial and, if the bucket ends inside its chunk, writes the finished bucket.
 // Only buckets spanning >= 3 chunks or a workgroup edge still go through the partial list.
+#ifndef PC_ACC_WAVES_PER_EU
+#define PC_ACC_WAVES_PER_EU 0
+#endif
+#if PC_ACC_WAVES_PER_EU
+#define PC_ACC_BOUNDS __launch_bounds__(256, PC_ACC_WAVES_PER_EU)
+#else
+#define PC_ACC_BOUNDS __launch_bounds__(256)
+#endif
 template <class C>
-__global__ void __launch_bounds__(256) k_accumulate(AccumulateBody<C> b, uint32_t lanes) {
+__global__ void PC_ACC_BOUNDS k_accumulate(AccumulateBody<C> b, uint32_t lanes) {
   typedef XyzzD<C> Pt;
   __shared__ uint32_t xch[Pt::WORDS * 256];
   __shared__ uint32_t key_offer[256], key_first[256];

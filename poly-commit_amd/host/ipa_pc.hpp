@@ -5,6 +5,8 @@
 //
 //   open (no hiding, no bounds) ipa_pc/mod.rs:475-723 (combination with the sponge's challenges, the random-oracle
 //                              challenges of :74-87 / :615-625 / :681-688, h_prime, the loop, Proof)
+//   succinct_check / check     ipa_pc/mod.rs:91-203, 725-773 (no hiding, no bounds): the verifier, whose one large
+//                              computation -- cm_commit(comm_key, check_poly.compute_coeffs()) -- runs on the device
 //
 // The coefficient vector, the powers of the evaluation point and the commitment key stay in HBM for the
 // whole proof (pc_hip_malloc / the resident SRS); per round two points come down and one challenge goes up.
@@ -173,6 +175,77 @@ struct InnerProductArgPC {
     pc_hip_free(ctx, cdev); pc_hip_free(ctx, zdev); pc_hip_free(ctx, sdev); pc_hip_free(ctx, aldev); pc_hip_free(ctx, ardev);
     pc_hip_srs_free(srs);
     return rc == PC_OK ? Error() : backend_error(ctx, rc);
+  }
+
+  // SuccinctCheckPolynomial::evaluate (ipa_pc/data_structures.rs:223-236): prod_i (1 + u_i * point^(2^(log_d - i)))
+  static Fr check_poly_evaluate(const std::vector<Fr>& challenges, const Fr& point) {
+    const size_t log_d = challenges.size();
+    std::vector<Fr> pw(log_d ? log_d : 1); pw[0] = point;                       // pw[k] = point^(2^k)
+    for (size_t k = 1; k < log_d; k++) pw[k] = pw[k - 1] * pw[k - 1];
+    Fr product = Fr::one();
+    for (size_t i = 1; i <= log_d; i++) product = product * (Fr::one() + pw[log_d - i] * challenges[i - 1]);
+    return product;
+  }
+
+  // succinct_check without hiding / degree bounds (ipa_pc/mod.rs:91-203): O(log d) group operations on the host.
+  // Returns false when the equation fails; on success `round_challenges` holds the check polynomial.
+  static bool succinct_check(const G1Affine<E>& h, const std::vector<G1Affine<E>>& commitments, const Fr& point,
+                             const std::vector<Fr>& values, const IpaProof<E>& proof, const std::vector<Fr>& opening_challenges,
+                             std::vector<Fr>& round_challenges) {
+    G1Affine<E> combined_commitment = G1Affine<E>::zero();
+    Fr combined_v = Fr::zero();
+    for (size_t j = 0; j < commitments.size(); j++) {                                             // :116-131
+      combined_v = combined_v + opening_challenges[j] * values[j];
+      combined_commitment = combined_commitment.add(commitments[j].mul(opening_challenges[j]));
+    }
+    Transcript<E> t; t.append(combined_commitment); t.append(point); t.append(combined_v);       // :153-161
+    Fr round_challenge = t.challenge();
+    const G1Affine<E> h_prime = h.mul(round_challenge);                                           // :163
+    G1Affine<E> round_commitment = combined_commitment.add(h_prime.mul(combined_v));              // :165
+    round_challenges.clear();
+    IpaRandomOracle<E> ro(round_challenge);
+    for (size_t k = 0; k < proof.l_vec.size(); k++) {                                             // :170-184
+      round_challenge = ro.next(proof.l_vec[k], proof.r_vec[k]);
+      round_challenges.push_back(round_challenge);
+      round_commitment = round_commitment.add(proof.l_vec[k].mul(round_challenge.inverse())).add(proof.r_vec[k].mul(round_challenge));
+    }
+    const Fr v_prime = check_poly_evaluate(round_challenges, point) * proof.c;                    // :187
+    const G1Affine<E> check_commitment_elem = proof.final_comm_key.mul(proof.c).add(h_prime.mul(v_prime));   // :190-195
+    return round_commitment == check_commitment_elem;
+  }
+
+  // check (ipa_pc/mod.rs:725-773): succinct_check, then final_comm_key == cm_commit(comm_key, check_poly.compute_coeffs()).
+  // The 2^log_d coefficients (data_structures.rs:204-220) are built on the device: they are the factors the prover's key
+  // folds apply to the bases (pc_hip_ipa_key_scalars folding a vector of ones by every challenge), so the verifier's one
+  // large computation is a resident vector and one MSM.
+  static Error check(pc_ctx* ctx, const IpaCommitterKey<E>& vk, const std::vector<G1Affine<E>>& commitments, const Fr& point,
+                     const std::vector<Fr>& values, const IpaProof<E>& proof, const std::vector<Fr>& opening_challenges, bool& ok) {
+    ok = false;
+    const size_t n = vk.comm_key.size();
+    size_t log_d = 0; while (((size_t)1 << log_d) < n) log_d++;                                   // ark_std::log2(d + 1)
+    if (proof.l_vec.size() != proof.r_vec.size() || proof.l_vec.size() != log_d) {
+      Error e; e.kind = Error::IncorrectInputLength; e.a = log_d; e.b = proof.l_vec.size();
+      e.msg = "Expected proof vectors to be " + std::to_string(log_d) + ". Instead, l_vec size is " + std::to_string(proof.l_vec.size()) +
+              " and r_vec size is " + std::to_string(proof.r_vec.size());
+      return e;
+    }
+    if (commitments.size() != values.size() || commitments.size() != opening_challenges.size()) { Error e; e.kind = Error::Backend; e.msg = "ipa check: one value and one opening challenge per commitment"; return e; }
+    std::vector<Fr> ch;
+    if (!succinct_check(vk.h, commitments, point, values, proof, opening_challenges, ch)) return Error();
+    pc_srs* srs = nullptr; void* sdev = nullptr;
+    int rc = pc_hip_srs_upload(ctx, E::ID, vk.comm_key.data(), n, sizeof(G1Affine<E>), PC_MEM_HOST, &srs);
+    if (rc == PC_OK) rc = pc_hip_malloc(ctx, n * 32, &sdev);
+    const Fr one = Fr::one();
+    if (rc == PC_OK) rc = pc_hip_fr_powers(ctx, E::ID, one.l, n, sdev);
+    size_t m = n;
+    for (size_t i = 0; rc == PC_OK && i < ch.size(); i++, m /= 2)
+      rc = pc_hip_ipa_key_scalars(ctx, E::ID, nullptr, 0, sdev, n, ch[i].l, m, nullptr, nullptr);
+    uint64_t kxy[2 * E::NQ]; int kinf = 0;
+    if (rc == PC_OK) rc = pc_hip_msm(ctx, srs, 0, sdev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n, kxy, &kinf);
+    pc_hip_free(ctx, sdev); pc_hip_srs_free(srs);
+    if (rc != PC_OK) return backend_error(ctx, rc);
+    ok = from_out(kxy) == proof.final_comm_key;
+    return Error();
   }
 };
 

@@ -169,3 +169,65 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     c = coeffs_dev[0].cpu().numpy().view(np.uint64).copy()
     srs.free()
     return np.stack(l_vec), np.stack(r_vec), final_key, c
+
+
+def succinct_check_eval(curve, challenges_mont, point_mont):
+    """SuccinctCheckPolynomial::evaluate (ipa_pc/data_structures.rs:223-236): prod_i (1 + u_i z^(2^(log_d - i)))
+    in O(log d).  Montgomery limbs in, Montgomery limbs out."""
+    p = FR_MODULUS[curve]
+    rinv = pow(_R, -1, p)
+    z = _limbs_to_int(point_mont) * rinv % p
+    log_d = len(challenges_mont)
+    prod = 1
+    for i, u in enumerate(challenges_mont, start=1):
+        prod = prod * (1 + pow(z, 1 << (log_d - i), p) * (_limbs_to_int(u) * rinv % p)) % p
+    return _int_to_limbs(prod * _R % p)
+
+
+def ipa_check(ctx, curve, comm_key, h_xy, comms, point_mont, values_mont, proof, opening_challenges):
+    """InnerProductArgPC::check without hiding / degree bounds (ipa_pc/mod.rs:725-773): the succinct check
+    (:91-203; O(log d) host point operations) and the verifier's only large computation, the MSM of the committer key
+    with the check polynomial's coefficients (:759-765), on the device -- the coefficients never exist on the host:
+    they are the per-base factors the key folds would apply (pc_hip_ipa_key_scalars folding ones by every challenge).
+    comm_key: n x (x||y) host array or a resident Srs.  proof = (l_vec, r_vec, final_comm_key, c).  Returns bool."""
+    import torch
+    l_vec, r_vec, final_key, c = proof
+    own = not isinstance(comm_key, _ffi.Srs)
+    n = comm_key.shape[0] if own else comm_key.n
+    log_d = (n - 1).bit_length()
+    if len(l_vec) != len(r_vec) or len(l_vec) != log_d:
+        raise ValueError(f"IncorrectInputLength: expected proof vectors to be {log_d}, l_vec {len(l_vec)}, r_vec {len(r_vec)}")
+    p = FR_MODULUS[curve]
+    rinv = pow(_R, -1, p)
+    to_int = lambda a: _limbs_to_int(a) * rinv % p           # noqa: E731
+    to_mont = lambda v: _int_to_limbs(v * _R % p)            # noqa: E731
+    xi = np.ascontiguousarray(opening_challenges, dtype=np.uint64)
+    combined_v = sum(to_int(x) * to_int(v) for x, v in zip(xi, values_mont)) % p
+    ccomm = _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, cm, x) for cm, x in zip(comms, xi)]))
+    rc = random_oracle_challenge(curve, ser_point(curve, ccomm) + ser_fr(curve, point_mont) + ser_fr(curve, to_mont(combined_v)))
+    h_prime = _ffi.point_mul(curve, np.ascontiguousarray(h_xy), rc)
+    terms = [ccomm, _ffi.point_mul(curve, h_prime, to_mont(combined_v))]
+    chal = []
+    for l, r in zip(l_vec, r_vec):
+        rc = random_oracle_challenge(curve, ser_fr(curve, rc) + ser_point(curve, l) + ser_point(curve, r))
+        chal.append(rc)
+        terms.append(_ffi.point_mul(curve, l, to_mont(pow(to_int(rc), -1, p))))
+        terms.append(_ffi.point_mul(curve, r, rc))
+    round_comm = _ffi.points_sum(curve, np.stack(terms))
+    v_prime = to_int(succinct_check_eval(curve, chal, point_mont)) * to_int(c) % p
+    check_elem = _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, final_key, c), _ffi.point_mul(curve, h_prime, to_mont(v_prime))]))
+    if not (round_comm == check_elem).all():
+        return False
+    srs = ctx.upload_srs(curve, np.ascontiguousarray(comm_key)) if own else comm_key
+    try:
+        s_dev = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        ctx.fr_powers(curve, to_mont(1), n, s_dev.data_ptr())
+        m = n
+        for u in chal:                                       # coefficient j picks up u_i iff bit (log_d - i) of j is set
+            ctx.ipa_key_scalars(curve, None, 0, s_dev.data_ptr(), n, fold_u=np.ascontiguousarray(u, dtype=np.uint64), fold_m=m)
+            m //= 2
+        key = srs.msm(s_dev.data_ptr(), n=n, base_offset=0, montgomery=True)[0]
+    finally:
+        if own:
+            srs.free()
+    return bool((key == np.asarray(final_key)).all())

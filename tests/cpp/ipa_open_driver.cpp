@@ -30,6 +30,24 @@ static int run(pc_ctx* ctx, FILE* in, uint32_t n, uint32_t k, const char* out_pa
   }
   IpaProof<E> proof;
   if (Error e = InnerProductArgPC<E>::open(ctx, ck, pp, comms, point, xi, proof)) { printf("open: %s\n", e.msg.c_str()); return 1; }
+  // the verifier of the same mirror (InnerProductArgPC::check, ipa_pc/mod.rs:725-773) accepts the proof for the true
+  // evaluations and rejects an altered c, an altered value and a short proof
+  std::vector<FrT<E>> values; for (auto& p : polys) values.push_back(p.evaluate(point));
+  bool ok = false;
+  if (Error e = InnerProductArgPC<E>::check(ctx, ck, comms, point, values, proof, xi, ok)) { printf("check: %s\n", e.msg.c_str()); return 1; }
+  if (!ok) { printf("check rejected an honest proof\n"); return 1; }
+  { IpaProof<E> bad = proof; bad.c = bad.c + FrT<E>::one();
+    if (InnerProductArgPC<E>::check(ctx, ck, comms, point, values, bad, xi, ok) || ok) { printf("check accepted an altered c\n"); return 1; } }
+  { std::vector<FrT<E>> bv = values; bv[0] = bv[0] + FrT<E>::one();
+    if (InnerProductArgPC<E>::check(ctx, ck, comms, point, bv, proof, xi, ok) || ok) { printf("check accepted an altered value\n"); return 1; } }
+  { IpaProof<E> bad = proof; bad.final_comm_key = bad.final_comm_key.add(ck.comm_key[0]);
+    if (InnerProductArgPC<E>::check(ctx, ck, comms, point, values, bad, xi, ok) || ok) { printf("check accepted an altered final_comm_key\n"); return 1; } }
+  if (!proof.l_vec.empty()) {
+    IpaProof<E> bad = proof; bad.l_vec.pop_back(); bad.r_vec.pop_back();
+    Error e = InnerProductArgPC<E>::check(ctx, ck, comms, point, values, bad, xi, ok);
+    if (e.kind != Error::IncorrectInputLength) { printf("check: short proof not reported as IncorrectInputLength\n"); return 1; }
+  }
+  printf("ipa check OK\n");
   FILE* out = fopen(out_path, "wb");
   auto wr_pt = [&](const G1Affine<E>& p) { uint64_t xy[2 * E::NQ]; p.to_xy(xy); fwrite(xy, 1, sizeof xy, out); };
   for (auto& p : proof.l_vec) wr_pt(p);

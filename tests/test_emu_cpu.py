@@ -392,6 +392,26 @@ def test_ipa_fixed_key_rounds_stepped(curve):
     assert R.msm(curve, K0, O.fr_from_mont_array(curve, s)) == key[0]
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_check_polynomial_coefficients_from_key_folds_stepped(curve):
+    """The verifier's final-key MSM (InnerProductArgPC::check, ipa_pc/mod.rs:759-765) takes
+    SuccinctCheckPolynomial::compute_coeffs (data_structures.rs:204-220).  The host layers build them on the device by
+    folding a vector of ones by every round challenge at sizes n, n/2, ... (IpaKeyScalarUpdateBody, stepped here):
+    the same 2^log_d coefficients."""
+    fr = R.CURVES[curve]["fr"]
+    ci = O.CURVES[curve]
+    for log_d in (1, 3, 5):
+        n = 1 << log_d
+        chal = R.gen_scalars(fr, 0x60 + log_d, log_d)
+        s = O.fr_mont_array(curve, [1] * n)
+        m = n
+        for u in chal:
+            u_m = O.fr_mont_array(curve, [u])[0]
+            emu().emu_ipa_key_scalars(ci, None, 0, p32(s.view(np.uint32)), n, p32(u_m.view(np.uint32)), m, None, None)
+            m //= 2
+        assert O.fr_from_mont_array(curve, s) == R.succinct_check_coeffs(fr, chal)
+
+
 @pytest.mark.parametrize("curve,compressed", [("bls12_381", False), ("bls12_381", True), ("bn254", False), ("bn254", True), ("pallas", False)])
 def test_srs_decode_ark_serialize_stepped(curve, compressed):
     """CanonicalDeserialize of Vec<G1Affine> (the head of kzg10::UniversalParams, kzg10/data_structures.rs:80-112): the

@@ -79,6 +79,37 @@ def test_ipa_open_whole_proof_python_host(ctx, curve, n):
     assert (l == wl).all() and (r == wr).all() and (fk == wfk).all() and (c == wc).all()
 
 
+@pytest.mark.parametrize("curve,n", [("pallas", 1 << 9), ("bn254", 1 << 4), ("bls12_381", 1 << 5)])
+def test_ipa_device_proof_passes_reference_check(ctx, curve, n):
+    """A proof made on the device satisfies the reference's verifier equations: InnerProductArgPC::check restated in
+    Python big ints (oracle/pyref.py, independent of the prover's code paths) and the device-side check of
+    poly-commit_amd/ipa.py (succinct check on the host, the verifier's final-key MSM -- ipa_pc/mod.rs:759-765 -- on the
+    GPU) both accept it, and both reject it once c, the claimed value or final_comm_key is altered."""
+    import torch
+    from poly_commit_amd import ipa
+    comm_key, h, polys, comms, xi, point = _open_inputs(curve, n)
+    dev = [torch.from_numpy(q.view(np.int64).copy()).cuda() for q in polys]
+    (l, r, fk, c), _ = ipa.ipa_open(ctx, curve, comm_key, h, [d.data_ptr() for d in dev], [len(q) for q in polys], comms, point, xi)
+    values = [O.poly_eval(curve, q, point) for q in polys]
+    assert ipa.ipa_check(ctx, curve, comm_key, h, comms, point, values, (l, r, fk, c), xi) is True
+    one = np.array([1, 0, 0, 0], dtype=np.uint64)
+    bad_c = c.copy(); bad_c[0] ^= np.uint64(1)
+    assert ipa.ipa_check(ctx, curve, comm_key, h, comms, point, values, (l, r, fk, bad_c), xi) is False
+    bad_v = [values[0].copy(), values[1]]; bad_v[0][1] ^= np.uint64(4)
+    assert ipa.ipa_check(ctx, curve, comm_key, h, comms, point, bad_v, (l, r, fk, c), xi) is False
+    assert ipa.ipa_check(ctx, curve, comm_key, h, comms, point, values, (l, r, comm_key[1], c), xi) is False
+    with pytest.raises(ValueError):
+        ipa.ipa_check(ctx, curve, comm_key, h, comms, point, values, (l[:-1], r[:-1], fk, c), xi)
+    # the independent verifier (Python big ints)
+    fr = R.CURVES[curve]["fr"]
+    to_i = lambda a: O.fr_from_mont_array(curve, np.ascontiguousarray(a).reshape(-1, 4))      # noqa: E731
+    pts = lambda a: O.array_to_points(curve, np.ascontiguousarray(a).reshape(-1, comm_key.shape[1]))   # noqa: E731
+    proof_i = (pts(l), pts(r), pts(fk)[0], to_i(c)[0])
+    args = (curve, pts(comm_key), pts(h)[0], [pts(cm)[0] for cm in comms], to_i(point)[0], [to_i(v)[0] for v in values])
+    assert R.ipa_check(*args, proof_i, to_i(xi)) is True
+    assert R.ipa_check(*args, (proof_i[0], proof_i[1], proof_i[2], (proof_i[3] + 1) % R.FIELDS[fr]["p"]), to_i(xi)) is False
+
+
 @pytest.mark.parametrize("curve,n", [("pallas", 1 << 8), ("bn254", 1 << 5), ("bls12_381", 1 << 5)])
 def test_ipa_open_whole_proof_cpp_host_mirror(curve, n, tmp_path):
     """The same through the C++ host mirror (host/ipa_pc.hpp: InnerProductArgPC::open, host/transcript.hpp):
