@@ -30,6 +30,17 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 import numpy as np  # noqa: E402
 
+# The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C
+# stdio when its first communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the
+# result line goes to the saved descriptor.
+_RESULT_FD = os.dup(1)
+os.dup2(2, 1)
+
+
+def emit(obj):
+    os.write(_RESULT_FD, (json.dumps(obj) + "\n").encode())
+
+
 PAIR_BYTES = {"bls12_381": 128, "bn254": 96, "pallas": 96}   # affine base + 32-byte scalar
 HBM_PEAK_GBPS = 8000.0                                        # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -162,7 +173,7 @@ def bench_ntt(args):
     kern_ms = float(ph.sum())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
     if rank == 0:
-        print(json.dumps({
+        emit(({
             "metric": "Ligero Reed-Solomon NTT input coefficients/sec (LigeroPCS over BLS12-381 Fr, 2^24 coeffs)",
             "value": world * rows * n_cols * args.steps / dt, "unit": "coeffs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -232,7 +243,7 @@ def bench_batch(args):
         dt = float(tmax.item())
     if rank == 0:
         pairs = args.polys * total
-        print(json.dumps({
+        emit(({
             "metric": "MSM G1-scalar-pairs/sec, batched MarlinKZG10<Bn254> commit (64 polys, deg 2^20, SRS sharded)",
             "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -271,6 +282,8 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
     pending = collections.deque()
 
     def drain():
+        if dist is not None and pending:
+            job.exchange(None, 0, [pending.popleft() for _ in range(len(pending))])
         while pending:
             pending.popleft().result()
 
@@ -279,6 +292,14 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
         # latency-bound tail of one MSM overlaps the bucket accumulation of the next
         # (N > 1: the open's exchange step -- shard evaluation + all_gather of one Fr per rank -- runs first, while
         # the previous step's MSMs are still in flight, so the blocking collective does not drain the pipelines)
+        if dist is not None and depth > 0:
+            # N > 1, pipelined: ONE collective per step -- this step's shard evaluations (the division carries) travel
+            # with the partial points of the step that left the pipeline (ShardedKzg.exchange)
+            done = [pending.popleft() for _ in range(max(0, len(pending) - 2 * (depth - 1)))]
+            carry, _results = job.exchange(coeffs, n, done)
+            pending.append(job.commit_async(coeffs, n))
+            pending.append(job.open_async(coeffs, n, prepared=True, carry=carry))
+            return
         carry = job.open_prepare(coeffs, n)
         pending.append(job.commit_async(coeffs, n))
         if depth == 0:                       # strictly blocking calls: the commitment is back before the open starts
@@ -529,7 +550,7 @@ def main():
                 "msm_phase_ms": sec["msm_phase_ms"], "roofline": sec["roofline"]}
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(curve, args.log_degree)
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -171,7 +171,10 @@ class ShardedKzg:
         B_s = p_s(z) (an evaluation-only up-sweep; the full division then runs once, with the carry)."""
         if self.world == 1:
             return None
-        b = self._all_gather(self.e.poly_eval(coeffs, n, self.z))
+        return self._carry_from_evals(self._all_gather(self.e.poly_eval(coeffs, n, self.z)), n)
+
+    def _carry_from_evals(self, b, n):
+        """carry into this rank's shard from the gathered shard evaluations b[s] = p_s(z) (Montgomery limbs)."""
         z = _limbs_to_int(self.z) * pow(_R, -1, self.p) % self.p
         zn_mont = pow(z, n, self.p) * _R % self.p          # Montgomery form of z^n
         rinv = pow(_R, -1, self.p)
@@ -179,6 +182,34 @@ class ShardedKzg:
         for s in range(self.world - 1, self.rank, -1):
             carry = (_limbs_to_int(b[s]) + zn_mont * carry * rinv) % self.p   # Montgomery arithmetic
         return _int_to_limbs(carry) if carry else None
+
+    def exchange(self, coeffs=None, n=0, futures=()):
+        """ONE collective for everything a pipelined prover has to exchange at a step boundary: the shard evaluation
+        of the polynomial about to be opened (-> this rank's division carry, as open_prepare) and the partial points
+        of earlier commits / opens whose local MSMs are awaited here (-> their combined results, as _Future.result).
+        Returns (carry or None, [combined point per future])."""
+        futures = list(futures)
+        local = [f.pending.wait() for f in futures]
+        if self.world == 1 and self.dist is None:
+            return None, local
+        parts = []
+        if coeffs is not None:
+            parts.append(np.ascontiguousarray(self.e.poly_eval(coeffs, n, self.z), dtype=np.uint64).reshape(-1))
+        parts += [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1) for x in local]
+        if not parts:
+            return None, []
+        g = self._all_gather(np.concatenate(parts))
+        off, carry = 0, None
+        if coeffs is not None:
+            carry = self._carry_from_evals(g[:, :4], n) if self.world > 1 else None
+            off = 4
+        out = []
+        for x in local:
+            w = x.size
+            pts = np.ascontiguousarray(g[:, off:off + w])
+            out.append(pts[0] if self.world == 1 else self.e.points_sum(pts))
+            off += w
+        return carry, out
 
     def open_async(self, coeffs, n, prepared=False, carry=None):
         if not prepared:

@@ -94,6 +94,16 @@ def main():
         rc1, want_c = O.kzg_commit(curve, powers, coeffs, 2)
         rc2, want_w = O.kzg_open(curve, powers, coeffs, z, 2)
         ok &= rc1 == 0 and rc2 == 0 and bool((comm == want_c).all()) and bool((proof == want_w).all())
+        # the pipelined form bench.py runs for N > 1: one collective carries the shard evaluations of the polynomial
+        # about to be opened together with the partial points of results leaving the pipeline (ShardedKzg.exchange)
+        f1 = job.commit_async(mine, n)
+        carry, none = job.exchange(mine, n, [])
+        f2 = job.open_async(mine, n, prepared=True, carry=carry)
+        f3 = job.commit_async(mine, n)
+        carry2, (c1, w1) = job.exchange(mine, n, [f1, f2])
+        f4 = job.open_async(mine, n, prepared=True, carry=carry2)
+        _, (c2, w2) = job.exchange(None, 0, [f3, f4])
+        ok &= none == [] and all(bool((a == b).all()) for a, b in ((c1, want_c), (w1, want_w), (c2, want_c), (w2, want_w)))
     # BASELINE configs[2] shape: k polynomials against one SRS in `world` contiguous chunks (bench.py --workload batch)
     # and configs[4] shape: matrix rows split over the ranks, no collective (bench.py --workload ntt)
     for curve in ("bn254",):
