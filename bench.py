@@ -426,6 +426,8 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
         "commit_open_per_s": steps / dt if world == 1 else None,
         "value_h2d_inclusive": h2d,
         "srs_window_table_build_ms": eng.precompute_ms,
+        "exchange_host_ms": ({k: (v / max(1, job.exchange_ms["calls"]) if k != "calls" else v) for k, v in job.exchange_ms.items()}
+                             if dist is not None else None),
         "blocking_msm_ms": blocking_msm_ms,
         "msm_phase_ms": {k: float(v) for k, v in zip(
             ["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], sp[:6])},
@@ -536,6 +538,7 @@ def main():
             "commit_open_per_s": prim["commit_open_per_s"],
             "value_h2d_inclusive": prim["value_h2d_inclusive"],
             "blocking_msm_ms": prim["blocking_msm_ms"],
+            "exchange_host_ms": prim["exchange_host_ms"],
             "msm_phase_ms": prim["msm_phase_ms"],
             "roofline": prim["roofline"],
         }

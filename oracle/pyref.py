@@ -637,3 +637,87 @@ def ipa_check(curve, comm_key, h, comms, point, values, proof, opening_challenge
         return False
     fr = CURVES[curve]["fr"]
     return msm(curve, comm_key, succinct_check_coeffs(fr, chal)) == proof[2]
+
+
+# ---------------------------------------------------------------------------------------
+# HyraxPC (poly-commit/src/hyrax): sqrt(n) row commitments of sqrt(n) pairs -- the batched small-MSM shape
+# (SURVEY.md 8f rank 4).  The sponge is the caller's: its challenge c and the prover's random field elements
+# are inputs, in the order the reference draws them.
+# ---------------------------------------------------------------------------------------
+def flat_to_matrix_column_major(flat, n, m):
+    """hyrax/utils.rs:13-21: row r = flat[r], flat[n + r], flat[2n + r], ..."""
+    assert len(flat) == n * m
+    return [[flat[col * n + row] for col in range(m)] for row in range(n)]
+
+
+def tensor_prime(field, values):
+    """hyrax/utils.rs:27-39: all evaluations of eq(i, values), first variable in the top bit."""
+    p = FIELDS[field]["p"]
+    if not values:
+        return [1]
+    tail = tensor_prime(field, values[1:])
+    val = values[0]
+    return [v * (1 - val) % p for v in tail] + [v * val % p for v in tail]
+
+
+def hyrax_commit(curve, com_key, h, evals, rands):
+    """HyraxPC::commit for one polynomial (hyrax/mod.rs:214-252): evals = poly.to_evaluations() (2^n values, n even),
+    rands = the dim row randomisers.  Returns (row_coms, matrix rows)."""
+    dim = 1 << ((len(evals).bit_length() - 1) // 2)
+    assert dim * dim == len(evals) and dim <= len(com_key)
+    m = flat_to_matrix_column_major(evals, dim, dim)
+    return [ec_add(curve, msm(curve, com_key[:dim], row), ec_mul(curve, r, h)) for row, r in zip(m, rands)], m
+
+
+def _hyrax_tensors(field, point):
+    n = len(point)
+    point_rev = list(reversed(point))                       # :297
+    return tensor_prime(field, point_rev[n // 2:]), tensor_prime(field, point_rev[:n // 2])    # l (lower), r (upper)
+
+
+def hyrax_open(curve, com_key, h, mat, rands, point, r_eval, d, r_d, r_b, c):
+    """HyraxPC::open for one polynomial (hyrax/mod.rs:287-402).  r_eval, d, r_d, r_b: the random elements in the
+    order the reference draws them (:352, :361-362, :367, :371); c: the sponge's challenge (:385).
+    Returns (com_eval, com_d, com_b, z, z_d, z_b) and the evaluation."""
+    fr = CURVES[curve]["fr"]
+    p = FIELDS[fr]["p"]
+    dim = len(mat)
+    l, r = _hyrax_tensors(fr, point)
+    lt = [sum(l[i] * mat[i][j] for i in range(dim)) % p for j in range(dim)]       # t.row_mul(&l)   :341
+    r_lt = sum(a * b for a, b in zip(l, rands)) % p                                 # :345-348
+    ev = sum(a * b for a, b in zip(lt, r)) % p                                      # :350
+    com_eval = ec_add(curve, ec_mul(curve, ev, com_key[0]), ec_mul(curve, r_eval, h))
+    b = sum(a * x for a, x in zip(r, d)) % p                                        # :364
+    com_d = ec_add(curve, msm(curve, com_key[:dim], d), ec_mul(curve, r_d, h))      # :368
+    com_b = ec_add(curve, ec_mul(curve, b, com_key[0]), ec_mul(curve, r_b, h))      # :372
+    z = [(x + c * y) % p for x, y in zip(d, lt)]                                    # :387
+    return (com_eval, com_d, com_b, z, (c * r_lt + r_d) % p, (c * r_eval + r_b) % p), ev
+
+
+def hyrax_check(curve, com_key, h, row_coms, point, proof, c):
+    """HyraxPC::check for one commitment (hyrax/mod.rs:418-511): equations (14) and (13) of the Hyrax paper."""
+    fr = CURVES[curve]["fr"]
+    p = FIELDS[fr]["p"]
+    n = len(point)
+    if n % 2 == 1:
+        raise ValueError("InvalidNumberOfVariables")
+    if len(row_coms) != 1 << (n // 2):
+        raise ValueError("IncorrectCommitmentSize")
+    com_eval, com_d, com_b, z, z_d, z_b = proof
+    l, r = _hyrax_tensors(fr, point)
+    ip = sum(a * b for a, b in zip(r, z)) % p
+    com_dp = ec_add(curve, ec_mul(curve, ip, com_key[0]), ec_mul(curve, z_b, h))                # :486
+    if com_dp != ec_add(curve, ec_mul(curve, c, com_eval), com_b):
+        return False
+    t_prime = msm(curve, row_coms, l)                                                           # :495
+    com_z_zd = ec_add(curve, msm(curve, com_key[:len(z)], z), ec_mul(curve, z_d, h))            # :498
+    return com_z_zd == ec_add(curve, ec_mul(curve, c, t_prime), com_d)
+
+
+def mle_evaluate(field, evals, point):
+    """DenseMultilinearExtension::evaluate (ark-poly 0.5, restated): variable 0 is the least significant index bit."""
+    p = FIELDS[field]["p"]
+    cur = list(evals)
+    for x in point:
+        cur = [(cur[2 * i] + x * (cur[2 * i + 1] - cur[2 * i])) % p for i in range(len(cur) // 2)]
+    return cur[0]

@@ -78,7 +78,7 @@ struct XyzzD {
     }
     Fq PP = Pp.sqr(), PPP = Pp.mul(PP), Q = X.mul(PP);
     Fq X3 = R.sqr().sub(PPP).sub(Q.dbl());
-    Y = R.mul(Q.sub(X3)).sub(Y.mul(PPP));
+    Y = R.mul_add_mul(Q.sub(X3), Y.neg(), PPP);        // R (Q - X3) - Y PPP, one reduction for the pair
     X = X3;
     ZZ = ZZ.mul(PP); ZZZ = ZZZ.mul(PPP);
   }

@@ -181,6 +181,50 @@ struct Fd {
   }
   __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
 
+  // a*b + c*d with ONE reduction: the columns of both products are gathered into the same accumulator before the
+  // m_i * p terms, 3 N^2 instead of 4 N^2 partial products for the pair (the sum stays below 2 p^2 < p R, so the
+  // result is below 2 p and the single conditional subtraction of mul() still canonicalises it).
+  template <int K>
+  __device__ __forceinline__ void dual_column_lo(const Fd& b, const Fd& c, const Fd& d, uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi) const {
+    constexpr int CNT = 2 * (K + 1) + nz_mod(1, K);
+    uint32_t x[CNT], y[CNT];
+    int n = 0;
+    PC_UNROLL for (int i = 0; i <= K; i++) { x[n] = l[i]; y[n] = b.l[K - i]; n++; }
+    PC_UNROLL for (int i = 0; i <= K; i++) { x[n] = c.l[i]; y[n] = d.l[K - i]; n++; }
+    PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[n] = m[i]; y[n] = mod[K - i]; n++; }
+    mac_n<CNT, true>(acc, hi, x, y);
+    m[K] = (uint32_t)acc * P::INV;
+    mac1(acc, hi, &m[K], &mod[0]);
+    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    if constexpr (K + 1 < N) dual_column_lo<K + 1>(b, c, d, m, mod, acc, hi);
+  }
+  template <int K>
+  __device__ __forceinline__ void dual_column_hi(const Fd& b, const Fd& c, const Fd& d, const uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi,
+                                                 uint32_t* t) const {
+    constexpr int CNT = 2 * (2 * N - 1 - K) + nz_mod(K - N + 1, N - 1);
+    uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
+    int n = 0;
+    PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[n] = l[i]; y[n] = b.l[K - i]; n++; }
+    PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[n] = c.l[i]; y[n] = d.l[K - i]; n++; }
+    PC_UNROLL for (int i = K - N + 1; i < N; i++) if (P::MOD[K - i] != 0) { x[n] = m[i]; y[n] = mod[K - i]; n++; }
+    mac_n<CNT, true>(acc, hi, x, y);
+    t[K - N] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    if constexpr (K + 1 < 2 * N) dual_column_hi<K + 1>(b, c, d, m, mod, acc, hi, t);
+  }
+  __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const {
+    static_assert(P::BITS < 32 * N, "the fused pair assumes 2 p <= R");
+    uint32_t m[N], t[N + 1], mod[N];
+    PC_UNROLL for (int i = 0; i < N; i++) mod[i] = P::MOD[i];
+    uint64_t acc = 0; uint32_t hi = 0;
+    dual_column_lo<0>(b, c, d, m, mod, acc, hi);
+    dual_column_hi<N>(b, c, d, m, mod, acc, hi, t);
+    Fd r;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
+    cond_sub(r.l, (uint32_t)acc);
+    return r;
+  }
+
   // Dedicated squaring: a^2 = sum_i a_i^2 2^(64 i) + sum_{i<j} a_i (2 a_j) 2^(32 (i+j)).  The doubled cross terms are
   // taken from d = a << 1 (it fits N limbs: every modulus here leaves a spare top bit): row i multiplies a_i by the limbs of
   // ((a >> 32 (i+1)) << 1), i.e. d_j for j >= i+2 and d_{i+1} without the bit that a_i shifted in.  N (N-1)/2 + N partial
@@ -262,6 +306,7 @@ struct Fd {
 #endif
 #if !defined(__HIP_DEVICE_COMPILE__)
   PC_HD Fd sqr() const { return mul(*this); }
+  PC_HD Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul(b).add(c.mul(d)); }
 #endif
 
   // Montgomery <-> canonical

@@ -116,6 +116,7 @@ class ShardedKzg:
         self.p = FR_MODULUS[curve]
         self.z = None
         self.last_phases = []
+        self.exchange_ms = {"wait_local_msm": 0.0, "shard_eval": 0.0, "all_gather": 0.0, "calls": 0}
 
     # bases: n+1 affine points; bases[0] = the power just below this chunk (unused on rank 0),
     # bases[1 + j] = power r*n + j.
@@ -188,17 +189,24 @@ class ShardedKzg:
         of the polynomial about to be opened (-> this rank's division carry, as open_prepare) and the partial points
         of earlier commits / opens whose local MSMs are awaited here (-> their combined results, as _Future.result).
         Returns (carry or None, [combined point per future])."""
+        import time
         futures = list(futures)
+        t0 = time.perf_counter()
         local = [f.pending.wait() for f in futures]
+        t1 = time.perf_counter()
         if self.world == 1 and self.dist is None:
             return None, local
         parts = []
         if coeffs is not None:
             parts.append(np.ascontiguousarray(self.e.poly_eval(coeffs, n, self.z), dtype=np.uint64).reshape(-1))
+        t2 = time.perf_counter()
         parts += [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1) for x in local]
         if not parts:
             return None, []
         g = self._all_gather(np.concatenate(parts))
+        t3 = time.perf_counter()
+        tm = self.exchange_ms                      # host-side time by part (bench.py reports it for N > 1)
+        tm["wait_local_msm"] += (t1 - t0) * 1e3; tm["shard_eval"] += (t2 - t1) * 1e3; tm["all_gather"] += (t3 - t2) * 1e3; tm["calls"] += 1
         off, carry = 0, None
         if coeffs is not None:
             carry = self._carry_from_evals(g[:, :4], n) if self.world > 1 else None

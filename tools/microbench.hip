@@ -57,6 +57,20 @@ __global__ void __launch_bounds__(256) k_fsqr(uint32_t* out, int iters) {
   out[t] = bad ? 0xdeadbeefu : (r == 0xdeadbeefu ? 0 : r);
 }
 template <class P>
+__global__ void __launch_bounds__(256) k_fdual(uint32_t* out, int iters) {
+  typedef pc::Fd<P> F;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  F x = F::one(), y = F::one(), u = F::one(), v = F::one();
+  x.l[0] += t; y.l[1] ^= t * 77; u.l[2] += t * 3; v.l[0] ^= t * 5;
+  for (int it = 0; it < iters; it++) { x = x.mul_add_mul(y, u, v); u = u.mul_add_mul(x, y, v); }
+  // cross-check of the fused pair against two products and an addition
+  F a = x.mul_add_mul(y, u, v), b = x.mul(y).add(u.mul(v));
+  uint32_t bad = 0;
+  for (int i = 0; i < P::N; i++) bad |= a.l[i] ^ b.l[i];
+  uint32_t r = 0; for (int i = 0; i < P::N; i++) r ^= x.l[i] ^ u.l[i];
+  out[t] = bad ? 0xdeadbeefu : (r == 0xdeadbeefu ? 0 : r);
+}
+template <class P>
 __global__ void __launch_bounds__(256) k_fadd(uint32_t* out, int iters) {
   typedef pc::Fd<P> F;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,6 +126,13 @@ int main() {
       std::vector<uint32_t> h(lanes); CHECK(hipMemcpy(h.data(), out, lanes * 4, hipMemcpyDeviceToHost));
       size_t bad = 0; for (uint32_t v : h) bad += v == 0xdeadbeefu;
       printf("fsqr %s             %8.3f ms  %8.2f G sqrmod/s   (sqr != mul on %zu of %zu lanes)\n", rep == 0 ? "bls12_381_fq" : "bn254_fq    ", ms, (double)lanes * it * 2 / ms * 1e-6, bad, lanes);
+    }
+    for (int rep = 0; rep < 2; rep++) {
+      ms = rep == 0 ? timeit([&]() { hipLaunchKernelGGL(k_fdual<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); })
+                    : timeit([&]() { hipLaunchKernelGGL(k_fdual<pc_bn254_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
+      std::vector<uint32_t> h(lanes); CHECK(hipMemcpy(h.data(), out, lanes * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (uint32_t v : h) bad += v == 0xdeadbeefu;
+      printf("a*b+c*d %s          %8.3f ms  %8.2f G pairs/s   (fused != mul,mul,add on %zu of %zu lanes)\n", rep == 0 ? "bls12_381_fq" : "bn254_fq    ", ms, (double)lanes * it * 2 / ms * 1e-6, bad, lanes);
     }
     ms = timeit([&]() { hipLaunchKernelGGL(k_fadd<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it * 8); });
     printf("fadd+fsub bls12_381_fq       %8.3f ms  %8.2f G addsub/s\n", ms, (double)lanes * it * 8 * 2 / ms * 1e-6);
