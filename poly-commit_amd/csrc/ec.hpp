@@ -51,7 +51,7 @@ struct XyzzD {
     Fq U = a.y.dbl(), V = U.sqr(), W = U.mul(V), S = a.x.mul(V);
     Fq xx = a.x.sqr(), M = xx.dbl().add(xx);
     r.X = M.sqr().sub(S.dbl());
-    r.Y = M.mul(S.sub(r.X)).sub(W.mul(a.y));
+    r.Y = M.mul_add_mul(S.sub(r.X), W.neg(), a.y);
     r.ZZ = V; r.ZZZ = W;
     return r;
   }
@@ -62,7 +62,7 @@ struct XyzzD {
     Fq U = Y.dbl(), V = U.sqr(), W = U.mul(V), S = X.mul(V);
     Fq xx = X.sqr(), M = xx.dbl().add(xx);
     r.X = M.sqr().sub(S.dbl());
-    r.Y = M.mul(S.sub(r.X)).sub(W.mul(Y));
+    r.Y = M.mul_add_mul(S.sub(r.X), W.neg(), Y);
     r.ZZ = V.mul(ZZ); r.ZZZ = W.mul(ZZZ);
     return r;
   }
@@ -94,7 +94,7 @@ struct XyzzD {
     }
     Fq PP = Pp.sqr(), PPP = Pp.mul(PP), Q = U1.mul(PP);
     Fq X3 = R.sqr().sub(PPP).sub(Q.dbl());
-    Y = R.mul(Q.sub(X3)).sub(S1.mul(PPP));
+    Y = R.mul_add_mul(Q.sub(X3), S1.neg(), PPP);       // one reduction for the pair
     X = X3;
     ZZ = ZZ.mul(o.ZZ).mul(PP); ZZZ = ZZZ.mul(o.ZZZ).mul(PPP);
   }
@@ -140,7 +140,7 @@ struct JacD {
     rr = rr.dbl();
     Fq HH = H.sqr(), I = HH.dbl().dbl(), J = H.mul(I), V = X.mul(I);
     Fq X3 = rr.sqr().sub(J).sub(V.dbl());
-    Fq Y3 = rr.mul(V.sub(X3)).sub(Y.mul(J).dbl());
+    Fq Y3 = rr.mul_add_mul(V.sub(X3), Y.dbl().neg(), J);   // r (V - X3) - 2 Y1 J, one reduction for the pair
     Z = Z.add(H).sqr().sub(Z1Z1).sub(HH);
     X = X3; Y = Y3;
   }
