@@ -179,7 +179,20 @@ struct Fd {
     cond_sub(r.l, (uint32_t)acc);
     return r;
   }
+  // PC_FIELD_CALLS (tuning experiment): the three field products as real functions (operands by value, in registers)
+  // instead of inlined bodies -- the unrolled mixed addition is ~50 KB of code against a 64 KB instruction cache
+  // shared by two CUs
+#if defined(PC_FIELD_CALLS)
+  static __device__ __noinline__ Fd mul_call(Fd a, Fd b) { return a.template mul_impl<false>(b); }
+  static __device__ __noinline__ Fd sqr_call(Fd a) { return a.sqr_inl(); }
+  __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_call(*this, o); }
+  __device__ __forceinline__ Fd sqr() const { return sqr_call(*this); }
+  __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl(b, c, d); }
+#else
   __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
+  __device__ __forceinline__ Fd sqr() const { return sqr_inl(); }
+  __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl(b, c, d); }
+#endif
 
   // a*b + c*d with ONE reduction: the columns of both products are gathered into the same accumulator before the
   // m_i * p terms, 3 N^2 instead of 4 N^2 partial products for the pair (the sum stays below 2 p^2 < p R, so the
@@ -212,7 +225,7 @@ struct Fd {
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) dual_column_hi<K + 1>(b, c, d, m, mod, acc, hi, t);
   }
-  __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const {
+  __device__ __forceinline__ Fd mul_add_mul_inl(const Fd& b, const Fd& c, const Fd& d) const {
     static_assert(P::BITS < 32 * N, "the fused pair assumes 2 p <= R");
     uint32_t m[N], t[N + 1], mod[N];
     PC_UNROLL for (int i = 0; i < N; i++) mod[i] = P::MOD[i];
@@ -261,7 +274,7 @@ struct Fd {
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) sq_column_hi<K + 1>(d, dm, m, mod, acc, hi, t);
   }
-  __device__ __forceinline__ Fd sqr() const {
+  __device__ __forceinline__ Fd sqr_inl() const {
     static_assert(P::BITS < 32 * N, "squaring assumes that 2a fits N limbs");
     uint32_t d[N], dm[N], m[N], t[N + 1], mod[N];
     PC_UNROLL for (int i = 0; i < N; i++) { mod[i] = P::MOD[i]; d[i] = (l[i] << 1) | (i ? l[i - 1] >> 31 : 0u); dm[i] = l[i] << 1; }
