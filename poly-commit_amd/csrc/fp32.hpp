@@ -102,30 +102,36 @@ struct Fd {
 #define PC_MAC1F(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
   // k partial products per asm statement (hipcc pads every statement with an s_nop).  FIRST: the
   // statement opens a column (`hi` is an output only).
-#define PC_MAC_FNS(NAME, M0, HI)                                                                                        \
+#define PC_MAC_FNS(NAME, M0, HI, YC)                                                                                    \
   static __device__ __forceinline__ void NAME##1(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
-    asm(M0("%2", "%3") : "+v"(acc), HI(hi) : "v"(x[0]), "v"(y[0]) : "vcc");                                              \
+    asm(M0("%2", "%3") : "+v"(acc), HI(hi) : "v"(x[0]), YC(y[0]) : "vcc");                                               \
   }                                                                                                                     \
   static __device__ __forceinline__ void NAME##2(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
     asm(M0("%2", "%3") PC_MAC1("%4", "%5")                                                                               \
-        : "+v"(acc), HI(hi) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc");                                       \
+        : "+v"(acc), HI(hi) : "v"(x[0]), YC(y[0]), "v"(x[1]), YC(y[1]) : "vcc");                                         \
   }                                                                                                                     \
   static __device__ __forceinline__ void NAME##4(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
     asm(M0("%2", "%3") PC_MAC1("%4", "%5") PC_MAC1("%6", "%7") PC_MAC1("%8", "%9")                                       \
         : "+v"(acc), HI(hi)                                                                                              \
-        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc");               \
+        : "v"(x[0]), YC(y[0]), "v"(x[1]), YC(y[1]), "v"(x[2]), YC(y[2]), "v"(x[3]), YC(y[3]) : "vcc");                   \
   }                                                                                                                     \
   static __device__ __forceinline__ void NAME##8(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {   \
     asm(M0("%2", "%3") PC_MAC1("%4", "%5") PC_MAC1("%6", "%7") PC_MAC1("%8", "%9")                                       \
         PC_MAC1("%10", "%11") PC_MAC1("%12", "%13") PC_MAC1("%14", "%15") PC_MAC1("%16", "%17")                          \
         : "+v"(acc), HI(hi)                                                                                              \
-        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]),                        \
-          "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");               \
+        : "v"(x[0]), YC(y[0]), "v"(x[1]), YC(y[1]), "v"(x[2]), YC(y[2]), "v"(x[3]), YC(y[3]),                            \
+          "v"(x[4]), YC(y[4]), "v"(x[5]), YC(y[5]), "v"(x[6]), YC(y[6]), "v"(x[7]), YC(y[7]) : "vcc");                   \
   }
 #define PC_HI_INOUT(h) "+v"(h)
 #define PC_HI_OUT(h) "=&v"(h)
-  PC_MAC_FNS(mac, PC_MAC1, PC_HI_INOUT)
-  PC_MAC_FNS(macf, PC_MAC1F, PC_HI_OUT)
+#define PC_Y_VGPR(v) "v"(v)
+#define PC_Y_SGPR(v) "s"(v)
+  PC_MAC_FNS(mac, PC_MAC1, PC_HI_INOUT, PC_Y_VGPR)
+  PC_MAC_FNS(macf, PC_MAC1F, PC_HI_OUT, PC_Y_VGPR)
+  // the same with the second factor in a scalar register: the modulus limbs of the reduction terms m_i * p_j are
+  // constants (one SGPR operand per VOP3 instruction is allowed), which keeps N vector registers free
+  PC_MAC_FNS(macs, PC_MAC1, PC_HI_INOUT, PC_Y_SGPR)
+  PC_MAC_FNS(macsf, PC_MAC1F, PC_HI_OUT, PC_Y_SGPR)
   template <int CNT, bool FIRST = false>
   static __device__ __forceinline__ void mac_n(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
     if constexpr (CNT >= 8) { if constexpr (FIRST) macf8(acc, hi, x, y); else mac8(acc, hi, x, y); mac_n<CNT - 8>(acc, hi, x + 8, y + 8); }
@@ -133,35 +139,57 @@ struct Fd {
     else if constexpr (CNT >= 2) { if constexpr (FIRST) macf2(acc, hi, x, y); else mac2(acc, hi, x, y); mac_n<CNT - 2>(acc, hi, x + 2, y + 2); }
     else if constexpr (CNT == 1) { if constexpr (FIRST) macf1(acc, hi, x, y); else mac1(acc, hi, x, y); }
   }
+  template <int CNT, bool FIRST = false>
+  static __device__ __forceinline__ void mac_ns(uint64_t& acc, uint32_t& hi, const uint32_t* x, const uint32_t* y) {
+    if constexpr (CNT >= 8) { if constexpr (FIRST) macsf8(acc, hi, x, y); else macs8(acc, hi, x, y); mac_ns<CNT - 8>(acc, hi, x + 8, y + 8); }
+    else if constexpr (CNT >= 4) { if constexpr (FIRST) macsf4(acc, hi, x, y); else macs4(acc, hi, x, y); mac_ns<CNT - 4>(acc, hi, x + 4, y + 4); }
+    else if constexpr (CNT >= 2) { if constexpr (FIRST) macsf2(acc, hi, x, y); else macs2(acc, hi, x, y); mac_ns<CNT - 2>(acc, hi, x + 2, y + 2); }
+    else if constexpr (CNT == 1) { if constexpr (FIRST) macsf1(acc, hi, x, y); else macs1(acc, hi, x, y); }
+  }
   // number of non-zero modulus limbs among MOD[lo..hi]
   static constexpr int nz_mod(int lo, int hi_) { int c = 0; for (int i = lo; i <= hi_; i++) c += P::MOD[i] != 0; return c; }
+  // reduction terms of column K: m_i * p_{K-i} for i = I0..I1 (zero limbs of p skipped), the limbs of p as scalar constants
+  template <int K, int I0, int I1, bool FIRST>
+  static __device__ __forceinline__ void red_terms(const uint32_t* m, uint64_t& acc, uint32_t& hi) {
+    constexpr int CR = I1 >= I0 ? nz_mod(K - I1, K - I0) : 0;
+    if constexpr (CR > 0) {
+      uint32_t x[CR], y[CR];
+      int c = 0;
+      PC_UNROLL for (int i = I0; i <= I1; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = P::MOD[K - i]; c++; }
+      mac_ns<CR, FIRST>(acc, hi, x, y);
+    }
+  }
+  static __device__ __forceinline__ void red_last(const uint32_t* mk, uint64_t& acc, uint32_t& hi) {
+    const uint32_t p0 = P::MOD[0];
+    macs1(acc, hi, mk, &p0);
+  }
 
   // UNIT: the second operand is the raw integer 1 (Montgomery -> canonical conversion): the only
   // a_i * b_j left in column K is a_K * 1, so a column is one product plus the reduction terms.
   template <int K, bool UNIT>
   __device__ __forceinline__ void column_lo(const Fd& o, uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi) const {
     // column K < N: a_i*b_{K-i} (i = 0..K), m_i*p_{K-i} (i = 0..K-1, p_{K-i} != 0)
-    constexpr int CNT = (UNIT ? 1 : K + 1) + nz_mod(1, K);
-    uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
+    constexpr int CNT = UNIT ? 1 : K + 1;
+    uint32_t x[CNT], y[CNT];
     int c = 0;
     if constexpr (UNIT) { x[c] = l[K]; y[c] = o.l[0]; c++; }
     else { PC_UNROLL for (int i = 0; i <= K; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; } }
-    PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
     mac_n<CNT, true>(acc, hi, x, y);
+    red_terms<K, 0, K - 1, false>(m, acc, hi);
     m[K] = (uint32_t)acc * P::INV;
-    mac1(acc, hi, &m[K], &mod[0]);
+    red_last(&m[K], acc, hi);
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < N) column_lo<K + 1, UNIT>(o, m, mod, acc, hi);
   }
   template <int K, bool UNIT>
   __device__ __forceinline__ void column_hi(const Fd& o, const uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi, uint32_t* t) const {
     // column K >= N: i = K-N+1 .. N-1
-    constexpr int CNT = (UNIT ? 0 : 2 * N - 1 - K) + nz_mod(K - N + 1, N - 1);
+    constexpr int CNT = UNIT ? 0 : 2 * N - 1 - K;
     uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
     int c = 0;
     if constexpr (!UNIT) { PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; } }
-    PC_UNROLL for (int i = K - N + 1; i < N; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
     mac_n<CNT, true>(acc, hi, x, y);      // (the last column has no products: its stale carry word only reaches discarded bits)
+    red_terms<K, K - N + 1, N - 1, CNT == 0>(m, acc, hi);
     t[K - N] = (uint32_t)acc;
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) column_hi<K + 1, UNIT>(o, m, mod, acc, hi, t);
@@ -179,48 +207,39 @@ struct Fd {
     cond_sub(r.l, (uint32_t)acc);
     return r;
   }
-  // PC_FIELD_CALLS (tuning experiment): the three field products as real functions (operands by value, in registers)
-  // instead of inlined bodies -- the unrolled mixed addition is ~50 KB of code against a 64 KB instruction cache
-  // shared by two CUs
-#if defined(PC_FIELD_CALLS)
-  static __device__ __noinline__ Fd mul_call(Fd a, Fd b) { return a.template mul_impl<false>(b); }
-  static __device__ __noinline__ Fd sqr_call(Fd a) { return a.sqr_inl(); }
-  __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_call(*this, o); }
-  __device__ __forceinline__ Fd sqr() const { return sqr_call(*this); }
-  __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl(b, c, d); }
-#else
   __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
   __device__ __forceinline__ Fd sqr() const { return sqr_inl(); }
   __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl(b, c, d); }
-#endif
+  // (the three products as real functions -- operands by value, in registers -- were measured against the ~50 KB of
+  // inlined code of a mixed addition: accumulate 36.8 -> 44.0 ms; the instruction cache is not what limits it)
 
   // a*b + c*d with ONE reduction: the columns of both products are gathered into the same accumulator before the
   // m_i * p terms, 3 N^2 instead of 4 N^2 partial products for the pair (the sum stays below 2 p^2 < p R, so the
   // result is below 2 p and the single conditional subtraction of mul() still canonicalises it).
   template <int K>
   __device__ __forceinline__ void dual_column_lo(const Fd& b, const Fd& c, const Fd& d, uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi) const {
-    constexpr int CNT = 2 * (K + 1) + nz_mod(1, K);
+    constexpr int CNT = 2 * (K + 1);
     uint32_t x[CNT], y[CNT];
     int n = 0;
     PC_UNROLL for (int i = 0; i <= K; i++) { x[n] = l[i]; y[n] = b.l[K - i]; n++; }
     PC_UNROLL for (int i = 0; i <= K; i++) { x[n] = c.l[i]; y[n] = d.l[K - i]; n++; }
-    PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[n] = m[i]; y[n] = mod[K - i]; n++; }
     mac_n<CNT, true>(acc, hi, x, y);
+    red_terms<K, 0, K - 1, false>(m, acc, hi);
     m[K] = (uint32_t)acc * P::INV;
-    mac1(acc, hi, &m[K], &mod[0]);
+    red_last(&m[K], acc, hi);
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < N) dual_column_lo<K + 1>(b, c, d, m, mod, acc, hi);
   }
   template <int K>
   __device__ __forceinline__ void dual_column_hi(const Fd& b, const Fd& c, const Fd& d, const uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi,
                                                  uint32_t* t) const {
-    constexpr int CNT = 2 * (2 * N - 1 - K) + nz_mod(K - N + 1, N - 1);
+    constexpr int CNT = 2 * (2 * N - 1 - K);
     uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
     int n = 0;
     PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[n] = l[i]; y[n] = b.l[K - i]; n++; }
     PC_UNROLL for (int i = K - N + 1; i < N; i++) { x[n] = c.l[i]; y[n] = d.l[K - i]; n++; }
-    PC_UNROLL for (int i = K - N + 1; i < N; i++) if (P::MOD[K - i] != 0) { x[n] = m[i]; y[n] = mod[K - i]; n++; }
     mac_n<CNT, true>(acc, hi, x, y);
+    red_terms<K, K - N + 1, N - 1, CNT == 0>(m, acc, hi);
     t[K - N] = (uint32_t)acc;
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) dual_column_hi<K + 1>(b, c, d, m, mod, acc, hi, t);
@@ -245,15 +264,15 @@ struct Fd {
   template <int K>
   __device__ __forceinline__ void sq_column_lo(const uint32_t* d, const uint32_t* dm, uint32_t* m, const uint32_t* mod, uint64_t& acc, uint32_t& hi) const {
     constexpr int NCROSS = (K + 1) / 2;                      // i < j, i + j = K, i = 0 .. NCROSS-1
-    constexpr int CNT = NCROSS + ((K & 1) ? 0 : 1) + nz_mod(1, K);
+    constexpr int CNT = NCROSS + ((K & 1) ? 0 : 1);
     uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
     int c = 0;
     PC_UNROLL for (int i = 0; i < NCROSS; i++) { x[c] = l[i]; y[c] = (K - i == i + 1) ? dm[K - i] : d[K - i]; c++; }
     if constexpr ((K & 1) == 0) { x[c] = l[K / 2]; y[c] = l[K / 2]; c++; }
-    PC_UNROLL for (int i = 0; i < K; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
     mac_n<CNT, true>(acc, hi, x, y);
+    red_terms<K, 0, K - 1, CNT == 0>(m, acc, hi);
     m[K] = (uint32_t)acc * P::INV;
-    mac1(acc, hi, &m[K], &mod[0]);
+    red_last(&m[K], acc, hi);
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < N) sq_column_lo<K + 1>(d, dm, m, mod, acc, hi);
   }
@@ -263,13 +282,13 @@ struct Fd {
     constexpr int I0 = K - N + 1;                            // i = I0 .. N-1 with j = K - i; cross terms: i < j  <=>  2 i < K
     constexpr int NCROSS = (K + 1) / 2 - I0 > 0 ? (K + 1) / 2 - I0 : 0;
     constexpr int DIAG = ((K & 1) == 0 && K / 2 < N) ? 1 : 0;
-    constexpr int CNT = NCROSS + DIAG + nz_mod(I0, N - 1);
+    constexpr int CNT = NCROSS + DIAG;
     uint32_t x[CNT > 0 ? CNT : 1], y[CNT > 0 ? CNT : 1];
     int c = 0;
     PC_UNROLL for (int i = I0; i < I0 + NCROSS; i++) { x[c] = l[i]; y[c] = (K - i == i + 1) ? dm[K - i] : d[K - i]; c++; }
     if constexpr (DIAG) { x[c] = l[K / 2]; y[c] = l[K / 2]; c++; }
-    PC_UNROLL for (int i = I0; i < N; i++) if (P::MOD[K - i] != 0) { x[c] = m[i]; y[c] = mod[K - i]; c++; }
     mac_n<CNT, true>(acc, hi, x, y);
+    red_terms<K, I0, N - 1, CNT == 0>(m, acc, hi);
     t[K - N] = (uint32_t)acc;
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) sq_column_hi<K + 1>(d, dm, m, mod, acc, hi, t);
