@@ -241,26 +241,11 @@ struct AccumulateBody {
         }
         // Software pipeline, issued right before the long addition: the base of entry p+1 (its index
         // arrived an iteration ago) and the index of entry p+2.
-#if defined(PC_ACC_NO_REG_PREFETCH)
-        // three waves per SIMD instead of a register copy of the next base: the gather of entry p+1 is only warmed
-        // (one dword per 128-byte line it touches, result unused), the point itself is loaded when it is needed
-        uint32_t nnval = nval;
-        if (p + 1 < e) {
-          const uint32_t* nb = bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride;
-          uint32_t d0, d1;
-          asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:92" : "=&v"(d0), "=&v"(d1) : "v"(nb) : "memory");
-        }
-        if (p + 2 < e) nnval = entries[p + 2];
-        acc.add_affine(pt.neg_if(val >> 31));
-        val = nval; nval = nnval;
-        if (p + 1 < e) pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * g.pt_stride);
-#else
         uint32_t nnval = nval; AffD<C> npt = pt;
         if (p + 1 < e) npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride);
         if (p + 2 < e) nnval = entries[p + 2];
         acc.add_affine(pt.neg_if(val >> 31));
         val = nval; nval = nnval; pt = npt;
-#endif
       }
       flush(acc, k, run_lo >= s && boundary <= e, t, first, k0, k1);
       last = acc;
