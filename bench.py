@@ -37,6 +37,14 @@ _RESULT_FD = os.dup(1)
 os.dup2(2, 1)
 
 
+# The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The MSM
+# pipelines keep seven streams busy; once RCCL adds its own, independent streams share a queue and serialise
+# (measured with one rank: 76.2 ms/step at 4 queues, 72.5 at 8 = the figure without RCCL).  Must be set before HIP
+# initialises, i.e. before torch touches the GPU.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def emit(obj):
     os.write(_RESULT_FD, (json.dumps(obj) + "\n").encode())
 
@@ -282,7 +290,7 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
     pending = collections.deque()
 
     def drain():
-        if dist is not None and pending:
+        if dist is not None and pending and not os.environ.get("PC_DIAG_DIST_NO_EXCHANGE"):
             job.exchange(None, 0, [pending.popleft() for _ in range(len(pending))])
         while pending:
             pending.popleft().result()
@@ -292,7 +300,7 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
         # latency-bound tail of one MSM overlaps the bucket accumulation of the next
         # (N > 1: the open's exchange step -- shard evaluation + all_gather of one Fr per rank -- runs first, while
         # the previous step's MSMs are still in flight, so the blocking collective does not drain the pipelines)
-        if dist is not None and depth > 0:
+        if dist is not None and depth > 0 and not os.environ.get("PC_DIAG_DIST_NO_EXCHANGE"):
             # N > 1, pipelined: ONE collective per step -- this step's shard evaluations (the division carries) travel
             # with the partial points of the step that left the pipeline (ShardedKzg.exchange)
             done = [pending.popleft() for _ in range(max(0, len(pending) - 2 * (depth - 1)))]
