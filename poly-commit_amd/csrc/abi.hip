@@ -331,8 +331,8 @@ int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t
     if ((uint64_t)Wd * srs->n >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;     // entry = 31-bit table index + sign
     // 96-byte points (BLS12-381) are padded to one 128-byte line each: a gather then touches one
     // DRAM line instead of 1.5 on average (the table no longer fits the 256 MB MALL)
-    uint32_t pt_stride = (uint32_t)srs->aw;
-    if (const char* e = getenv("PC_HIP_TBL_PAD")) { if (atoi(e) && srs->aw == 24) pt_stride = 32; }
+    uint32_t pt_stride = srs->aw == 24 ? 32u : (uint32_t)srs->aw;
+    if (const char* e = getenv("PC_HIP_TBL_PAD")) { if (!atoi(e)) pt_stride = (uint32_t)srs->aw; }      // =0: packed 96-byte rows
     const size_t bytes = (size_t)Wd * srs->n * pt_stride * 4;
     uint32_t* table = (uint32_t*)ctx->be.alloc(bytes);
     try {

@@ -11,6 +11,7 @@ timeout -k 10 900 python bench.py > gpurun_out/d_bench_n1.json 2> gpurun_out/d_b
 timeout -k 10 600 python bench.py --inflight 0 --no-cpu-baseline > gpurun_out/d_bench_n1_inflight0.json 2>/dev/null
 timeout -k 10 600 python bench.py --precompute 0 --no-cpu-baseline > gpurun_out/d_bench_n1_notable.json 2>/dev/null
 timeout -k 10 600 python bench.py --workload ntt > gpurun_out/d_bench_ntt.json 2>/dev/null
+(export MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1; PC_BENCH_FORCE_DIST=1 timeout -k 10 600 python bench.py --no-cpu-baseline --no-h2d --secondary-log-degree 0 > gpurun_out/d_bench_rccl_1rank.json 2>/dev/null)
 timeout -k 10 600 python bench.py --workload batch > gpurun_out/d_bench_batch.json 2>/dev/null
 timeout -k 10 300 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_out/d_ipa_2p22.json
 timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/d_lincomb.json
@@ -39,7 +40,7 @@ cd $R
 find gpurun_out -name "*.csv" -size +30M -delete 2>/dev/null
 python - <<'PY'
 import json
-for f in ("d_bench_n1", "d_bench_n1_inflight0", "d_bench_n1_notable"):
+for f in ("d_bench_n1", "d_bench_n1_inflight0", "d_bench_n1_notable", "d_bench_rccl_1rank"):
     try:
         d = json.load(open(f"gpurun_out/{f}.json")); s = d.get("secondary")
         print(f, "2^24", round(d["ms_per_step"], 2), round(d["blocking_msm_ms"], 2), {k: round(v, 2) for k, v in d["msm_phase_ms"].items()},
