@@ -24,7 +24,7 @@ SIMDS, CLOCK = 256 * 4, 2.4e9
 def main():
     *paths, out = sys.argv[1:]
     doc = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY "
-                     "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES -- python bench.py ... --inflight 0 (see tools/gpu_run_*.sh)",
+                     "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES -- python bench.py ... --inflight 0 (see tools/gpu_full_run.sh)",
            "units": "SQ_* cycle counters are quad-cycles summed over waves; per-launch averages", "kernels": {}}
     for path in paths:
         acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
