@@ -35,6 +35,7 @@ struct LdsPoints {
 template <class C>
 __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t lgK, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
                                                           const uint32_t* x, const uint32_t* old_in, uint32_t* out) {
+  PC_LATENCY_KERNEL();
   typedef XyzzD<C> Pt;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   LdsPoints<C> lds{smem, K};
@@ -119,6 +120,7 @@ __global__ void PC_ACC_BOUNDS k_accumulate(AccumulateBody<C> b, uint32_t lanes) 
 // it has launches but no additions left (it still handles buckets spanning three or more chunks: skewed scalars).
 template <class C>
 __global__ void __launch_bounds__(64) k_accumulate_edges(AccumulateBody<C> b, uint32_t lanes) {
+  PC_LATENCY_KERNEL();
   typedef XyzzD<C> Pt;
   const uint32_t k = blockIdx.x * 64 + threadIdx.x;
   const uint64_t t64 = (uint64_t)(k + 1) * 256;           // first lane of workgroup k + 1
@@ -144,6 +146,7 @@ template <class C>
 __global__ void __launch_bounds__(256) k_seg_reduce_tail(MsmGeom g, uint32_t level, uint32_t slots, uint32_t* pk0, uint32_t* pk1,
                                                          uint32_t* pp0, uint32_t* pp1, int cur, const uint32_t* offsets,
                                                          uint32_t* buckets) {
+  PC_LATENCY_KERNEL();
   uint32_t* pk[2] = {pk0, pk1}; uint32_t* pp[2] = {pp0, pp1};
   for (;;) {
     const uint32_t T2l = level == 1 ? g.T2 : g.T2b;
