@@ -2,6 +2,7 @@
 // low-priority tail stream), every kernel body launched through a single generic __global__ wrapper,
 // the u32 scan as three small kernels of its own.
 #pragma once
+#include <string.h>
 #include <hip/hip_runtime.h>
 #include <stdexcept>
 #include <string>
@@ -118,8 +119,11 @@ struct HipBackend {
       int lo = 0, hi = 0;
       PC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
       (void)hi;    // (raising the main queues to `hi` as well measured the same at 2^20 and 4 % slower at 2^22)
-      PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, 0));
-      PC_HIP_CHECK(hipStreamCreateWithPriority(&tail_stream, hipStreamNonBlocking, lo));
+      int tail_prio = lo, main_prio = 0;
+      if (const char* e = getenv("PC_HIP_TAIL_PRIO")) tail_prio = !strcmp(e, "hi") ? hi : !strcmp(e, "lo") ? lo : 0;   // tuning experiments
+      if (const char* e = getenv("PC_HIP_MAIN_PRIO")) main_prio = !strcmp(e, "hi") ? hi : !strcmp(e, "lo") ? lo : 0;
+      PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, main_prio));
+      PC_HIP_CHECK(hipStreamCreateWithPriority(&tail_stream, hipStreamNonBlocking, tail_prio));
       PC_HIP_CHECK(hipEventCreateWithFlags(&tail_ev, hipEventDisableTiming));
       main_stream = stream;
     } else {
