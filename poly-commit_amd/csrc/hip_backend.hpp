@@ -2,6 +2,7 @@
 // low-priority tail stream), every kernel body launched through a single generic __global__ wrapper,
 // the u32 scan as three small kernels of its own.
 #pragma once
+#include <type_traits>
 #include <string.h>
 #include <hip/hip_runtime.h>
 #include <stdexcept>
@@ -23,7 +24,7 @@ struct HipError : std::runtime_error {
   } while (0)
 
 // The short, latency-bound kernels around the bucket accumulation (division scan levels, bucket / segmented reduction
-// levels, cooperative reductions) usually share the chip with an accumulation of another pipeline whose waves issue
+// levels, cooperative reductions; a k_run body opts in, see body_latency_bound) usually share the chip with an accumulation of another pipeline whose waves issue
 // multiply-adds back to back: they raise their waves' issue priority so that they finish while the accumulation runs
 // instead of crawling beside it (pipelined trace at 2^20 before: division 2.6 ms instead of 0.6, reduction levels 3 ms
 // instead of 0.3, and the open's sort waiting for the division): commit+open 6.58 -> 5.78 ms at 2^20, 64 x 2^20 batch
@@ -35,9 +36,15 @@ struct HipError : std::runtime_error {
 #define PC_LATENCY_KERNEL() ((void)0)
 #endif
 
+// a kernel body opts in with `static constexpr bool LATENCY_BOUND = true;` (the heavy streaming bodies -- digits, histogram,
+// scatter of the table-free sort, table builds, hashes -- must not: prioritised, they starve the accumulation: the table-free
+// 2^24 step went from 108.6 to 138.4 ms when every k_run kernel raised its priority)
+template <class B, class = void> struct body_latency_bound : std::false_type {};
+template <class B> struct body_latency_bound<B, std::void_t<decltype(B::LATENCY_BOUND)>> : std::bool_constant<B::LATENCY_BOUND> {};
+
 template <class Body>
 __global__ void __launch_bounds__(256) k_run(Body body, uint32_t lanes) {
-  PC_LATENCY_KERNEL();
+  if constexpr (body_latency_bound<Body>::value) PC_LATENCY_KERNEL();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < lanes) body(i);
 }

@@ -263,6 +263,7 @@ struct AccumulateBody {
 // ---------------------------------------------------------------------------------------
 template <class C>
 struct SegReduceBody {
+  static constexpr bool LATENCY_BOUND = true;   // raised wave priority beside an accumulation (hip_backend.hpp)
   typedef XyzzD<C> Pt;
   MsmGeom g;
   uint32_t level;            // level of the INPUT slots (>= 1)
@@ -305,6 +306,7 @@ struct SegReduceBody {
 // ---------------------------------------------------------------------------------------
 template <class C>
 struct BucketReduceBody {
+  static constexpr bool LATENCY_BOUND = true;   // raised wave priority beside an accumulation (hip_backend.hpp)
   typedef XyzzD<C> Pt;
   uint32_t m_in;             // elements per window at this level
   uint32_t K;                // group size (power of two, <= m_in)
@@ -330,6 +332,7 @@ struct BucketReduceBody {
 // one launch instead of (1 + l).
 template <class C>
 struct BucketLevelBody {
+  static constexpr bool LATENCY_BOUND = true;   // raised wave priority beside an accumulation (hip_backend.hpp)
   typedef XyzzD<C> Pt;
   uint32_t K, weight_off, cnt, n_old;
   const uint32_t* x;           // weighted input, cnt * K points

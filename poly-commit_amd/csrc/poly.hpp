@@ -14,6 +14,7 @@ namespace pc {
 // out[u] = Horner(x[u*G .. min(count,(u+1)*G)), high index first, factor f, carry-in 0)
 template <class FrP>
 struct ScanUpBody {
+  static constexpr bool LATENCY_BOUND = true;   // raised wave priority beside an accumulation (hip_backend.hpp)
   typedef Fd<FrP> F;
   const uint32_t* x; uint32_t count; uint32_t G; F f; uint32_t* out;
   const uint32_t* extra;      // optional virtual element x[count - 1] (the caller's carry-in), else null
@@ -29,6 +30,7 @@ struct ScanUpBody {
 // group u: acc = carry_in[u] (or 0); for j high..low: [pre] out[j] = acc; acc = x[j] + f*acc; [post] out[j] = acc
 template <class FrP>
 struct ScanDownBody {
+  static constexpr bool LATENCY_BOUND = true;   // raised wave priority beside an accumulation (hip_backend.hpp)
   typedef Fd<FrP> F;
   const uint32_t* x; uint32_t count; uint32_t G; F f;
   const uint32_t* carry_in;   // one per group, may be null

@@ -8,6 +8,7 @@ for f in bench_n1 bench_n1_inflight0 bench_n1_notable bench_ntt bench_rccl_1rank
 cp $G/d_bench_batch.json profiles/r02_bench_batch_bn254.json
 cp $G/d_ipa_2p22.json profiles/r02_ipa_pallas_2p22.json
 cp $G/d_lincomb.json profiles/r02_lincomb_bn254.json
+[ -f $G/d_hyrax.jsonl ] && cp $G/d_hyrax.jsonl profiles/r02_hyrax_bn254.jsonl
 cp $G/d_prof24/bench_kernel_stats.csv profiles/r02_bench_2p24_kernel_stats.csv
 cp $G/d_prof20/bench_kernel_stats.csv profiles/r02_bench_2p20_kernel_stats.csv
 cp $G/d_profntt/bench_kernel_stats.csv profiles/r02_ntt_kernel_stats.csv

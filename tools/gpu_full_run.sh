@@ -15,6 +15,7 @@ timeout -k 10 600 python bench.py --workload ntt > gpurun_out/d_bench_ntt.json 2
 timeout -k 10 600 python bench.py --workload batch > gpurun_out/d_bench_batch.json 2>/dev/null
 timeout -k 10 300 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_out/d_ipa_2p22.json
 timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/d_lincomb.json
+timeout -k 10 300 python tools/hyrax_timing.py 2>/dev/null | grep workload > gpurun_out/d_hyrax.jsonl
 
 
 cd /tmp && export TMPDIR=/tmp
