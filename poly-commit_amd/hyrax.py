@@ -38,6 +38,20 @@ def _to_mont(curve, v):
     return _int_to_limbs(v % p * _R % p)
 
 
+def _vec_to_int(curve, arr):
+    """(k, 4) Montgomery limbs -> list of canonical ints."""
+    p = FR_MODULUS[curve]
+    rinv = pow(_R, -1, p)
+    raw = np.ascontiguousarray(arr, dtype="<u8").reshape(-1, 4).tobytes()
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") * rinv % p for i in range(len(raw) // 32)]
+
+
+def _vec_to_mont(curve, vals):
+    """list of canonical ints -> (k, 4) Montgomery limbs."""
+    p = FR_MODULUS[curve]
+    return np.frombuffer(b"".join((v % p * _R % p).to_bytes(32, "little") for v in vals), dtype="<u8").astype(np.uint64).reshape(-1, 4)
+
+
 def tensor_prime(curve, values):
     """hyrax/utils.rs:27-39 on canonical ints."""
     p = FR_MODULUS[curve]
@@ -109,17 +123,17 @@ def open(key, state, point_mont, r_eval, d_mont, r_d, r_b, c):   # noqa: A001 (t
     if n % 2 == 1 or 1 << (n // 2) != dim:
         raise InvalidNumberOfVariables(f"point of {n} variables, matrix of dimension {dim}")
     l, r = _tensors(curve, point_mont)
-    l_m = np.stack([_to_mont(curve, v) for v in l])
+    l_m = _vec_to_mont(curve, l)
     dev = mat.device
     lt = torch.empty((dim, 4), dtype=torch.int64, device=dev)
     ctx.fr_lincomb(curve, [mat.data_ptr() + 32 * dim * i for i in range(dim)], l_m, n_out=dim, out=lt.data_ptr(), lens=[dim] * dim)   # :341
-    r_lt = sum(a * _to_int(curve, b) for a, b in zip(l, rands)) % p                                                 # :345-348
-    r_dev = torch.from_numpy(np.stack([_to_mont(curve, v) for v in r]).view(np.int64)).to(dev)
+    r_lt = sum(a * b for a, b in zip(l, _vec_to_int(curve, rands))) % p                                                 # :345-348
+    r_dev = torch.from_numpy(_vec_to_mont(curve, r).view(np.int64)).to(dev)
     ev = ctx.fr_dot(curve, lt.data_ptr(), r_dev.data_ptr(), dim)                                                    # :350
     g0 = key.com_key[0]
     com_eval = _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, g0, ev), _ffi.point_mul(curve, key.h, r_eval)]))    # :353
     d_mont = np.ascontiguousarray(d_mont, dtype=np.uint64).reshape(dim, 4)
-    b = sum(a * _to_int(curve, x) for a, x in zip(r, d_mont)) % p                                                   # :364
+    b = sum(a * x for a, x in zip(r, _vec_to_int(curve, d_mont))) % p                                                   # :364
     d_ext = torch.from_numpy(np.concatenate([d_mont, np.asarray(r_d, dtype=np.uint64).reshape(1, 4)]).view(np.int64)).to(dev)
     com_d = key.ext(dim).msm(d_ext.data_ptr(), n=dim + 1, montgomery=True)[0]                                       # :368
     com_b = _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, g0, _to_mont(curve, b)), _ffi.point_mul(curve, key.h, r_b)]))   # :372
@@ -148,13 +162,13 @@ def check(key, row_coms, point_mont, proof, c):
     com_eval, com_d, com_b, z, z_d, z_b = proof
     l, r = _tensors(curve, point_mont)
     z = np.ascontiguousarray(z, dtype=np.uint64).reshape(dim, 4)
-    ip = sum(a * _to_int(curve, x) for a, x in zip(r, z)) % p
+    ip = sum(a * x for a, x in zip(r, _vec_to_int(curve, z))) % p
     com_dp = _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, key.com_key[0], _to_mont(curve, ip)), _ffi.point_mul(curve, key.h, z_b)]))   # :486
     if not (com_dp == _ffi.points_sum(curve, np.stack([_ffi.point_mul(curve, com_eval, c), com_b]))).all():
         return False
     rows = ctx.upload_srs(curve, row_coms)
     try:
-        l_dev = torch.from_numpy(np.stack([_to_mont(curve, v) for v in l]).view(np.int64)).cuda()
+        l_dev = torch.from_numpy(_vec_to_mont(curve, l).view(np.int64)).cuda()
         t_prime = rows.msm(l_dev.data_ptr(), n=dim, montgomery=True)[0]                                             # :495
     finally:
         rows.free()

@@ -29,11 +29,11 @@ _R = 1 << 256
 
 
 def _limbs_to_int(a):
-    return sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(a, dtype=np.uint64).reshape(-1)))
+    return int.from_bytes(np.ascontiguousarray(a, dtype="<u8").tobytes(), "little")
 
 
 def _int_to_limbs(v):
-    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    return np.frombuffer(int(v).to_bytes(32, "little"), dtype="<u8").astype(np.uint64)
 
 
 class HipEngine:
