@@ -557,7 +557,9 @@ struct MsmConfig {
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
   uint32_t seg_tail_lanes = 256;         // seg-reduce levels with at most this many lanes run inside one launch
-  uint32_t coop_max_points = 1u << 17;   // levels with more points than this use the serial fan-in K0
+  uint32_t coop_max_points = 1u << 17;   // levels with more points than this use the serial fan-in K0 (cooperative levels from the
+                                         // first level on -- 7 + 6 + 6 instead of 16 + 8 + 8 dependent additions at 2^19 buckets --
+                                         // measured slower: bucket reduction 1.82 vs 1.55 ms on the same box; PC_HIP_COOP_MAX_LOG2)
   // Precomputed window table of a resident SRS (pc_hip_srs_precompute): calls of at least tbl_min_n
   // pairs run with window width tbl_c against tbl[w][i] = 2^(tbl_c w) P_i and ONE shared bucket set.
   const uint32_t* tbl = nullptr;
@@ -814,7 +816,17 @@ class MsmPlan {
     while (m > 1) {
       // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
       // points the chain length is all that matters: workgroup-cooperative "bits" levels (K1).
-      uint32_t K = ((size_t)g_.W * m > cfg_.coop_max_points) ? (tbl ? cfg_.tbl_K0 : cfg_.K0) : cfg_.K1; if (K > m) K = m;
+      uint32_t K;
+      if ((size_t)g_.W * m > cfg_.coop_max_points) K = tbl ? cfg_.tbl_K0 : cfg_.K0;
+      else {
+        // the remaining log2(m) bits are split evenly over the fewest cooperative levels of at most log2(K1) bits each:
+        // the chain is one addition per bit, so 19 bits cost 7 + 6 + 6 dependent additions, not 8 + 8 + a serial tail
+        uint32_t rem = 0; while ((1u << rem) < m) rem++;
+        uint32_t lg1 = 0; while ((1u << lg1) < cfg_.K1) lg1++;
+        const uint32_t nl = (rem + lg1 - 1) / lg1;
+        K = 1u << ((rem + nl - 1) / nl);
+      }
+      if (K > m) K = m;
       uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
       const bool bits = K >= 16;
       const uint32_t woff = n_levels_ == 0 ? 1u : 0u;
