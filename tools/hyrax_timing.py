@@ -37,10 +37,12 @@ def main():
         for _ in range(reps):
             row_coms, state = hyrax.commit(key, evals, rands)
         commit_ms = (time.perf_counter() - t0) / reps * 1e3
+        hyrax.open(key, state, point, rnd[0], rnd[1:1 + dim], rnd[1 + dim], rnd[2 + dim], c)      # first call allocates the MSM pipelines of the key
         t0 = time.perf_counter()
         for _ in range(reps):
             proof, ev = hyrax.open(key, state, point, rnd[0], rnd[1:1 + dim], rnd[1 + dim], rnd[2 + dim], c)
         open_ms = (time.perf_counter() - t0) / reps * 1e3
+        hyrax.check(key, row_coms, point, proof, c)
         t0 = time.perf_counter()
         for _ in range(reps):
             ok = hyrax.check(key, row_coms, point, proof, c)
