@@ -12,17 +12,85 @@
 
 namespace pc {
 
+// One MSM pipeline.  With PC_HIP_GRAPHS=1 a call that repeats an earlier one exactly (same resident bases, same device
+// scalar buffer, same length -- the late rounds of an IPA opening, a prover that keeps its buffers) replays the ~25
+// launches of the MSM from a captured hipGraph: the first occurrence runs normally (it also grows every lazily sized
+// workspace), the second is captured, later ones are one hipGraphLaunch.  Off by default: measured on one box, it
+// changed nothing (2^20 commit+open 5.79-5.82 vs 5.81-5.84 ms, blocking MSM 3.86 vs 3.85 ms, Pallas IPA open 126.3 vs
+// 126.6 ms) -- the launches are issued asynchronously behind running kernels, and the six (pipeline, buffer) pairs of an
+// IPA's late rounds pay one capture + instantiation each for three or four replays.
 template <class C>
 struct MsmRunnerT : MsmRunner {
   HipBackend& be;
   MsmPlan<C, HipBackend> plan;
-  MsmRunnerT(HipBackend& b, size_t n, const MsmConfig& cfg, uint32_t subs = 0) : be(b), plan(b, n, cfg, subs) {}
+  struct CallKey {
+    const uint32_t* bases; uint32_t base_off; const uint32_t* scalars; size_t n; bool from_mont;
+    bool operator==(const CallKey& o) const { return bases == o.bases && base_off == o.base_off && scalars == o.scalars && n == o.n && from_mont == o.from_mont; }
+  };
+  struct GraphSlot { CallKey key; int seen = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; uint64_t stamp = 0; };
+  static constexpr int GRAPH_SLOTS = 4;
+  GraphSlot slots[GRAPH_SLOTS];
+  uint64_t clock = 0;
+  bool graphs_on;
+  hipEvent_t join_ev = nullptr;
+  MsmRunnerT(HipBackend& b, size_t n, const MsmConfig& cfg, uint32_t subs = 0) : be(b), plan(b, n, cfg, subs) {
+    const char* e = getenv("PC_HIP_GRAPHS");
+    graphs_on = e && !strcmp(e, "1") && subs == 0;
+  }
+  ~MsmRunnerT() override {
+    for (auto& s : slots) drop(s);
+    if (join_ev) (void)hipEventDestroy(join_ev);
+  }
+  static void drop(GraphSlot& s) {
+    if (s.exec) (void)hipGraphExecDestroy(s.exec);
+    if (s.graph) (void)hipGraphDestroy(s.graph);
+    s.exec = nullptr; s.graph = nullptr; s.seen = 0;
+  }
+  GraphSlot* slot_for(const CallKey& k) {
+    GraphSlot* lru = &slots[0];
+    for (auto& s : slots) { if (s.seen && s.key == k) return &s; if (s.stamp < lru->stamp) lru = &s; }
+    drop(*lru); lru->key = k;
+    return lru;
+  }
+  // capture the launch sequence of plan.enqueue() on the pipeline's queues into slot s; false: capture unavailable
+  bool capture(GraphSlot& s, const uint32_t* bases, uint32_t base_off, const uint32_t* sdev, size_t n, bool from_mont) {
+    hipStream_t origin = be.stream;
+    if (hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ok = true;
+    try {
+      plan.enqueue(bases, base_off, sdev, n, from_mont);
+      if (be.tail_stream) {     // the reductions forked to the tail queue: join them back before the capture ends
+        if (!join_ev) PC_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+        PC_HIP_CHECK(hipEventRecord(join_ev, be.tail_stream));
+        PC_HIP_CHECK(hipStreamWaitEvent(origin, join_ev, 0));
+      }
+    } catch (...) { ok = false; }
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(origin, &g) != hipSuccess || !g) { (void)hipGetLastError(); ok = false; }
+    if (ok && hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); s.exec = nullptr; ok = false; }
+    if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
+    s.graph = g;
+    return true;
+  }
   void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) override {
     const uint32_t* sdev = (const uint32_t*)scalars;
     be.n_ev = 0; be.mark();
     if (where == PC_MEM_HOST && n) {
       be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
       sdev = plan.scalar_staging();
+    }
+    if (graphs_on && !be.timing && where == PC_MEM_DEVICE && n >= 32) {
+      GraphSlot* s = slot_for(CallKey{bases, base_off, sdev, n, from_mont});
+      s->stamp = ++clock;
+      if (s->seen >= 1 && !s->exec && !capture(*s, bases, base_off, sdev, n, from_mont)) graphs_on = false;   // this runner stays on plain launches
+      if (s->exec) {
+        plan.prepare_replay(n);
+        PC_HIP_CHECK(hipGraphLaunch(s->exec, be.stream));
+        be.record_done();
+        s->seen++;
+        return;
+      }
+      s->seen++;
     }
     plan.enqueue(bases, base_off, sdev, n, from_mont);
   }

@@ -789,6 +789,10 @@ class MsmPlan {
     be_.record_done();
   }
 
+  // Host-side state of enqueue() for a call whose device work is replayed from a captured graph (same n as the captured
+  // call): what finish() and its Horner fold read.
+  void prepare_replay(size_t n) { pending_empty_ = (n == 0); if (n) plan_geometry(n); }
+
   // Wait for the queued MSM and fold its partial sums on the host (Horner) into one affine point.
   void finish(uint32_t* out_host) {
     if (subs_) {      // subs_ affine points: batch-normalise the folded XYZZ results (one inversion in all)

@@ -421,3 +421,29 @@ def test_msm_batch_fast_path_over_window_table(ctx, curve, k):
     mixed = srs.msm_batch([t.data_ptr() for t in dev], lens, base_offsets=[off] * k)
     assert (mixed[k - 1] == O.msm_pippenger(curve, np.ascontiguousarray(b[off:off + lens[-1]]), host[-1][:lens[-1]], 8, 1)).all()
     srs.free()
+
+
+def test_msm_repeated_call_through_captured_graph(monkeypatch):
+    """PC_HIP_GRAPHS=1: the second identical call (same resident bases, same device scalar buffer) is captured into a
+    hipGraph, later ones replay it; a different buffer in between takes another slot.  Every result equals the oracle's."""
+    import torch
+    import poly_commit_amd as pc
+    monkeypatch.setenv("PC_HIP_GRAPHS", "1")
+    ctx = pc.Context(0)
+    curve, n = "bls12_381", 5000
+    bases = O.gen_bases(curve, n)
+    sc = [O.gen_scalars(curve, 0x6A0 + k, n) for k in range(2)]
+    want = [O.msm_pippenger(curve, bases, s, 8, 1) for s in sc]
+    dev = [torch.from_numpy(s.view(np.int64).copy()).cuda() for s in sc]
+    srs = ctx.upload_srs(curve, bases)
+    for rnd in range(4):                      # 3 pipelines: every (pipeline, buffer) pair is seen, captured and replayed
+        for k in (0, 1, 0):
+            got, _ = srs.msm(dev[k].data_ptr(), n=n)
+            assert (got == want[k]).all(), (rnd, k)
+    srs.precompute(min_pairs=1)               # new pipelines (window table): capture again
+    for rnd in range(4):
+        for k in (1, 0):
+            got, _ = srs.msm(dev[k].data_ptr(), n=n)
+            assert (got == want[k]).all(), (rnd, k)
+    srs.free()
+    ctx.close()
