@@ -721,3 +721,140 @@ def mle_evaluate(field, evals, point):
     for x in point:
         cur = [(cur[2 * i] + x * (cur[2 * i + 1] - cur[2 * i])) % p for i in range(len(cur) // 2)]
     return cur[0]
+
+
+# ---------------------------------------------------------------------------------------
+# InnerProductArgPC with hiding and degree bounds (the general form of commit / open / succinct_check above)
+# ---------------------------------------------------------------------------------------
+def ipa_commit_general(curve, comm_key, s, coeffs, degree_bound=None, rand=0, shifted_rand=0):
+    """InnerProductArgPC::commit for one polynomial (ipa_pc/mod.rs:403-473): comm = MSM(comm_key[..deg+1], coeffs) + s*rand;
+    with a degree bound also shifted_comm = MSM(comm_key[supported_degree - bound ..], coeffs) + s*shifted_rand.
+    Returns (comm, shifted_comm or None)."""
+    d = len(comm_key) - 1
+    comm = ec_add(curve, msm(curve, comm_key[:len(coeffs)], coeffs), ec_mul(curve, rand, s))
+    shifted = None
+    if degree_bound is not None:
+        shifted = ec_add(curve, msm(curve, comm_key[d - degree_bound:d - degree_bound + len(coeffs)], coeffs), ec_mul(curve, shifted_rand, s))
+    return comm, shifted
+
+
+def _ipa_challenge_stream(challenges):
+    it = iter(challenges)
+    return lambda: next(it)
+
+
+def ipa_open_general(curve, comm_key, h, s, polys, point, challenges, hiding_poly=None, hiding_rand=0):
+    """InnerProductArgPC::open (ipa_pc/mod.rs:475-723) with hiding and degree bounds.
+    polys: list of dicts {coeffs, comm, shifted_comm, degree_bound (None or int), hiding (bool), rand, shifted_rand};
+    challenges: the values the caller's sponge squeezes, in order (:502, then :525 and :556 per polynomial);
+    hiding_poly / hiding_rand: what the reference draws from the rng at :577 / :579 when any polynomial hides
+    (d + 1 coefficients, before the subtraction of its value at the point).
+    Returns (l_vec, r_vec, final_comm_key, c, hiding_comm or None, rand or None, round_challenges)."""
+    fr = CURVES[curve]["fr"]
+    p = FIELDS[fr]["p"]
+    n = len(comm_key)
+    d = n - 1
+    squeeze = _ipa_challenge_stream(challenges)
+    combined = [0] * n
+    combined_rand, combined_comm, has_hiding = 0, None, False
+    cur = squeeze()
+    for q in polys:
+        co = q["coeffs"]
+        if len(co) - 1 > d:
+            raise ValueError("TooManyCoefficients")
+        db = q.get("degree_bound")
+        if db is not None and (db < len(co) - 1 or db > d):
+            raise ValueError("IncorrectDegreeBound")
+        for i, v in enumerate(co):
+            combined[i] = (combined[i] + cur * v) % p
+        combined_comm = ec_add(curve, combined_comm, ec_mul(curve, cur, q["comm"]))
+        if q.get("hiding"):
+            has_hiding = True
+            combined_rand = (combined_rand + cur * q["rand"]) % p
+        cur = squeeze()
+        if db is not None:
+            shift = d - db                                             # shift_polynomial, :230-239
+            for i, v in enumerate(co):
+                combined[shift + i] = (combined[shift + i] + cur * v) % p
+            combined_comm = ec_add(curve, combined_comm, ec_mul(curve, cur, q["shifted_comm"]))
+            if q.get("hiding"):
+                combined_rand = (combined_rand + cur * q["shifted_rand"]) % p
+        cur = squeeze()
+    combined_v = poly_eval(fr, combined, point)
+    hiding_comm = None
+    if has_hiding:
+        hp = list(hiding_poly) + [0] * (n - len(hiding_poly))
+        hp[0] = (hp[0] - poly_eval(fr, hp, point)) % p                 # :578
+        hiding_comm = ec_add(curve, msm(curve, comm_key, hp), ec_mul(curve, hiding_rand, s))       # :580-585
+        hc = random_oracle_challenge(fr, ser_point(curve, combined_comm) + ser_field(fr, point) + ser_field(fr, combined_v)
+                                     + ser_point(curve, hiding_comm))  # :592-603
+        combined = [(a + hc * b) % p for a, b in zip(combined, hp)]
+        combined_rand = (combined_rand + hc * hiding_rand) % p
+        combined_comm = ec_add(curve, combined_comm, ec_add(curve, ec_mul(curve, hc, hiding_comm),
+                                                            ec_neg(curve, ec_mul(curve, combined_rand, s))))      # :606-607
+    rc = random_oracle_challenge(fr, ser_point(curve, combined_comm) + ser_field(fr, point) + ser_field(fr, combined_v))
+    h_prime = ec_mul(curve, rc, h)
+    zs = [pow(point, i, p) for i in range(n)]
+    key, cs = list(comm_key), list(combined)
+    l_vec, r_vec, chal = [], [], []
+    m = n
+    while m > 1:
+        hh = m // 2
+        ip_l = sum(a * b for a, b in zip(cs[hh:m], zs[:hh])) % p
+        ip_r = sum(a * b for a, b in zip(cs[:hh], zs[hh:m])) % p
+        l = ec_add(curve, msm(curve, key[:hh], cs[hh:m]), ec_mul(curve, ip_l, h_prime))
+        r = ec_add(curve, msm(curve, key[hh:m], cs[:hh]), ec_mul(curve, ip_r, h_prime))
+        l_vec.append(l)
+        r_vec.append(r)
+        rc = random_oracle_challenge(fr, ser_field(fr, rc) + ser_point(curve, l) + ser_point(curve, r))
+        chal.append(rc)
+        ui = pow(rc, -1, p)
+        for i in range(hh):
+            cs[i] = (cs[i] + ui * cs[hh + i]) % p
+            zs[i] = (zs[i] + rc * zs[hh + i]) % p
+            key[i] = ec_add(curve, key[i], ec_mul(curve, rc, key[hh + i]))
+        m = hh
+    return l_vec, r_vec, key[0], cs[0], hiding_comm, (combined_rand if has_hiding else None), chal
+
+
+def ipa_check_general(curve, comm_key, h, s, comms, point, values, proof, challenges):
+    """InnerProductArgPC::check with hiding and degree bounds (ipa_pc/mod.rs:725-773 over succinct_check :91-203).
+    comms: list of dicts {comm, shifted_comm, degree_bound}; proof = (l_vec, r_vec, final_comm_key, c, hiding_comm, rand)."""
+    fr = CURVES[curve]["fr"]
+    p = FIELDS[fr]["p"]
+    d = len(comm_key) - 1
+    log_d = ark_log2(d + 1)
+    l_vec, r_vec, final_key, c, hiding_comm, rand = proof
+    if len(l_vec) != len(r_vec) or len(l_vec) != log_d:
+        raise ValueError("IncorrectInputLength")
+    squeeze = _ipa_challenge_stream(challenges)
+    combined_comm, combined_v = None, 0
+    cur = squeeze()
+    for cm, value in zip(comms, values):
+        combined_v = (combined_v + cur * value) % p
+        combined_comm = ec_add(curve, combined_comm, ec_mul(curve, cur, cm["comm"]))
+        cur = squeeze()
+        db = cm.get("degree_bound")
+        assert (db is not None) == (cm.get("shifted_comm") is not None)
+        if db is not None:
+            shift = pow(point, d - db, p)                                                      # :128
+            combined_v = (combined_v + cur * value % p * shift) % p
+            combined_comm = ec_add(curve, combined_comm, ec_mul(curve, cur, cm["shifted_comm"]))
+        cur = squeeze()
+    assert (hiding_comm is not None) == (rand is not None)
+    if hiding_comm is not None:                                                                # :138-151
+        hc = random_oracle_challenge(fr, ser_point(curve, combined_comm) + ser_field(fr, point) + ser_field(fr, combined_v)
+                                     + ser_point(curve, hiding_comm))
+        combined_comm = ec_add(curve, combined_comm, ec_add(curve, ec_mul(curve, hc, hiding_comm), ec_neg(curve, ec_mul(curve, rand, s))))
+    rc = random_oracle_challenge(fr, ser_point(curve, combined_comm) + ser_field(fr, point) + ser_field(fr, combined_v))
+    h_prime = ec_mul(curve, rc, h)
+    round_comm = ec_add(curve, combined_comm, ec_mul(curve, combined_v, h_prime))
+    chal = []
+    for l, r in zip(l_vec, r_vec):
+        rc = random_oracle_challenge(fr, ser_field(fr, rc) + ser_point(curve, l) + ser_point(curve, r))
+        chal.append(rc)
+        round_comm = ec_add(curve, round_comm, ec_add(curve, ec_mul(curve, pow(rc, -1, p), l), ec_mul(curve, rc, r)))
+    v_prime = succinct_check_eval(fr, chal, point) * c % p
+    if round_comm != ec_add(curve, ec_mul(curve, c, final_key), ec_mul(curve, v_prime, h_prime)):
+        return False
+    return msm(curve, comm_key, succinct_check_coeffs(fr, chal)) == final_key

@@ -7,6 +7,8 @@
 //                              challenges of :74-87 / :615-625 / :681-688, h_prime, the loop, Proof)
 //   succinct_check / check     ipa_pc/mod.rs:91-203, 725-773 (no hiding, no bounds): the verifier, whose one large
 //                              computation -- cm_commit(comm_key, check_poly.compute_coeffs()) -- runs on the device
+//   commit_general / open_general / check_general: the same with hiding and degree bounds (:403-473, :475-723, :116-151);
+//                              the rng's draws (row randomness, hiding polynomial) are arguments
 //
 // The coefficient vector, the powers of the evaluation point and the commitment key stay in HBM for the
 // whole proof (pc_hip_malloc / the resident SRS); per round two points come down and one challenge goes up.
@@ -175,6 +177,132 @@ struct InnerProductArgPC {
     pc_hip_free(ctx, cdev); pc_hip_free(ctx, zdev); pc_hip_free(ctx, sdev); pc_hip_free(ctx, aldev); pc_hip_free(ctx, ardev);
     pc_hip_srs_free(srs);
     return rc == PC_OK ? Error() : backend_error(ctx, rc);
+  }
+
+  // ---- the general form: hiding and degree bounds -------------------------------------------------------------------
+  // One labeled polynomial with its commitment and commitment state (LabeledPolynomial + LabeledCommitment<Commitment> +
+  // Randomness, ipa_pc/data_structures.rs:94-160).  degree_bound < 0: none.  hiding == false: Randomness::empty().
+  struct Labeled {
+    const DensePolynomial<E>* polynomial = nullptr;
+    long degree_bound = -1;
+    bool hiding = false;
+    Fr rand = Fr::zero(), shifted_rand = Fr::zero();
+    G1Affine<E> comm = G1Affine<E>::zero(), shifted_comm = G1Affine<E>::zero();
+  };
+  struct GeneralProof {                              // Proof { l_vec, r_vec, final_comm_key, c, hiding_comm, rand }
+    IpaProof<E> core;
+    bool has_hiding = false;
+    G1Affine<E> hiding_comm = G1Affine<E>::zero();
+    Fr rand = Fr::zero();
+  };
+  static Error incorrect_degree_bound(size_t deg, long bound) { Error e; e.kind = Error::UnsupportedDegreeBound; e.a = deg; e.b = (size_t)bound; return e; }
+
+  // commit for one polynomial (ipa_pc/mod.rs:403-473): fills comm / shifted_comm of `lp`
+  static Error commit_general(pc_ctx* ctx, const IpaCommitterKey<E>& ck, Labeled& lp) {
+    const DensePolynomial<E>& p = *lp.polynomial;
+    const size_t d = ck.supported_degree();
+    if (Error e = KZG10<E>::check_degree_is_too_large(p.degree(), d + 1)) return e;
+    if (lp.degree_bound >= 0 && ((size_t)lp.degree_bound < p.degree() || (size_t)lp.degree_bound > d)) return incorrect_degree_bound(p.degree(), lp.degree_bound);
+    const size_t m = p.degree() + 1;
+    std::vector<Fr> co(p.coeffs.begin(), p.coeffs.begin() + std::min(m, p.coeffs.size()));
+    std::vector<G1Affine<E>> key(ck.comm_key.begin(), ck.comm_key.begin() + co.size());
+    if (Error e = cm_commit(ctx, key, co, &ck.s, lp.hiding ? &lp.rand : nullptr, lp.comm)) return e;
+    if (lp.degree_bound >= 0) {
+      std::vector<G1Affine<E>> skey(ck.comm_key.begin() + (d - (size_t)lp.degree_bound), ck.comm_key.begin() + (d - (size_t)lp.degree_bound) + co.size());
+      if (Error e = cm_commit(ctx, skey, co, &ck.s, lp.hiding ? &lp.shifted_rand : nullptr, lp.shifted_comm)) return e;
+    }
+    return Error();
+  }
+
+  // open (ipa_pc/mod.rs:475-723).  challenges: the caller's sponge output in squeeze order (:502, then :525 and :556 per
+  // polynomial); hiding_polynomial (d + 1 coefficients) / hiding_rand: what the reference draws at :577 / :579.
+  static Error open_general(pc_ctx* ctx, const IpaCommitterKey<E>& ck, const std::vector<Labeled>& polys, const Fr& point,
+                            const std::vector<Fr>& challenges, const std::vector<Fr>* hiding_polynomial, const Fr* hiding_rand,
+                            GeneralProof& proof) {
+    const size_t d1 = ck.comm_key.size(), d = d1 - 1;
+    if (challenges.size() < 2 * polys.size() + 1) { Error e; e.kind = Error::Backend; e.msg = "ipa open: 2 k + 1 sponge challenges expected"; return e; }
+    std::vector<std::vector<Fr>> shifted;                 shifted.reserve(polys.size());
+    std::vector<const void*> ptrs; std::vector<size_t> lens; std::vector<Fr> xis;
+    G1Affine<E> combined_commitment = G1Affine<E>::zero();
+    Fr combined_rand = Fr::zero();
+    bool has_hiding = false;
+    size_t ci = 0;
+    Fr cur = challenges[ci++];
+    for (const Labeled& lp : polys) {
+      const DensePolynomial<E>& p = *lp.polynomial;
+      if (Error e = KZG10<E>::check_degree_is_too_large(p.degree(), d1)) return e;
+      if (lp.degree_bound >= 0 && ((size_t)lp.degree_bound < p.degree() || (size_t)lp.degree_bound > d)) return incorrect_degree_bound(p.degree(), lp.degree_bound);
+      ptrs.push_back(p.coeffs.data()); lens.push_back(std::min(p.coeffs.size(), d1)); xis.push_back(cur);
+      combined_commitment = combined_commitment.add(lp.comm.mul(cur));
+      if (lp.hiding) { has_hiding = true; combined_rand = combined_rand + cur * lp.rand; }
+      cur = challenges[ci++];
+      if (lp.degree_bound >= 0) {
+        shifted.emplace_back(d - (size_t)lp.degree_bound, Fr::zero());                               // shift_polynomial, :230-239
+        shifted.back().insert(shifted.back().end(), p.coeffs.begin(), p.coeffs.end());
+        ptrs.push_back(shifted.back().data()); lens.push_back(std::min(shifted.back().size(), d1)); xis.push_back(cur);
+        combined_commitment = combined_commitment.add(lp.shifted_comm.mul(cur));
+        if (lp.hiding) combined_rand = combined_rand + cur * lp.shifted_rand;
+      }
+      cur = challenges[ci++];
+    }
+    std::vector<Fr> combined(d1, Fr::zero());
+    if (!ptrs.empty()) {
+      int rc = pc_hip_fr_lincomb(ctx, E::ID, ptrs.data(), PC_MEM_HOST, lens.data(), ptrs.size(), xis.data(), combined.data(), PC_MEM_HOST, d1);
+      if (rc != PC_OK) return backend_error(ctx, rc);
+    }
+    DensePolynomial<E> cp; cp.coeffs = combined;
+    const Fr combined_v = cp.evaluate(point);
+    proof = GeneralProof();
+    if (has_hiding) {
+      if (!hiding_polynomial || !hiding_rand) { Error e; e.kind = Error::MissingRng; return e; }
+      std::vector<Fr> hp(*hiding_polynomial); hp.resize(d1, Fr::zero());
+      DensePolynomial<E> hpp; hpp.coeffs = hp;
+      hp[0] = hp[0] - hpp.evaluate(point);                                                              // :578
+      G1Affine<E> hiding_comm;
+      if (Error e = cm_commit(ctx, ck.comm_key, hp, &ck.s, hiding_rand, hiding_comm)) return e;        // :580-585
+      Transcript<E> t; t.append(combined_commitment); t.append(point); t.append(combined_v); t.append(hiding_comm);
+      const Fr hc = t.challenge();                                                                       // :592-603
+      for (size_t i = 0; i < d1; i++) combined[i] = combined[i] + hc * hp[i];
+      combined_rand = combined_rand + hc * *hiding_rand;
+      combined_commitment = combined_commitment.add(hiding_comm.mul(hc)).add(ck.s.mul(combined_rand).neg());   // :606-607
+      proof.has_hiding = true; proof.hiding_comm = hiding_comm; proof.rand = combined_rand;
+    }
+    Transcript<E> t; t.append(combined_commitment); t.append(point); t.append(combined_v);
+    const Fr round_challenge = t.challenge();
+    const G1Affine<E> h_prime = ck.h.mul(round_challenge);
+    IpaRandomOracle<E> ro(round_challenge);
+    return open_rounds(ctx, ck.comm_key, combined, point, h_prime, ro, proof.core);
+  }
+
+  // check with hiding and degree bounds: the combination of succinct_check (:116-151), then the plain check of the one
+  // combined commitment
+  static Error check_general(pc_ctx* ctx, const IpaCommitterKey<E>& vk, const std::vector<Labeled>& comms, const Fr& point,
+                             const std::vector<Fr>& values, const GeneralProof& proof, const std::vector<Fr>& challenges, bool& ok) {
+    ok = false;
+    const size_t d = vk.supported_degree();
+    if (challenges.size() < 2 * comms.size() + 1 || values.size() != comms.size()) { Error e; e.kind = Error::Backend; e.msg = "ipa check: 2 k + 1 sponge challenges and k values expected"; return e; }
+    G1Affine<E> combined_commitment = G1Affine<E>::zero();
+    Fr combined_v = Fr::zero();
+    size_t ci = 0;
+    Fr cur = challenges[ci++];
+    for (size_t j = 0; j < comms.size(); j++) {
+      combined_v = combined_v + cur * values[j];
+      combined_commitment = combined_commitment.add(comms[j].comm.mul(cur));
+      cur = challenges[ci++];
+      if (comms[j].degree_bound >= 0) {
+        Fr shift = Fr::one(), b = point;                                                           // point^(d - bound), :128
+        for (size_t e = d - (size_t)comms[j].degree_bound; e; e >>= 1) { if (e & 1) shift = shift * b; b = b * b; }
+        combined_v = combined_v + cur * values[j] * shift;
+        combined_commitment = combined_commitment.add(comms[j].shifted_comm.mul(cur));
+      }
+      cur = challenges[ci++];
+    }
+    if (proof.has_hiding) {                                                                        // :138-151
+      Transcript<E> t; t.append(combined_commitment); t.append(point); t.append(combined_v); t.append(proof.hiding_comm);
+      const Fr hc = t.challenge();
+      combined_commitment = combined_commitment.add(proof.hiding_comm.mul(hc)).add(vk.s.mul(proof.rand).neg());
+    }
+    return check(ctx, vk, {combined_commitment}, point, {combined_v}, proof.core, {Fr::one()}, ok);
   }
 
   // SuccinctCheckPolynomial::evaluate (ipa_pc/data_structures.rs:223-236): prod_i (1 + u_i * point^(2^(log_d - i)))

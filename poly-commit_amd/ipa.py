@@ -231,3 +231,145 @@ def ipa_check(ctx, curve, comm_key, h_xy, comms, point_mont, values_mont, proof,
         if own:
             srs.free()
     return bool((key == np.asarray(final_key)).all())
+
+
+# ---- the general form: hiding and degree bounds (ipa_pc/mod.rs:403-473, 475-723, 91-203) ----------------------------
+def _neg_point(curve, xy):
+    q = FQ_MODULUS[curve]
+    xy = np.ascontiguousarray(xy, dtype=np.uint64)
+    if not xy.any():
+        return xy.copy()
+    nq = len(xy) // 2
+    out = xy.copy()
+    y = _limbs_to_int(xy[nq:])
+    out[nq:] = np.frombuffer(((q - y) % q).to_bytes(8 * nq, "little"), dtype="<u8")      # Montgomery form of -y is q - (y R)
+    return out
+
+
+def ipa_commit_general(ctx, curve, comm_key, s_xy, coeffs_dev, n_coeffs, degree_bound=None, rand=None, shifted_rand=None, srs=None):
+    """InnerProductArgPC::commit for one polynomial: (comm, shifted_comm or None).  coeffs_dev: device pointer of
+    n_coeffs Montgomery coefficients; rand / shifted_rand: Montgomery limbs or None (= Randomness::empty())."""
+    own = srs is None
+    if own:
+        srs = ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
+    try:
+        d = srs.n - 1
+        comm = srs.msm(coeffs_dev, n=n_coeffs, base_offset=0, montgomery=True)[0]
+        if rand is not None:
+            comm = _ffi.points_sum(curve, np.stack([comm, _ffi.point_mul(curve, s_xy, rand)]))
+        shifted = None
+        if degree_bound is not None:
+            shifted = srs.msm(coeffs_dev, n=n_coeffs, base_offset=d - degree_bound, montgomery=True)[0]
+            if shifted_rand is not None:
+                shifted = _ffi.points_sum(curve, np.stack([shifted, _ffi.point_mul(curve, s_xy, shifted_rand)]))
+    finally:
+        if own:
+            srs.free()
+    return comm, shifted
+
+
+def ipa_open_general(ctx, curve, comm_key, h_xy, s_xy, polys, point_mont, challenges, hiding_poly_dev=None, hiding_rand=None,
+                     timings=None):
+    """InnerProductArgPC::open with hiding and degree bounds.  polys: dicts {dev (torch cuda int64 (len, 4)), comm,
+    shifted_comm, degree_bound, hiding, rand, shifted_rand}; challenges: the caller's sponge output in squeeze order
+    (:502, then :525 and :556 per polynomial), Montgomery limbs; hiding_poly_dev (torch (d+1, 4), CONSUMED) / hiding_rand:
+    what the reference draws at :577 / :579.  Returns ((l_vec, r_vec, final_comm_key, c, hiding_comm, rand), first round challenge)."""
+    import torch
+    n = comm_key.shape[0]
+    d = n - 1
+    p = FR_MODULUS[curve]
+    rinv = pow(_R, -1, p)
+    to_int = lambda a: _limbs_to_int(a) * rinv % p           # noqa: E731
+    to_mont = lambda v: _int_to_limbs(v % p * _R % p)        # noqa: E731
+    ch = iter([np.ascontiguousarray(c, dtype=np.uint64) for c in challenges])
+    vecs, lens, xis, terms = [], [], [], []
+    combined_rand, has_hiding = 0, False
+    keep = []
+    cur = next(ch)
+    for q in polys:
+        m = q["dev"].shape[0]
+        if m - 1 > d:
+            raise ValueError("TooManyCoefficients")
+        db = q.get("degree_bound")
+        if db is not None and (db < m - 1 or db > d):
+            raise ValueError("IncorrectDegreeBound")
+        vecs.append(q["dev"].data_ptr()); lens.append(m); xis.append(cur)
+        terms.append(_ffi.point_mul(curve, q["comm"], cur))
+        if q.get("hiding"):
+            has_hiding = True
+            combined_rand = (combined_rand + to_int(cur) * to_int(q["rand"])) % p
+        cur = next(ch)
+        if db is not None:
+            sh = torch.cat([torch.zeros((d - db, 4), dtype=torch.int64, device=q["dev"].device), q["dev"]])     # shift_polynomial, :230-239
+            keep.append(sh)
+            vecs.append(sh.data_ptr()); lens.append(sh.shape[0]); xis.append(cur)
+            terms.append(_ffi.point_mul(curve, q["shifted_comm"], cur))
+            if q.get("hiding"):
+                combined_rand = (combined_rand + to_int(cur) * to_int(q["shifted_rand"])) % p
+        cur = next(ch)
+    comb = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.fr_lincomb(curve, vecs, np.stack(xis), n_out=n, out=comb.data_ptr(), lens=lens)
+    ccomm = _ffi.points_sum(curve, np.stack(terms))
+    v = ctx.poly_eval(curve, comb.data_ptr(), point_mont, n=n)
+    hiding_comm = None
+    if has_hiding:
+        hp = hiding_poly_dev
+        assert hp is not None and hp.shape[0] == n and hiding_rand is not None
+        hv = ctx.poly_eval(curve, hp.data_ptr(), point_mont, n=n)                               # :578
+        h0 = hp[0].cpu().numpy().view(np.uint64)
+        hp[0] = torch.from_numpy(to_mont(to_int(h0) - to_int(hv)).view(np.int64)).to(hp.device)
+        srs = ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
+        hiding_comm = _ffi.points_sum(curve, np.stack([srs.msm(hp.data_ptr(), n=n, montgomery=True)[0],
+                                                       _ffi.point_mul(curve, s_xy, hiding_rand)]))          # :580-585
+        srs.free()
+        hc = random_oracle_challenge(curve, ser_point(curve, ccomm) + ser_fr(curve, point_mont) + ser_fr(curve, v) + ser_point(curve, hiding_comm))
+        comb2 = torch.empty_like(comb)
+        ctx.fr_lincomb(curve, [comb.data_ptr(), hp.data_ptr()], np.stack([to_mont(1), hc]), n_out=n, out=comb2.data_ptr(), lens=[n, n])
+        comb = comb2
+        combined_rand = (combined_rand + to_int(hc) * to_int(hiding_rand)) % p
+        ccomm = _ffi.points_sum(curve, np.stack([ccomm, _ffi.point_mul(curve, hiding_comm, hc),
+                                                 _neg_point(curve, _ffi.point_mul(curve, s_xy, to_mont(combined_rand)))]))   # :606-607
+    rc = random_oracle_challenge(curve, ser_point(curve, ccomm) + ser_fr(curve, point_mont) + ser_fr(curve, v))
+    h_prime = _ffi.point_mul(curve, np.ascontiguousarray(h_xy), rc)
+    state = {"rc": rc}
+
+    def next_challenge(l, r):
+        state["rc"] = random_oracle_challenge(curve, ser_fr(curve, state["rc"]) + ser_point(curve, l) + ser_point(curve, r))
+        return state["rc"]
+    l, r, fk, c = ipa_open_rounds(ctx, curve, comm_key, comb, n, point_mont, h_prime, next_challenge, timings)
+    return (l, r, fk, c, hiding_comm, (to_mont(combined_rand) if has_hiding else None)), rc
+
+
+def ipa_check_general(ctx, curve, comm_key, h_xy, s_xy, comms, point_mont, values_mont, proof, challenges):
+    """InnerProductArgPC::check with hiding and degree bounds: comms = dicts {comm, shifted_comm, degree_bound};
+    proof = (l_vec, r_vec, final_comm_key, c, hiding_comm, rand).  The combination of :116-151 happens here, the rest is
+    ipa_check's (succinct equation on the host, final-key MSM on the device)."""
+    n = comm_key.shape[0]
+    d = n - 1
+    p = FR_MODULUS[curve]
+    rinv = pow(_R, -1, p)
+    to_int = lambda a: _limbs_to_int(a) * rinv % p           # noqa: E731
+    to_mont = lambda v: _int_to_limbs(v % p * _R % p)        # noqa: E731
+    l_vec, r_vec, final_key, c, hiding_comm, rand = proof
+    ch = iter([np.ascontiguousarray(x, dtype=np.uint64) for x in challenges])
+    z = to_int(point_mont)
+    combined_v, terms = 0, []
+    cur = next(ch)
+    for cm, value in zip(comms, values_mont):
+        combined_v = (combined_v + to_int(cur) * to_int(value)) % p
+        terms.append(_ffi.point_mul(curve, cm["comm"], cur))
+        cur = next(ch)
+        db = cm.get("degree_bound")
+        assert (db is not None) == (cm.get("shifted_comm") is not None)
+        if db is not None:
+            combined_v = (combined_v + to_int(cur) * to_int(value) % p * pow(z, d - db, p)) % p
+            terms.append(_ffi.point_mul(curve, cm["shifted_comm"], cur))
+        cur = next(ch)
+    ccomm = _ffi.points_sum(curve, np.stack(terms))
+    assert (hiding_comm is not None) == (rand is not None)
+    if hiding_comm is not None:
+        hc = random_oracle_challenge(curve, ser_point(curve, ccomm) + ser_fr(curve, point_mont) + ser_fr(curve, to_mont(combined_v))
+                                     + ser_point(curve, hiding_comm))
+        ccomm = _ffi.points_sum(curve, np.stack([ccomm, _ffi.point_mul(curve, hiding_comm, hc), _neg_point(curve, _ffi.point_mul(curve, s_xy, rand))]))
+    # from here on it is the plain check of ONE commitment `ccomm` with value combined_v and opening challenge 1
+    return ipa_check(ctx, curve, comm_key, h_xy, [ccomm], point_mont, [to_mont(combined_v)], (l_vec, r_vec, final_key, c), [to_mont(1)])

@@ -1,0 +1,80 @@
+// Test driver: InnerProductArgPC commit / open / check WITH hiding and degree bounds through the C++ host mirror
+// (poly-commit_amd/host/ipa_pc.hpp: commit_general, open_general, check_general).
+//   file in : u32 curve, u32 n, u32 k | comm_key n*xy | h xy | s xy |
+//             k x (u32 len, len*Fr, i32 degree_bound, u32 hiding, rand Fr, shifted_rand Fr) | point Fr | (2k+1) challenges Fr |
+//             hiding polynomial n*Fr | hiding_rand Fr
+//   file out: k x (comm xy, shifted_comm xy) | log2(n) x l xy | log2(n) x r xy | final_comm_key xy | c Fr | hiding_comm xy | rand Fr
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../poly-commit_amd/host/ipa_pc.hpp"
+using namespace pc_host;
+
+template <class E>
+static int run(pc_ctx* ctx, FILE* in, uint32_t n, uint32_t k, const char* out_path) {
+  typedef FrT<E> Fr;
+  typedef InnerProductArgPC<E> PC;
+  auto rd = [&](void* p, size_t b) { if (fread(p, 1, b, in) != b) { printf("short input\n"); exit(2); } };
+  auto rd_pt = [&]() { uint64_t xy[2 * E::NQ]; rd(xy, sizeof xy); bool inf = true; for (int i = 0; i < 2 * E::NQ; i++) inf &= xy[i] == 0; return G1Affine<E>::from_xy(xy, inf); };
+  auto rd_fr = [&](size_t c) { std::vector<Fr> v(c); if (c) rd(v.data(), c * 32); return v; };
+  IpaCommitterKey<E> ck;
+  for (uint32_t i = 0; i < n; i++) ck.comm_key.push_back(rd_pt());
+  ck.h = rd_pt(); ck.s = rd_pt();
+  std::vector<DensePolynomial<E>> polys(k);
+  std::vector<typename PC::Labeled> lps(k);
+  for (uint32_t j = 0; j < k; j++) {
+    uint32_t len; rd(&len, 4); polys[j].coeffs = rd_fr(len);
+    int32_t db; uint32_t hid; rd(&db, 4); rd(&hid, 4);
+    lps[j].polynomial = &polys[j]; lps[j].degree_bound = db; lps[j].hiding = hid != 0;
+    lps[j].rand = rd_fr(1)[0]; lps[j].shifted_rand = rd_fr(1)[0];
+  }
+  Fr point = rd_fr(1)[0];
+  std::vector<Fr> ch = rd_fr(2 * k + 1), hp = rd_fr(n);
+  Fr hr = rd_fr(1)[0];
+  for (auto& lp : lps) if (Error e = PC::commit_general(ctx, ck, lp)) { printf("commit: kind %d %s\n", (int)e.kind, e.msg.c_str()); return 1; }
+  typename PC::GeneralProof proof;
+  if (Error e = PC::open_general(ctx, ck, lps, point, ch, &hp, &hr, proof)) { printf("open: kind %d %s\n", (int)e.kind, e.msg.c_str()); return 1; }
+  std::vector<Fr> values; for (auto& p : polys) values.push_back(p.evaluate(point));
+  bool ok = false;
+  if (Error e = PC::check_general(ctx, ck, lps, point, values, proof, ch, ok)) { printf("check: kind %d %s\n", (int)e.kind, e.msg.c_str()); return 1; }
+  if (!ok) { printf("check rejected an honest proof\n"); return 1; }
+  { typename PC::GeneralProof bad = proof; bad.rand = bad.rand + Fr::one();
+    if (PC::check_general(ctx, ck, lps, point, values, bad, ch, ok) || (ok && proof.has_hiding)) { printf("check accepted an altered rand\n"); return 1; } }
+  { std::vector<Fr> bv = values; bv.back() = bv.back() + Fr::one();
+    if (PC::check_general(ctx, ck, lps, point, bv, proof, ch, ok) || ok) { printf("check accepted an altered value\n"); return 1; } }
+  { std::vector<typename PC::Labeled> bad = lps;                       // a bound below the degree is refused before any device work
+    for (auto& lp : bad) if (lp.degree_bound >= 0) { lp.degree_bound = (long)lp.polynomial->degree() - 1; break; }
+    typename PC::GeneralProof pr2;
+    bool any = false; for (auto& lp : lps) any |= lp.degree_bound >= 0 && lp.polynomial->degree() > 0;
+    if (any && PC::open_general(ctx, ck, bad, point, ch, &hp, &hr, pr2).kind != Error::UnsupportedDegreeBound) { printf("bad degree bound not refused\n"); return 1; } }
+  FILE* out = fopen(out_path, "wb");
+  auto wr_pt = [&](const G1Affine<E>& p) { uint64_t xy[2 * E::NQ]; p.to_xy(xy); fwrite(xy, 1, sizeof xy, out); };
+  for (auto& lp : lps) { wr_pt(lp.comm); wr_pt(lp.degree_bound >= 0 ? lp.shifted_comm : G1Affine<E>::zero()); }
+  for (auto& p : proof.core.l_vec) wr_pt(p);
+  for (auto& p : proof.core.r_vec) wr_pt(p);
+  wr_pt(proof.core.final_comm_key);
+  fwrite(proof.core.c.l, 1, 32, out);
+  wr_pt(proof.hiding_comm);
+  fwrite(proof.rand.l, 1, 32, out);
+  fclose(out);
+  printf("ipa general OK (%zu rounds, hiding %d)\n", proof.core.l_vec.size(), (int)proof.has_hiding);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { printf("usage: ipa_general_driver in out\n"); return 2; }
+  FILE* in = fopen(argv[1], "rb");
+  if (!in) { printf("cannot open %s\n", argv[1]); return 2; }
+  uint32_t hdr[3]; if (fread(hdr, 4, 3, in) != 3) return 2;
+  pc_ctx* ctx = nullptr;
+  int rc = pc_hip_init(0, &ctx);
+  if (rc != PC_OK) { printf("pc_hip_init failed: %s\n", pc_hip_strerror(rc)); return rc == PC_ERR_NO_DEVICE ? 77 : 1; }
+  int r = 1;
+  switch (hdr[0]) {
+    case 0: r = run<Bls12_381>(ctx, in, hdr[1], hdr[2], argv[2]); break;
+    case 1: r = run<Bn254>(ctx, in, hdr[1], hdr[2], argv[2]); break;
+    case 2: r = run<Pallas>(ctx, in, hdr[1], hdr[2], argv[2]); break;
+  }
+  fclose(in);
+  pc_hip_shutdown(ctx);
+  return r;
+}

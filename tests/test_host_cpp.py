@@ -58,15 +58,16 @@ def test_host_blake2s_rfc7693_vector():
     assert r.returncode == 0 and "blake2s OK" in r.stdout
 
 
-def test_hyrax_host_mirror_compiles():
-    """CPU: host/hyrax.hpp (HyraxPC commit / open / check above the C ABI) compiles and links against the library; the
-    driver built here is the one the -m gpu test runs."""
+def test_hyrax_and_general_ipa_host_mirrors_compile():
+    """CPU: host/hyrax.hpp (HyraxPC commit / open / check) and the general IPA entry points of host/ipa_pc.hpp (hiding,
+    degree bounds) compile and link against the library; the drivers built here are the ones the -m gpu tests run."""
     libdir = os.path.join(ROOT, "poly-commit_amd")
     if not os.path.exists(os.path.join(libdir, "libpc_hip.so")):
         import importlib
         importlib.import_module("poly_commit_amd.build").build()
-    exe = os.path.join(ROOT, "tests", "cpp", "hyrax_driver")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, exe + ".cpp", "-L" + libdir, "-lpc_hip",
-                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 2 and "usage" in r.stdout
+    for name in ("hyrax_driver", "ipa_general_driver"):
+        exe = os.path.join(ROOT, "tests", "cpp", name)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, exe + ".cpp", "-L" + libdir, "-lpc_hip",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "usage" in r.stdout

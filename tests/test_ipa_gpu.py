@@ -110,6 +110,45 @@ def test_ipa_device_proof_passes_reference_check(ctx, curve, n):
     assert R.ipa_check(*args, (proof_i[0], proof_i[1], proof_i[2], (proof_i[3] + 1) % R.FIELDS[fr]["p"]), to_i(xi)) is False
 
 
+@pytest.mark.parametrize("curve,n", [("pallas", 64), ("bn254", 16), ("bls12_381", 8)])
+def test_ipa_hiding_and_degree_bounds_device(ctx, curve, n):
+    """InnerProductArgPC with hiding and degree bounds through poly-commit_amd/ipa.py (commitments with the hiding term and
+    the shifted key, the combination with shifted polynomials, the hiding polynomial of open, the verifier's combination):
+    bit for bit against the restatement in oracle/pyref.py, then through both verifiers."""
+    import torch
+    from poly_commit_amd import ipa
+    from test_oracle_cpu import _ipa_general_case
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    key, h, s, polys_i, ch_i, point_i, hp_i, hr_i = _ipa_general_case(curve, n)
+    want = R.ipa_open_general(curve, key, h, s, polys_i, point_i, ch_i, hp_i, hr_i)
+    m = lambda v: O.fr_mont_array(curve, v)                          # noqa: E731
+    pa = lambda P: O.points_to_array(curve, [P])[0]                  # noqa: E731
+    comm_key, h_xy, s_xy = O.points_to_array(curve, key), pa(h), pa(s)
+    polys = []
+    for q in polys_i:
+        dev = torch.from_numpy(m(q["coeffs"]).view(np.int64)).cuda()
+        rand = m([q["rand"]])[0] if q["hiding"] else None
+        srand = m([q["shifted_rand"]])[0] if (q["hiding"] and q["degree_bound"] is not None) else None
+        comm, sh = ipa.ipa_commit_general(ctx, curve, comm_key, s_xy, dev.data_ptr(), dev.shape[0], q["degree_bound"], rand, srand)
+        assert O.array_to_points(curve, comm.reshape(1, -1))[0] == q["comm"]
+        assert (sh is None) == (q["shifted_comm"] is None) and (sh is None or O.array_to_points(curve, sh.reshape(1, -1))[0] == q["shifted_comm"])
+        polys.append(dict(dev=dev, comm=comm, shifted_comm=sh, degree_bound=q["degree_bound"], hiding=q["hiding"], rand=rand, shifted_rand=srand))
+    hp = torch.from_numpy(m(hp_i).view(np.int64)).cuda()
+    (l, r, fk, c, hc, rand), _ = ipa.ipa_open_general(ctx, curve, comm_key, h_xy, s_xy, polys, m([point_i])[0], m(ch_i), hp, m([hr_i])[0])
+    pts = lambda a: O.array_to_points(curve, np.ascontiguousarray(a).reshape(-1, comm_key.shape[1]))   # noqa: E731
+    assert pts(l) == want[0] and pts(r) == want[1] and pts(fk)[0] == want[2] and pts(hc)[0] == want[4]
+    assert O.fr_from_mont_array(curve, np.stack([c, rand])) == [want[3], want[5]]
+    vals = [R.poly_eval(fr, q["coeffs"], point_i) for q in polys_i]
+    proof = (l, r, fk, c, hc, rand)
+    assert ipa.ipa_check_general(ctx, curve, comm_key, h_xy, s_xy, polys, m([point_i])[0], m(vals), proof, m(ch_i)) is True
+    bad_rand = m([(want[5] + 1) % p])[0]
+    assert ipa.ipa_check_general(ctx, curve, comm_key, h_xy, s_xy, polys, m([point_i])[0], m(vals), (l, r, fk, c, hc, bad_rand), m(ch_i)) is False
+    bad_vals = [vals[0], (vals[1] + 1) % p, vals[2]]
+    assert ipa.ipa_check_general(ctx, curve, comm_key, h_xy, s_xy, polys, m([point_i])[0], m(bad_vals), proof, m(ch_i)) is False
+    assert R.ipa_check_general(curve, key, h, s, polys_i, point_i, vals, (want[0], want[1], want[2], want[3], want[4], want[5]), ch_i) is True
+
+
 @pytest.mark.parametrize("curve,n", [("pallas", 1 << 8), ("bn254", 1 << 5), ("bls12_381", 1 << 5)])
 def test_ipa_open_whole_proof_cpp_host_mirror(curve, n, tmp_path):
     """The same through the C++ host mirror (host/ipa_pc.hpp: InnerProductArgPC::open, host/transcript.hpp):
@@ -138,3 +177,42 @@ def test_ipa_open_whole_proof_cpp_host_mirror(curve, n, tmp_path):
     wl, wr, wfk, wc, _ = _oracle_open(curve, comm_key, h, polys, comms, xi, point)
     assert (got[:lg * nq].reshape(lg, nq) == wl).all() and (got[lg * nq:2 * lg * nq].reshape(lg, nq) == wr).all()
     assert (got[2 * lg * nq:(2 * lg + 1) * nq] == wfk).all() and (got[(2 * lg + 1) * nq:] == wc).all()
+
+
+@pytest.mark.parametrize("curve,n", [("pallas", 32), ("bn254", 16), ("bls12_381", 8)])
+def test_ipa_hiding_and_degree_bounds_cpp_host_mirror(curve, n, tmp_path):
+    """The same through the C++ host mirror (host/ipa_pc.hpp: commit_general / open_general / check_general); the driver
+    also runs the mirror's verifier on honest and altered inputs."""
+    from test_oracle_cpu import _ipa_general_case
+    key, h, s, polys_i, ch_i, point_i, hp_i, hr_i = _ipa_general_case(curve, n)
+    want = R.ipa_open_general(curve, key, h, s, polys_i, point_i, ch_i, hp_i, hr_i)
+    libdir = os.path.join(ROOT, "poly-commit_amd")
+    exe = os.path.join(ROOT, "tests", "cpp", "ipa_general_driver")
+    src = exe + ".cpp"
+    deps = [src, os.path.join(libdir, "libpc_hip.so")] + [os.path.join(libdir, "host", f) for f in os.listdir(os.path.join(libdir, "host"))]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + libdir, "-lpc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    m = lambda v: O.fr_mont_array(curve, v)                          # noqa: E731
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<III", O.CURVES[curve], n, len(polys_i)))
+        f.write(O.points_to_array(curve, key + [h, s]).tobytes())
+        for q in polys_i:
+            f.write(struct.pack("<I", len(q["coeffs"]))); f.write(m(q["coeffs"]).tobytes())
+            f.write(struct.pack("<iI", -1 if q["degree_bound"] is None else q["degree_bound"], 1 if q["hiding"] else 0))
+            f.write(m([q["rand"], q["shifted_rand"]]).tobytes())
+        f.write(m([point_i]).tobytes()); f.write(m(ch_i).tobytes()); f.write(m(hp_i).tobytes()); f.write(m([hr_i]).tobytes())
+    res = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    aw = 2 * O.fq_limbs(curve)
+    raw = np.fromfile(fout, dtype=np.uint64)
+    k, rounds = len(polys_i), (n - 1).bit_length()
+    off = 0
+    coms = O.array_to_points(curve, raw[off:off + 2 * k * aw].reshape(2 * k, aw)); off += 2 * k * aw
+    for j, q in enumerate(polys_i):
+        assert coms[2 * j] == q["comm"] and coms[2 * j + 1] == q["shifted_comm"]
+    lr = O.array_to_points(curve, raw[off:off + (2 * rounds + 1) * aw].reshape(2 * rounds + 1, aw)); off += (2 * rounds + 1) * aw
+    assert lr[:rounds] == want[0] and lr[rounds:2 * rounds] == want[1] and lr[2 * rounds] == want[2]
+    assert O.fr_from_mont_array(curve, raw[off:off + 4].reshape(1, 4))[0] == want[3]; off += 4
+    assert O.array_to_points(curve, raw[off:off + aw].reshape(1, aw))[0] == want[4]; off += aw
+    assert O.fr_from_mont_array(curve, raw[off:off + 4].reshape(1, 4))[0] == want[5]
