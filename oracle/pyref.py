@@ -858,3 +858,70 @@ def ipa_check_general(curve, comm_key, h, s, comms, point, values, proof, challe
     if round_comm != ec_add(curve, ec_mul(curve, c, final_key), ec_mul(curve, v_prime, h_prime)):
         return False
     return msm(curve, comm_key, succinct_check_coeffs(fr, chal)) == final_key
+
+
+# ---------------------------------------------------------------------------------------
+# LinearCodePCS (univariate Ligero) commit / open / check (linear_codes/mod.rs:228-505, univariate_ligero/mod.rs:68-86).
+# The sponge is the caller's: the query indices and (with check_well_formedness) the vector r are inputs.
+# ---------------------------------------------------------------------------------------
+def ligero_commit(field, coeffs, rho_inv=4, sec_param=128, col_hash="blake2s", tree_hash="sha256"):
+    """commit for one polynomial (:248-277): matrix, encoded matrix, column digests, Merkle tree."""
+    n_rows, n_cols, _ = ligero_dimensions(field, len(coeffs), rho_inv, sec_param)
+    flat = list(coeffs) + [0] * (n_rows * n_cols - len(coeffs))
+    mat = [flat[r * n_cols:(r + 1) * n_cols] for r in range(n_rows)]
+    ext = [reed_solomon(field, row, rho_inv) for row in mat]
+    n_ext = len(ext[0])
+    leaves = [column_digest(field, [ext[r][j] for r in range(n_rows)], col_hash) for j in range(n_ext)]
+    nodes = merkle_tree(leaves, tree_hash)
+    return dict(n_rows=n_rows, n_cols=n_cols, n_ext_cols=n_ext, root=nodes[0], mat=mat, ext=ext, leaves=leaves, nodes=nodes)
+
+
+def ligero_tensor(field, z, left, right):
+    """UnivariateLigero::tensor (univariate_ligero/mod.rs:70-86): ((1, z, .., z^(left-1)), (1, z^left, z^(2 left), ..))."""
+    p = FIELDS[field]["p"]
+    a, pw = [], 1
+    for _ in range(left):
+        a.append(pw)
+        pw = pw * z % p
+    b, q = [], 1
+    for _ in range(right):
+        b.append(q)
+        q = q * pw % p
+    return a, b
+
+
+def ligero_num_queries(field, n_ext_cols, rho_inv=4, sec_param=128):
+    return calculate_t(FIELDS[field]["p"].bit_length(), sec_param, (rho_inv - 1, rho_inv), n_ext_cols)
+
+
+def ligero_open(field, st, z, indices, r=None):
+    """open for one polynomial (:300-373 with generate_proof :523-565): v = b.M, the queried columns of the encoded
+    matrix with their Merkle paths, and r.M when well-formedness is checked."""
+    _, b = ligero_tensor(field, z, st["n_cols"], st["n_rows"])
+    wf = fr_lincomb(field, st["mat"], r) if r is not None else None
+    v = fr_lincomb(field, st["mat"], b)
+    columns = [[st["ext"][row][i] for row in range(st["n_rows"])] for i in indices]
+    paths = [(i,) + merkle_path(st["nodes"], st["leaves"], i) for i in indices]
+    return dict(v=v, columns=columns, paths=paths, well_formedness=wf)
+
+
+def ligero_check(field, commitment, z, value, proof, indices, r=None, rho_inv=4, col_hash="blake2s", tree_hash="sha256"):
+    """check for one commitment (:375-503).  commitment: dict with n_rows, n_cols, n_ext_cols, root.
+    Raises ValueError("InvalidCommitment") where the reference returns Err, returns False for a wrong value."""
+    p = FIELDS[field]["p"]
+    n_rows, n_cols, n_ext = commitment["n_rows"], commitment["n_cols"], commitment["n_ext_cols"]
+    if (r is not None) != (proof["well_formedness"] is not None):
+        raise ValueError("InvalidCommitment")
+    col_hashes = [column_digest(field, c, col_hash) for c in proof["columns"]]
+    for leaf, q_j, (idx, sib, path) in zip(col_hashes, indices, proof["paths"]):
+        if idx != q_j or not merkle_verify(commitment["root"], leaf, idx, sib, path, tree_hash):
+            raise ValueError("InvalidCommitment")
+    w = reed_solomon(field, proof["v"], rho_inv)
+    a, b = ligero_tensor(field, z, n_cols, n_rows)
+    wwf = reed_solomon(field, proof["well_formedness"], rho_inv) if r is not None else None
+    for col, idx in zip(proof["columns"], indices):
+        if r is not None and sum(x * y for x, y in zip(r, col)) % p != wwf[idx]:
+            raise ValueError("InvalidCommitment")
+        if sum(x * y for x, y in zip(b, col)) % p != w[idx]:
+            raise ValueError("InvalidCommitment")
+    return sum(x * y for x, y in zip(proof["v"], a)) % p == value % p

@@ -1,0 +1,50 @@
+"""GPU parity for LinearCodePCS (univariate Ligero) commit / open / check through poly-commit_amd/ligero.py against the
+Python restatement in oracle/pyref.py: commitment (root, shape), opening proof (v, queried columns, Merkle paths,
+well-formedness vector) bit for bit; then both verifiers on honest and altered proofs."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve,poly_len,wf", [("bn254", 300, True), ("bls12_381", 1 << 12, False), ("bls12_381", 5000, True)])
+def test_ligero_commit_open_check_vs_oracle(ctx, curve, poly_len, wf):
+    import torch
+    from poly_commit_amd import ligero
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    co = R.gen_scalars(fr, 0x810, poly_len)
+    want = R.ligero_commit(fr, co)
+    m = lambda v: O.fr_mont_array(curve, v)                          # noqa: E731
+    dev = torch.from_numpy(m(co).view(np.int64)).cuda()
+    com, state = ligero.commit(ctx, curve, dev)
+    assert (com["n_rows"], com["n_cols"], com["n_ext_cols"], com["root"]) == (want["n_rows"], want["n_cols"], want["n_ext_cols"], want["root"])
+    z = R.gen_scalars(fr, 0x811, 1)[0]
+    t = R.ligero_num_queries(fr, want["n_ext_cols"])
+    assert t == ligero.calculate_t(p.bit_length(), 128, (3, 4), want["n_ext_cols"])
+    idx = [(i * 7919 + 13) % want["n_ext_cols"] for i in range(t)]                 # what the caller's sponge would produce
+    r = R.gen_scalars(fr, 0x812, want["n_rows"]) if wf else None
+    want_pr = R.ligero_open(fr, want, z, idx, r)
+    pr = ligero.open(ctx, curve, state, m([z])[0], idx, m(r) if wf else None)
+    assert O.fr_from_mont_array(curve, pr["v"]) == want_pr["v"]
+    assert [O.fr_from_mont_array(curve, c) for c in pr["columns"]] == want_pr["columns"]
+    assert pr["paths"] == want_pr["paths"]
+    assert (pr["well_formedness"] is None) == (not wf) and (not wf or O.fr_from_mont_array(curve, pr["well_formedness"]) == want_pr["well_formedness"])
+    value = R.poly_eval(fr, co, z)
+    args = (ctx, curve, com, m([z])[0])
+    assert ligero.check(*args, m([value])[0], pr, idx, m(r) if wf else None) is True
+    assert R.ligero_check(fr, want, z, value, want_pr, idx, r) is True
+    assert ligero.check(*args, m([(value + 1) % p])[0], pr, idx, m(r) if wf else None) is False
+    bad = dict(pr); bad["v"] = pr["v"].copy(); bad["v"][0, 0] ^= np.uint64(1)
+    with pytest.raises(ligero.InvalidCommitment):
+        ligero.check(*args, m([value])[0], bad, idx, m(r) if wf else None)
+    bad = dict(pr); bad["columns"] = pr["columns"].copy(); bad["columns"][1, 0, 0] ^= np.uint64(1)
+    with pytest.raises(ligero.InvalidCommitment):
+        ligero.check(*args, m([value])[0], bad, idx, m(r) if wf else None)
+    shifted = [idx[1]] + idx[1:]
+    if shifted != idx:
+        with pytest.raises(ligero.InvalidCommitment):
+            ligero.check(*args, m([value])[0], pr, shifted, m(r) if wf else None)
