@@ -188,6 +188,13 @@ int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_m
 int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_mem where_in, size_t n_leaves,
                        int len_prefix, void* out_nodes, pc_mem where_out);
 
+/* The queried columns of a resident encoded matrix: generate_proof's `ext_mat.cols()[i]` for the t indices the sponge
+ * produced (poly-commit/src/linear_codes/mod.rs:546-552), without moving the matrix:
+ *   out[j * rows + r] = mat[r * n_cols + indices[j]],  32-byte elements, any of the scalar fields.
+ * mat_dev: device pointer (rows x n_cols, row-major: the ext_out of pc_hip_ligero_commit / pc_hip_ntt_batch). */
+int pc_hip_matrix_columns(pc_ctx* ctx, const void* mat_dev, size_t rows, size_t n_cols, const uint32_t* indices_host, size_t t,
+                          void* out, pc_mem where_out);
+
 /* LinearCodePCS::commit steps 1-3 for one polynomial in one call, nothing but the results leaving
  * HBM (poly-commit/src/linear_codes/mod.rs:248-277): encode the rows x in_cols coefficient matrix
  * (pc_hip_ntt_batch), digest the 2^log_n columns (pc_hip_column_hash, col_hash), build the Merkle

@@ -76,6 +76,7 @@ def load_library():
     lib.pc_hip_set_timing.argtypes = [vp, ip]
     lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_last_msm_shape.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.pc_hip_matrix_columns.argtypes = [vp, vp, sz, sz, vp, sz, vp, ip]
     lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
@@ -192,6 +193,13 @@ class Context:
         pout, wout = _ptr(out)
         hid = {"sha256": 0, "blake2s": 1}[hash_name]
         self.check(self.lib.pc_hip_column_hash(self.h, CURVES[curve], pin, win, rows, n_cols, hid, pout, wout))
+        return out
+
+    def matrix_columns(self, mat_dev, rows, n_cols, indices):
+        """Columns `indices` of a resident rows x n_cols matrix of 32-byte elements -> (t, rows, 4) uint64 host array."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        out = np.zeros((len(idx), rows, 4), dtype=np.uint64)
+        self.check(self.lib.pc_hip_matrix_columns(self.h, mat_dev, rows, n_cols, idx.ctypes.data, len(idx), out.ctypes.data, PC_MEM_HOST))
         return out
 
     def merkle_tree(self, digests, hash_name="sha256", len_prefix=True, out=None, n_leaves=None):

@@ -780,6 +780,22 @@ int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_m
   });
 }
 
+int pc_hip_matrix_columns(pc_ctx* ctx, const void* mat_dev, size_t rows, size_t n_cols, const uint32_t* indices_host, size_t t,
+                          void* out, pc_mem where_out) {
+  if (!ctx || !mat_dev || !rows || !n_cols || (t && (!indices_host || !out))) return PC_ERR_INVALID_ARG;
+  if (rows * (uint64_t)t >= (1ull << 31) || n_cols >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  for (size_t j = 0; j < t; j++) if (indices_host[j] >= n_cols) return PC_ERR_INVALID_ARG;
+  if (!t) return PC_OK;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    Staged sidx(ctx->be, indices_host, PC_MEM_HOST, t * 4, true);
+    Staged sout(ctx->be, out, where_out, rows * t * 32, false);
+    pc::gather_columns(ctx->be, (const uint32_t*)mat_dev, rows, n_cols, (const uint32_t*)sidx.dev, t, (uint32_t*)sout.dev);
+    if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, rows * t * 32); else ctx->be.sync();
+    return (int)PC_OK;
+  });
+}
+
 int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, pc_mem where_in, const size_t* lens,
                       size_t k, const void* xi_host, void* out, pc_mem where_out, size_t n_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || (k && (!polys || !lens || !xi_host)) || (n_out && !out))

@@ -73,6 +73,7 @@ inline const FieldOps& field_ops(pc_curve c) {
 }
 
 // hash-only kernels (hash_tu.hip)
+void gather_columns(HipBackend& be, const uint32_t* mat, size_t rows, size_t n_cols, const uint32_t* idx_dev, size_t t, uint32_t* out);
 void merkle_level(HipBackend& be, int hash, const uint32_t* child, uint32_t* parent, uint32_t n_leaves, uint32_t bottom,
                   uint32_t len_prefix, size_t cnt);
 

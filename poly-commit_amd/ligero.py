@@ -125,8 +125,7 @@ def open(ctx, curve, state, z_mont, indices, r_mont=None):   # noqa: A001 (the r
         return out.cpu().numpy().view(np.uint64)
     wf = row_mul(r_mont) if r_mont is not None else None           # :343-349
     v = row_mul(_monts(curve, b))                                  # generate_proof step 1
-    idx = torch.tensor(list(indices), dtype=torch.long, device=ext.device)
-    cols = ext.view(n_rows, n_ext, 4)[:, idx, :].permute(1, 0, 2).contiguous().cpu().numpy().view(np.uint64)      # (t, n_rows, 4)
+    cols = ctx.matrix_columns(ext.data_ptr(), n_rows, n_ext, list(indices))                           # (t, n_rows, 4)
     paths = [(int(i),) + _merkle_path(state["nodes"], state["leaves"], int(i)) for i in indices]
     return dict(v=v, columns=cols, paths=paths, well_formedness=wf)
 
