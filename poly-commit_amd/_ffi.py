@@ -415,6 +415,14 @@ class Srs:
         u = np.ascontiguousarray(u, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.pc_hip_ec_fold(self.ctx.h, self.h, n_half, C.c_void_p(u.ctypes.data)))
 
+    def device_ptr(self):
+        """Address of the resident packed point array (pc_hip_srs_device_ptr)."""
+        return int(self.ctx.lib.pc_hip_srs_device_ptr(self.h))
+
+    def clone(self):
+        """A second resident copy (device-to-device): what a destructive consumer -- the IPA key fold -- works on."""
+        return Srs(self.ctx, self.curve, self.device_ptr(), n=self.n)
+
     def read(self, offset, count):
         out = np.zeros((count, 2 * FQ_BYTES[self.curve] // 8), dtype=np.uint64)
         self.ctx.check(self.ctx.lib.pc_hip_srs_read(self.ctx.h, self.h, offset, count, C.c_void_p(out.ctypes.data)))

@@ -69,7 +69,7 @@ def ipa_open(ctx, curve, comm_key, h_xy, polys_dev, lens, comms, point_mont, ope
     polys_dev: device pointers of the coefficient vectors; comms: their commitments (x||y).
     Returns (l_vec, r_vec, final_comm_key, c)."""
     import torch
-    n = comm_key.shape[0]
+    n = comm_key.n if isinstance(comm_key, _ffi.Srs) else comm_key.shape[0]
     p = FR_MODULUS[curve]
     xi = np.ascontiguousarray(opening_challenges, dtype=np.uint64)
     comb = torch.empty((n, 4), dtype=torch.int64, device="cuda")
@@ -91,7 +91,7 @@ FIXED_KEY_BELOW = 1 << 17     # rounds with n <= this keep the key and fold per-
 
 def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, timings=None,
                     fixed_key_below=None):
-    """comm_key: n x (x||y) host array; coeffs_dev: torch cuda int64 tensor (n,4), Montgomery,
+    """comm_key: n x (x||y) host array, or a resident Srs (it is cloned on the device, not consumed); coeffs_dev: torch cuda int64 tensor (n,4), Montgomery,
     CONSUMED (folded in place).  Returns (l_vec, r_vec, final_comm_key, c) as numpy arrays."""
     if fixed_key_below is None:
         fixed_key_below = FIXED_KEY_BELOW
@@ -112,7 +112,8 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     p = FR_MODULUS[curve]
     rinv = pow(_R, -1, p)
     with _T("upload_key"):
-        srs = ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
+        # the folds are destructive: work on a copy of the key -- device-to-device when the caller keeps it resident
+        srs = comm_key.clone() if isinstance(comm_key, _ffi.Srs) else ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
     h_prime_xy = np.ascontiguousarray(h_prime_xy)
     z = torch.empty((n, 4), dtype=torch.int64, device=coeffs_dev.device)
     ctx.fr_powers(curve, point_mont, n, z.data_ptr())

@@ -77,6 +77,13 @@ def test_ipa_open_whole_proof_python_host(ctx, curve, n):
     (l, r, fk, c), _ = ipa.ipa_open(ctx, curve, comm_key, h, [d.data_ptr() for d in dev], [len(q) for q in polys], comms, point, xi)
     wl, wr, wfk, wc, _ = _oracle_open(curve, comm_key, h, polys, comms, xi, point)
     assert (l == wl).all() and (r == wr).all() and (fk == wfk).all() and (c == wc).all()
+    # the same with the committer key resident (cloned on the device for the destructive folds, itself untouched)
+    key_srs = ctx.upload_srs(curve, comm_key)
+    dev = [torch.from_numpy(q.view(np.int64).copy()).cuda() for q in polys]
+    (l2, r2, fk2, c2), _ = ipa.ipa_open(ctx, curve, key_srs, h, [d.data_ptr() for d in dev], [len(q) for q in polys], comms, point, xi)
+    assert (l2 == wl).all() and (r2 == wr).all() and (fk2 == wfk).all() and (c2 == wc).all()
+    assert (key_srs.read(0, min(n, 8)) == comm_key[:min(n, 8)]).all()
+    key_srs.free()
 
 
 @pytest.mark.parametrize("curve,n", [("pallas", 1 << 9), ("bn254", 1 << 4), ("bls12_381", 1 << 5)])

@@ -23,11 +23,11 @@ torch.cuda.synchronize()
 for _ in range(3):      # every pipeline of the SRS exists (streams + workspace are created on first use)
     srs.msm(cdev.data_ptr(), n=n, montgomery=True)
 t = time.perf_counter(); srs.msm(cdev.data_ptr(), n=n, montgomery=True); t_commit = time.perf_counter() - t
-srs.free()
 it = iter(range(log_n))
 t = time.perf_counter()
 tm = {}
-ipa.ipa_open_rounds(ctx, curve, key[:n], cdev, n, point, key[n], lambda L, R_: ch[next(it)], timings=tm, fixed_key_below=fkb)
+# the committer key stays resident (like a KZG SRS): the destructive folds of open work on a device-to-device copy of it
+ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, key[n], lambda L, R_: ch[next(it)], timings=tm, fixed_key_below=fkb)
 per_round = tm.pop("per_round_ms", [])
 t_open = time.perf_counter() - t
 print(json.dumps({"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: commit MSM + {log_n} halving rounds (challenges supplied)",
