@@ -8,8 +8,10 @@
 //   generate_proof step 1 (row_mul)     linear_codes/mod.rs:539, poly-commit/src/utils.rs:120-147
 // Matrix<F> is the reference's dense row-major matrix (utils.rs:49-147) flattened.
 #pragma once
+#include <array>
 #include <math.h>
 #include "kzg10.hpp"
+#include "transcript.hpp"
 
 namespace pc_host {
 
@@ -132,6 +134,90 @@ struct LinearCodePCS {
       const size_t sib = (node & 1) ? node + 1 : node - 1;
       path.insert(path.end(), st.nodes.begin() + sib * 32, st.nodes.begin() + (sib + 1) * 32);
     }
+  }
+
+  // ---- open / check (linear_codes/mod.rs:300-503, generate_proof :523-565).  The sponge is the caller's: the t query
+  //      indices (get_indices_from_sponge, utils.rs:136-153) and, with check_well_formedness, the vector r are arguments.
+  struct ProofSingle {                               // LinCodePCProof { opening: LinCodePCProofSingle { paths, v, columns }, well_formedness }
+    std::vector<size_t> leaf_index;
+    std::vector<std::array<uint8_t, 32>> leaf_sibling;
+    std::vector<std::vector<uint8_t>> paths;         // per query: sibling inner nodes, bottom-up
+    std::vector<FrT<E>> v;
+    std::vector<std::vector<FrT<E>>> columns;
+    bool has_well_formedness = false;
+    std::vector<FrT<E>> well_formedness;
+  };
+  // UnivariateLigero::tensor (univariate_ligero/mod.rs:70-86): ((1, z, .., z^(left-1)), (1, z^left, z^(2 left), ..))
+  static void tensor(const FrT<E>& z, size_t left, size_t right, std::vector<FrT<E>>& a, std::vector<FrT<E>>& b) {
+    a.clear(); b.clear();
+    FrT<E> pw = FrT<E>::one();
+    for (size_t i = 0; i < left; i++) { a.push_back(pw); pw = pw * z; }
+    FrT<E> q = FrT<E>::one();
+    for (size_t i = 0; i < right; i++) { b.push_back(q); q = q * pw; }
+  }
+  static Error invalid_commitment(const char* what) { Error e; e.kind = Error::InvalidCommitment; e.msg = what; return e; }
+  void two_to_one(const uint8_t* data, size_t len, uint8_t out[32]) const {
+    if (tree_hash == PC_HASH_SHA256) Sha256Host::digest(data, len, out); else Blake2s::digest(data, len, out);
+  }
+  // Path::verify for the byte-digest Config: bottom level D(conv(l) || conv(r)), upper levels D(left || right)
+  bool verify_path(const uint8_t root[32], const uint8_t leaf[32], size_t index, const uint8_t sibling[32], const std::vector<uint8_t>& path) const {
+    uint8_t buf[96], cur[32]; size_t n = 0;
+    auto put = [&](const uint8_t* d) { if (len_prefix) { uint64_t l = 32; memcpy(buf + n, &l, 8); n += 8; } memcpy(buf + n, d, 32); n += 32; };
+    if (index % 2 == 0) { put(leaf); put(sibling); } else { put(sibling); put(leaf); }
+    two_to_one(buf, n, cur);
+    index /= 2;
+    for (size_t k = 0; k + 32 <= path.size(); k += 32, index /= 2) {
+      if (index % 2 == 0) { memcpy(buf, cur, 32); memcpy(buf + 32, path.data() + k, 32); } else { memcpy(buf, path.data() + k, 32); memcpy(buf + 32, cur, 32); }
+      two_to_one(buf, 64, cur);
+    }
+    return memcmp(cur, root, 32) == 0;
+  }
+  Error open(pc_ctx* ctx, const LinCodePCCommitment& com, const LinCodePCCommitmentState<E>& st, const FrT<E>& z,
+             const std::vector<size_t>& indices, const std::vector<FrT<E>>* r, ProofSingle& proof) const {
+    if (st.ext_mat.entries.empty()) { Error e; e.kind = Error::Backend; e.msg = "open needs the encoded matrix in the commitment state"; return e; }
+    std::vector<FrT<E>> a, b; tensor(z, com.metadata.n_cols, com.metadata.n_rows, a, b);
+    proof = ProofSingle();
+    if (r) { if (Error e = row_mul(ctx, st.mat, *r, proof.well_formedness)) return e; proof.has_well_formedness = true; }     // :343-349
+    if (Error e = row_mul(ctx, st.mat, b, proof.v)) return e;                                                              // generate_proof 1.
+    for (size_t idx : indices) {                                                                                            // 3.
+      if (idx >= st.ext_mat.m) return invalid_commitment("query index out of range");
+      std::vector<FrT<E>> col(st.ext_mat.n);
+      for (size_t row = 0; row < st.ext_mat.n; row++) col[row] = st.ext_mat.entries[row * st.ext_mat.m + idx];
+      proof.columns.push_back(col);
+      std::array<uint8_t, 32> sib; std::vector<uint8_t> path;
+      merkle_path(st, idx, sib.data(), path);
+      proof.leaf_index.push_back(idx); proof.leaf_sibling.push_back(sib); proof.paths.push_back(path);
+    }
+    return Error();
+  }
+  // ok == false: the claimed value is wrong (:494-499); Error::InvalidCommitment: a path, an index or an inner product fails
+  Error check(pc_ctx* ctx, const LinCodePCCommitment& com, const LigeroPCParams& param, const FrT<E>& z, const FrT<E>& value,
+              const ProofSingle& proof, const std::vector<size_t>& indices, const std::vector<FrT<E>>* r, bool& ok) const {
+    ok = false;
+    const size_t n_rows = com.metadata.n_rows, n_cols = com.metadata.n_cols, n_ext = com.metadata.n_ext_cols, t = indices.size();
+    if ((r != nullptr) != proof.has_well_formedness) return invalid_commitment("well-formedness proof missing or unexpected");
+    if (proof.columns.size() != t || proof.paths.size() != t || proof.v.size() != n_cols) return invalid_commitment("proof shape");
+    // 3. hash the received columns (device: they are the columns of an n_rows x t matrix)
+    std::vector<FrT<E>> m(n_rows * t);
+    for (size_t j = 0; j < t; j++) { if (proof.columns[j].size() != n_rows) return invalid_commitment("column length"); for (size_t row = 0; row < n_rows; row++) m[row * t + j] = proof.columns[j][row]; }
+    std::vector<uint8_t> digests(t * 32);
+    int rc = t ? pc_hip_column_hash(ctx, E::ID, m.data(), PC_MEM_HOST, n_rows, t, col_hash, digests.data(), PC_MEM_HOST) : PC_OK;
+    if (rc != PC_OK) { Error e; e.kind = Error::Backend; e.msg = pc_hip_strerror(rc); return e; }
+    for (size_t j = 0; j < t; j++)                                                                                          // 4.
+      if (proof.leaf_index[j] != indices[j] || !verify_path(com.root, &digests[j * 32], indices[j], proof.leaf_sibling[j].data(), proof.paths[j]))
+        return invalid_commitment("Merkle path");
+    std::vector<FrT<E>> w, wwf;                                                                                             // 5.
+    if (Error e = LinearEncode<E>::reed_solomon(ctx, proof.v, param.rho_inv, w)) return e;
+    if (r) if (Error e = LinearEncode<E>::reed_solomon(ctx, proof.well_formedness, param.rho_inv, wwf)) return e;
+    if (w.size() != n_ext) return invalid_commitment("encoding length");
+    std::vector<FrT<E>> a, b; tensor(z, n_cols, n_rows, a, b);                                                               // 6.
+    auto ip = [](const std::vector<FrT<E>>& x, const std::vector<FrT<E>>& y) { FrT<E> acc = FrT<E>::zero(); for (size_t i = 0; i < x.size() && i < y.size(); i++) acc = acc + x[i] * y[i]; return acc; };
+    for (size_t j = 0; j < t; j++) {                                                                                         // 7.
+      if (r && !(ip(*r, proof.columns[j]) == wwf[indices[j]])) return invalid_commitment("well-formedness inner product");
+      if (!(ip(b, proof.columns[j]) == w[indices[j]])) return invalid_commitment("b . column != w");
+    }
+    ok = ip(proof.v, a) == value;
+    return Error();
   }
 };
 

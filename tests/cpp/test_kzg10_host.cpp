@@ -230,6 +230,23 @@ static void run(pc_ctx* ctx, const char* name) {
     LinearCodePCS<E>::merkle_path(st, 5, sib, path);
     CHECK(path.size() == (ark_log2(st.ext_mat.m) - 1) * 32 && memcmp(sib, st.leaves.data() + 4 * 32, 32) == 0);
     CHECK(memcmp(path.data() + path.size() - 32, st.nodes.data() + 2 * 32, 32) == 0);   // leaf 5 is in the left half: last sibling is node 2
+    // open / check (linear_codes/mod.rs:300-503) with the sponge's outputs supplied: honest, wrong value, altered v / column / index
+    {
+      std::vector<size_t> idx; for (size_t j = 0; j < 24; j++) idx.push_back((j * 7919 + 13) % com.metadata.n_ext_cols);
+      std::vector<FrT<E>> r(st.mat.n); for (auto& x : r) x = rng.next_fr();
+      const FrT<E> z = rng.next_fr(), value = pol.evaluate(z);
+      for (int wf = 0; wf < 2; wf++) {
+        typename LinearCodePCS<E>::ProofSingle pr;
+        CHECK(!pcs.open(ctx, com, st, z, idx, wf ? &r : nullptr, pr));
+        bool ok = false;
+        CHECK(!pcs.check(ctx, com, param, z, value, pr, idx, wf ? &r : nullptr, ok) && ok);
+        CHECK(!pcs.check(ctx, com, param, z, value + FrT<E>::one(), pr, idx, wf ? &r : nullptr, ok) && !ok);
+        { auto bad = pr; bad.v[3] = bad.v[3] + FrT<E>::one(); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        { auto bad = pr; bad.columns[2][1] = bad.columns[2][1] + FrT<E>::one(); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        { auto bad = idx; bad[0] = idx[1]; CHECK(pcs.check(ctx, com, param, z, value, pr, bad, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        CHECK(pcs.check(ctx, com, param, z, value, pr, idx, wf ? nullptr : &r, ok).kind == Error::InvalidCommitment);
+      }
+    }
   }
   // ---- InnerProductArgPC: cm_commit and the halving loop of open (ipa_pc/mod.rs:54-72, 664-711) against the
   //      same rounds replayed with host point / field arithmetic ----
