@@ -894,10 +894,26 @@ def ligero_num_queries(field, n_ext_cols, rho_inv=4, sec_param=128):
     return calculate_t(FIELDS[field]["p"].bit_length(), sec_param, (rho_inv - 1, rho_inv), n_ext_cols)
 
 
-def ligero_open(field, st, z, indices, r=None):
+def tensor_vec(field, values):
+    """linear_codes/utils.rs:240-258: eq-tensor of the values, value i in bit i of the index."""
+    p = FIELDS[field]["p"]
+    layer = [1]
+    for v in values:
+        layer = [x * (1 - v) % p for x in layer] + [x * v % p for x in layer]
+    return layer
+
+
+def ligero_multilinear_tensor(field, point, left_len):
+    """MultilinearLigero::tensor (multilinear_ligero/mod.rs:70-84): the point is split at log2(left_len)."""
+    split = ark_log2(left_len)
+    return tensor_vec(field, point[:split]), tensor_vec(field, point[split:])
+
+
+def ligero_open(field, st, z, indices, r=None, tensors=None):
     """open for one polynomial (:300-373 with generate_proof :523-565): v = b.M, the queried columns of the encoded
-    matrix with their Merkle paths, and r.M when well-formedness is checked."""
-    _, b = ligero_tensor(field, z, st["n_cols"], st["n_rows"])
+    matrix with their Merkle paths, and r.M when well-formedness is checked.  tensors = (a, b) overrides the univariate
+    L::tensor(z, ..) (the multilinear scheme passes ligero_multilinear_tensor)."""
+    _, b = tensors if tensors is not None else ligero_tensor(field, z, st["n_cols"], st["n_rows"])
     wf = fr_lincomb(field, st["mat"], r) if r is not None else None
     v = fr_lincomb(field, st["mat"], b)
     columns = [[st["ext"][row][i] for row in range(st["n_rows"])] for i in indices]
@@ -905,7 +921,7 @@ def ligero_open(field, st, z, indices, r=None):
     return dict(v=v, columns=columns, paths=paths, well_formedness=wf)
 
 
-def ligero_check(field, commitment, z, value, proof, indices, r=None, rho_inv=4, col_hash="blake2s", tree_hash="sha256"):
+def ligero_check(field, commitment, z, value, proof, indices, r=None, rho_inv=4, col_hash="blake2s", tree_hash="sha256", tensors=None):
     """check for one commitment (:375-503).  commitment: dict with n_rows, n_cols, n_ext_cols, root.
     Raises ValueError("InvalidCommitment") where the reference returns Err, returns False for a wrong value."""
     p = FIELDS[field]["p"]
@@ -917,7 +933,7 @@ def ligero_check(field, commitment, z, value, proof, indices, r=None, rho_inv=4,
         if idx != q_j or not merkle_verify(commitment["root"], leaf, idx, sib, path, tree_hash):
             raise ValueError("InvalidCommitment")
     w = reed_solomon(field, proof["v"], rho_inv)
-    a, b = ligero_tensor(field, z, n_cols, n_rows)
+    a, b = tensors if tensors is not None else ligero_tensor(field, z, n_cols, n_rows)
     wwf = reed_solomon(field, proof["well_formedness"], rho_inv) if r is not None else None
     for col, idx in zip(proof["columns"], indices):
         if r is not None and sum(x * y for x, y in zip(r, col)) % p != wwf[idx]:

@@ -70,6 +70,23 @@ def tensor(curve, z_mont, left, right):
     return a, b
 
 
+def tensor_vec(curve, values):
+    """linear_codes/utils.rs:240-258 on canonical ints: value i in bit i of the index."""
+    p = FR_MODULUS[curve]
+    layer = [1]
+    for v in values:
+        layer = [x * (1 - v) % p for x in layer] + [x * v % p for x in layer]
+    return layer
+
+
+def multilinear_tensor(curve, point_mont, left_len):
+    """MultilinearLigero::tensor (multilinear_ligero/mod.rs:70-84): (a, b) for open / check's `tensors` argument; the
+    multilinear scheme commits to the evaluations with rho_inv = 2 and always checks well-formedness (:49-55)."""
+    pt = _ints(curve, np.ascontiguousarray(point_mont, dtype=np.uint64))
+    split = max(0, (left_len - 1).bit_length())
+    return tensor_vec(curve, pt[:split]), tensor_vec(curve, pt[split:])
+
+
 def commit(ctx, curve, coeffs_dev, rho_inv=4, sec_param=128, col_hash="blake2s", tree_hash="sha256"):
     """LinearCodePCS::commit for one polynomial.  coeffs_dev: torch cuda int64 (len, 4), Montgomery.
     Returns (commitment dict {n_rows, n_cols, n_ext_cols, root}, state)."""
@@ -111,12 +128,13 @@ def _merkle_verify(root, leaf, index, leaf_sibling, path, hash_name):
     return cur == root
 
 
-def open(ctx, curve, state, z_mont, indices, r_mont=None):   # noqa: A001 (the reference's name)
-    """LinearCodePCS::open for one polynomial: LinCodePCProof {opening: {paths, v, columns}, well_formedness}."""
+def open(ctx, curve, state, z_mont, indices, r_mont=None, tensors=None):   # noqa: A001 (the reference's name)
+    """LinearCodePCS::open for one polynomial: LinCodePCProof {opening: {paths, v, columns}, well_formedness}.
+    tensors = (a, b) replaces the univariate L::tensor(z, ..) (multilinear_tensor for MultilinearLigero)."""
     import torch
     n_rows, n_cols, n_ext = state["n_rows"], state["n_cols"], state["n_ext_cols"]
     mat, ext = state["mat"], state["ext"]
-    _, b = tensor(curve, z_mont, n_cols, n_rows)
+    _, b = tensors if tensors is not None else tensor(curve, z_mont, n_cols, n_rows)
     rows = [mat.data_ptr() + 32 * n_cols * i for i in range(n_rows)]
 
     def row_mul(coeffs_mont):                                      # Matrix::row_mul (poly-commit/src/utils.rs:120-147)
@@ -130,7 +148,8 @@ def open(ctx, curve, state, z_mont, indices, r_mont=None):   # noqa: A001 (the r
     return dict(v=v, columns=cols, paths=paths, well_formedness=wf)
 
 
-def check(ctx, curve, commitment, z_mont, value_mont, proof, indices, r_mont=None, rho_inv=4, col_hash="blake2s", tree_hash="sha256"):
+def check(ctx, curve, commitment, z_mont, value_mont, proof, indices, r_mont=None, rho_inv=4, col_hash="blake2s", tree_hash="sha256",
+          tensors=None):
     """LinearCodePCS::check for one commitment.  Raises InvalidCommitment where the reference returns Err(InvalidCommitment),
     returns False when only the claimed value is wrong (:494-499)."""
     import torch
@@ -156,7 +175,7 @@ def check(ctx, curve, commitment, z_mont, value_mont, proof, indices, r_mont=Non
         return y
     sel = torch.tensor(list(indices), dtype=torch.long, device="cuda")
     w = _ints(curve, encode(proof["v"])[sel].cpu().numpy().view(np.uint64))
-    a, b = tensor(curve, z_mont, n_cols, n_rows)
+    a, b = tensors if tensors is not None else tensor(curve, z_mont, n_cols, n_rows)
     col_ints = [_ints(curve, cols[j]) for j in range(t)]
     if r_mont is not None:
         wwf = _ints(curve, encode(proof["well_formedness"])[sel].cpu().numpy().view(np.uint64))

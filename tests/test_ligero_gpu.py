@@ -48,3 +48,29 @@ def test_ligero_commit_open_check_vs_oracle(ctx, curve, poly_len, wf):
     if shifted != idx:
         with pytest.raises(ligero.InvalidCommitment):
             ligero.check(*args, m([value])[0], pr, shifted, m(r) if wf else None)
+
+
+
+def test_multilinear_ligero_device(ctx):
+    """MultilinearLigero through the same device entry points (rho_inv = 2, tensor_vec tensors): opening and both verifiers
+    against the restatement and the multilinear extension's value."""
+    import torch
+    from poly_commit_amd import ligero
+    curve, n_vars = "bls12_381", 10
+    fr = R.CURVES[curve]["fr"]
+    evals = R.gen_scalars(fr, 0x830, 1 << n_vars)
+    point = R.gen_scalars(fr, 0x831, n_vars)
+    want = R.ligero_commit(fr, evals, rho_inv=2)
+    m = lambda v: O.fr_mont_array(curve, v)                          # noqa: E731
+    com, state = ligero.commit(ctx, curve, torch.from_numpy(m(evals).view(np.int64)).cuda(), rho_inv=2)
+    assert (com["n_rows"], com["n_cols"], com["n_ext_cols"], com["root"]) == (want["n_rows"], want["n_cols"], want["n_ext_cols"], want["root"])
+    ab = ligero.multilinear_tensor(curve, m(point), com["n_cols"])
+    assert ab == R.ligero_multilinear_tensor(fr, point, want["n_cols"])
+    idx = [(i * 911 + 3) % com["n_ext_cols"] for i in range(R.ligero_num_queries(fr, com["n_ext_cols"], rho_inv=2))]
+    r = R.gen_scalars(fr, 0x832, com["n_rows"])
+    pr = ligero.open(ctx, curve, state, None, idx, m(r), tensors=ab)
+    want_pr = R.ligero_open(fr, want, None, idx, r, tensors=ab)
+    assert O.fr_from_mont_array(curve, pr["v"]) == want_pr["v"] and pr["paths"] == want_pr["paths"]
+    value = R.mle_evaluate(fr, evals, point)
+    assert ligero.check(ctx, curve, com, None, m([value])[0], pr, idx, m(r), rho_inv=2, tensors=ab) is True
+    assert ligero.check(ctx, curve, com, None, m([value + 1])[0], pr, idx, m(r), rho_inv=2, tensors=ab) is False
