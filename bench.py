@@ -428,6 +428,18 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
                  "digits_per_scalar": shape["digits_per_scalar"], "buckets": shape["buckets"],
                  "note": "reported beside the prescribed HBM roofline: k_accumulate in the blocking MSMs (roofline.serial) "
                          "against a pure-arithmetic loop of the same addition on this GPU"}
+    valu_busy = None                      # SQ counters are a separate rocprofv3 pass (tools/sq_summary.py), like the PMC traffic
+    vf = os.path.join(ROOT, "profiles", "r02_valu.json")
+    if os.path.exists(vf) and args.precompute:
+        try:
+            ks = json.load(open(vf)).get("workloads", {}).get(f"kzg_2p{log_degree}", {})
+            valu_busy = next((v.get("valu_busy") for k, v in ks.items() if "k_accumulate<" in k), None)
+        except Exception:
+            valu_busy = None
+    if arith is not None:
+        arith["valu_busy"] = valu_busy
+        arith["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel time * 2.4 GHz) from profiles/r02_valu.json (separate rocprofv3 "
+                                   "--pmc pass of this workload); the nominal clock understates it under sustained VALU load")
     res = {
         "log_degree": log_degree, "steps": steps, "warmup": warmup, "dt": dt, "pairs_per_step": pairs_per_step,
         "value": pairs_per_step * steps / dt, "ms_per_step": dt / steps * 1e3,

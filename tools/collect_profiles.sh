@@ -16,4 +16,4 @@ rm -f profiles/r02_pmc_traffic.json
 python tools/pmc_summary.py $G/d_fetch24/bench_counter_collection.csv $G/d_write24/bench_counter_collection.csv profiles/r02_pmc_traffic.json "bls12_381:2^24:table"
 python tools/pmc_summary.py $G/d_fetch20/bench_counter_collection.csv $G/d_write20/bench_counter_collection.csv profiles/r02_pmc_traffic.json "bls12_381:2^20:table"
 python tools/pmc_summary.py $G/d_fetchntt/bench_counter_collection.csv $G/d_writentt/bench_counter_collection.csv profiles/r02_pmc_traffic.json "ntt:bls12_381:2^24"
-python tools/sq_summary.py $G/d_sq24/bench_counter_collection.csv $G/d_sq20/bench_counter_collection.csv $G/d_sqntt/bench_counter_collection.csv profiles/r02_valu.json | grep "accumulate\|ntt_pass\|ColumnHash"
+python tools/sq_summary.py kzg_2p24=$G/d_sq24/bench_counter_collection.csv kzg_2p20=$G/d_sq20/bench_counter_collection.csv ligero_2p24=$G/d_sqntt/bench_counter_collection.csv profiles/r02_valu.json | grep "accumulate\|ntt_pass\|ColumnHash"
