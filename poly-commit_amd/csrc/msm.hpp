@@ -44,6 +44,19 @@
 #include "ec.hpp"
 #include "host_tail.hpp"
 
+// "these values must have arrived": an empty asm that reads one register of every 16-byte load of an affine point (and
+// an index word) makes the compiler place its s_waitcnt here
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PC_ARRIVED(PT, IDX)                                                                                             \
+  do {                                                                                                                  \
+    constexpr int PC_N_ = sizeof((PT).x.l) / 4;                                                                         \
+    for (int pc_i_ = 0; pc_i_ < PC_N_; pc_i_ += 4) asm volatile("" ::"v"((PT).x.l[pc_i_]), "v"((PT).y.l[pc_i_]));     \
+    asm volatile("" ::"v"(IDX));                                                                                        \
+  } while (0)
+#else
+#define PC_ARRIVED(PT, IDX) ((void)0)
+#endif
+
 namespace pc {
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -229,6 +242,12 @@ struct AccumulateBody {
       uint32_t nval = (s + 1 < e) ? entries[s + 1] : val;
       AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * g.pt_stride);
       for (uint32_t p = s; p < e; p++) {
+        // Everything in flight here (the base and the index gathered during the previous addition) has had a whole addition
+        // to arrive: wait for it NOW, before the boundary block below issues its bucket stores and `offsets` loads.  The
+        // memory counter is in order, so the compiler's own wait -- at the first use of `pt`, behind that block -- became
+        // vmcnt(0) over the just-issued stores: every wave sat out a store round trip on the ~50 % of iterations in which
+        // one of its lanes crosses a bucket boundary (13 % of the wave cycles waiting in the SQ counters).
+        PC_ARRIVED(pt, nval);
         // Bucket boundary first: its loads of `offsets` must not sit behind this iteration's gathers
         // (waiting for the youngest load waits for all older ones: that stalled every wave on the
         // HBM latency of the prefetch it had just issued, on nearly every iteration).

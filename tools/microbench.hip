@@ -93,6 +93,20 @@ __global__ void __launch_bounds__(256) k_madd(uint32_t* out, const uint32_t* pts
   out[t] = r;
 }
 
+// the same loop held to two waves per SIMD (what the accumulate kernel runs at): how much of the 3-wave rate is left
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_madd_2waves(uint32_t* out, const uint32_t* pts, int npts, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  pc::XyzzD<C> acc = pc::XyzzD<C>::infinity();
+  constexpr int AW = 2 * C::FqP::N;
+  for (int it = 0; it < iters; it++) {
+    pc::AffD<C> p = pc::AffD<C>::load(pts + (size_t)((t * 31 + it) % npts) * AW);
+    acc.add_affine(p);
+  }
+  uint32_t r = 0; for (int i = 0; i < C::FqP::N; i++) r ^= acc.X.l[i] ^ acc.ZZ.l[i];
+  out[t] = r;
+}
+
 template <class K>
 static float timeit(K launch) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -149,6 +163,8 @@ int main() {
     const int it = 64;
     float ms = timeit([&]() { hipLaunchKernelGGL(k_madd<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
     printf("XYZZ madd bls12_381          %8.3f ms  %8.2f M madd/s\n", ms, (double)lanes * it / ms * 1e-3);
+    ms = timeit([&]() { hipLaunchKernelGGL(k_madd_2waves<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    printf("  same, 2 waves per SIMD     %8.3f ms  %8.2f M madd/s\n", ms, (double)lanes * it / ms * 1e-3);
   }
   return 0;
 }
