@@ -8,6 +8,7 @@
 #include "../../poly-commit_amd/host/marlin_kzg10.hpp"
 #include "../../poly-commit_amd/host/linear_codes.hpp"
 #include "../../poly-commit_amd/host/ipa_pc.hpp"
+#include "../../poly-commit_amd/host/hyrax.hpp"
 
 using namespace pc_host;
 
@@ -314,7 +315,53 @@ static void host_logic_checks() {
   LigeroPCParams bad; bad.sec_param = 400;                                           // no 255-bit field gives 2^-400
   size_t n = 0, m = 0;
   CHECK(bad.compute_dimensions<Bls12_381>((size_t)1 << 20, n, m).kind == Error::InvalidParameters);
-  printf("host logic OK (calculate_t bounds of linear_codes/utils.rs:344-359, Ligero shape table, InvalidParameters)\n");
+  // ---- device-free parts of the newer host layers ----
+  { // SHA-256 (FIPS 180-4 "abc") and a Merkle path built and verified with the host digests (byte-digest Config)
+    uint8_t d[32];
+    Sha256Host::digest((const uint8_t*)"abc", 3, d);
+    static const uint8_t want_abc[32] = {0xba, 0x78, 0x16, 0xbf, 0x8f, 0x01, 0xcf, 0xea, 0x41, 0x41, 0x40, 0xde, 0x5d, 0xae, 0x22, 0x23,
+                                         0xb0, 0x03, 0x61, 0xa3, 0x96, 0x17, 0x7a, 0x9c, 0xb4, 0x10, 0xff, 0x61, 0xf2, 0x00, 0x15, 0xad};
+    CHECK(memcmp(d, want_abc, 32) == 0);
+    LinearCodePCS<Bn254> pcs;                                      // Blake2s columns, SHA-256 tree, length-prefixed leaves
+    LinCodePCCommitmentState<Bn254> st;
+    const size_t n_leaves = 8;
+    st.leaves.resize(n_leaves * 32);
+    for (size_t i = 0; i < st.leaves.size(); i++) st.leaves[i] = (uint8_t)(i * 37 + 11);
+    st.nodes.assign((n_leaves - 1) * 32, 0);
+    auto node = [&](size_t i) { return st.nodes.data() + i * 32; };
+    for (size_t i = 0; i < n_leaves / 2; i++) {                      // bottom level: D(conv(l) || conv(r)), conv = u64 length || bytes
+      uint8_t buf[80]; uint64_t len = 32;
+      memcpy(buf, &len, 8); memcpy(buf + 8, &st.leaves[(2 * i) * 32], 32); memcpy(buf + 40, &len, 8); memcpy(buf + 48, &st.leaves[(2 * i + 1) * 32], 32);
+      Sha256Host::digest(buf, 80, node(n_leaves / 2 - 1 + i));
+    }
+    for (size_t i = n_leaves / 2 - 1; i-- > 0;) { uint8_t buf[64]; memcpy(buf, node(2 * i + 1), 32); memcpy(buf + 32, node(2 * i + 2), 32); Sha256Host::digest(buf, 64, node(i)); }
+    for (size_t idx = 0; idx < n_leaves; idx++) {
+      uint8_t sib[32]; std::vector<uint8_t> path;
+      LinearCodePCS<Bn254>::merkle_path(st, idx, sib, path);
+      CHECK(path.size() == 2 * 32);
+      CHECK(pcs.verify_path(node(0), &st.leaves[idx * 32], idx, sib, path));
+      uint8_t bad[32]; memcpy(bad, &st.leaves[idx * 32], 32); bad[0] ^= 1;
+      CHECK(!pcs.verify_path(node(0), bad, idx, sib, path));
+      CHECK(!pcs.verify_path(node(0), &st.leaves[idx * 32], idx ^ 2, sib, path));
+    }
+  }
+  { // tensors and check polynomials on small integers
+    typedef FrT<Pallas> Fr;
+    auto f = [](uint64_t v) { return Fr::from_u64(v); };
+    std::vector<Fr> a, b;
+    LinearCodePCS<Pallas>::tensor(f(3), 3, 2, a, b);                                  // ((1, z, z^2), (1, z^3))
+    CHECK(a.size() == 3 && b.size() == 2 && a[0] == f(1) && a[1] == f(3) && a[2] == f(9) && b[0] == f(1) && b[1] == f(27));
+    const Fr vals[2] = {f(3), f(5)};
+    std::vector<Fr> tp = HyraxPC<Pallas>::tensor_prime(vals, 2);                      // first value in the top bit
+    CHECK(tp.size() == 4 && tp[0] == (Fr::one() - f(3)) * (Fr::one() - f(5)) && tp[1] == (Fr::one() - f(3)) * f(5) &&
+          tp[2] == f(3) * (Fr::one() - f(5)) && tp[3] == f(15));
+    // SuccinctCheckPolynomial::evaluate against the product of its coefficient form: prod (1 + u_i x^(2^(log_d - i)))
+    std::vector<Fr> u = {f(7), f(11), f(13)};
+    const Fr x = f(2);
+    Fr want = (Fr::one() + u[0] * f(16)) * (Fr::one() + u[1] * f(4)) * (Fr::one() + u[2] * f(2));
+    CHECK(InnerProductArgPC<Pallas>::check_poly_evaluate(u, x) == want);
+  }
+  printf("host logic OK (calculate_t bounds of linear_codes/utils.rs:344-359, Ligero shape table, InvalidParameters, SHA-256 / Merkle paths, tensors)\n");
 }
 
 int main() {
