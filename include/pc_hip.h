@@ -74,7 +74,8 @@ void pc_hip_srs_free(pc_srs* srs);
 int pc_hip_srs_load_serialized(pc_ctx* ctx, pc_curve curve, const void* bytes, size_t n_bytes, int compressed,
                                size_t max_points, pc_srs** out, size_t* out_points, size_t* out_bytes_consumed);
 /* Optional, once per committer key (same place as the upload, i.e. `trim`): build the window
- * table T[w][i] = 2^(c w) * bases[i] in HBM, (bits/c + 1) x the size of the SRS.  MSMs of at least
+ * table T[w][i] = 2^(c w) * bases[i] in HBM, (bits/c + 1) x the size of the SRS (BLS12-381: every 96-byte point in its
+ * own 128-byte line, so 4/3 of that: 25.8 GB for 2^24 points at c = 22; PC_HIP_TBL_PAD=0 packs them).  MSMs of at least
  * min_pairs pairs (0 = a quarter of the SRS) against this SRS then run with one bucket set shared
  * by all windows: fewer, wider windows, no window fold -- same results, bit for bit.  window_bits
  * 0 = choose from the SRS length.  Shorter MSMs keep the table-free path.  pc_hip_ec_fold drops
