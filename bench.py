@@ -15,7 +15,7 @@ N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ONE polynomia
 N*2^24 whose SRS and coefficients are sharded in contiguous chunks (weak scaling: fixed pairs
 per GPU); each rank runs the full Pippenger on its chunk and the partial commitments /
 opening proofs are combined with an all_gather + EC adds (RCCL has no EC reduce op); the
-division carry crosses ranks as one Fr element.  See poly-commit_amd/sharded.py.
+division carry crosses ranks as one Fr element.  See poly_commit_amd/sharded.py.
 """
 import argparse
 import json

@@ -292,7 +292,7 @@ int pc_hip_srs_read(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count,
  * (one host thread per device) -- each device reduces its buckets to ONE point -- and adds the N partial points on
  * the host (what pc_hip_points_sum does; N * 96 bytes, no device-to-device collective: raw bucket arrays never
  * move).  Results are bit-identical to the single-device calls.  A device id may be listed more than once (tests on
- * a one-GPU machine).  The one-process-per-GPU form of the same protocol over RCCL is poly-commit_amd/sharded.py. */
+ * a one-GPU machine).  The one-process-per-GPU form of the same protocol over RCCL is poly_commit_amd/sharded.py. */
 typedef struct pc_group pc_group;
 typedef struct pc_group_srs pc_group_srs;
 int pc_hip_group_create(const int* device_ids, int n_devices, pc_group** out);

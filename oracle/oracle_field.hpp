@@ -1,5 +1,5 @@
 // CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Never linked into, or called from, the product
-// library (poly-commit_amd/csrc).  Only tests/, __graft_entry__.smoke() and bench.py's
+// library (poly_commit_amd/csrc).  Only tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg may load the shared object built from this file.
 //
 // Prime-field and short-Weierstrass (a = 0) arithmetic with 64-bit limbs and

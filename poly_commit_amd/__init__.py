@@ -1,8 +1,8 @@
-"""Import alias.  The product package lives in the directory ``poly-commit_amd/`` (the
-hyphen is part of the project name and is not importable); this shim points the importable
-name ``poly_commit_amd`` at it."""
-import os as _os
+"""MI355X (gfx950) backend for the commit/open hot path of arkworks-rs/poly-commit.
 
-__path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "poly-commit_amd")]
-with open(_os.path.join(__path__[0], "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(__path__[0], "__init__.py"), "exec"))
+Python is only the harness language here (tests, bench, torch.distributed plumbing); the
+product is the C-ABI library ``libpc_hip.so`` (include/pc_hip.h) built from ``csrc/``.
+"""
+from ._ffi import (  # noqa: F401
+    CURVES, Context, Group, GroupSrs, PcHipError, Srs, library_path, load_library, point_mul, points_sum,
+)

@@ -26,7 +26,7 @@ def library_path():
 
 
 def load_library():
-    """Load libpc_hip.so (built by poly-commit_amd/build.py).  Raises if it is absent."""
+    """Load libpc_hip.so (built by poly_commit_amd/build.py).  Raises if it is absent."""
     global _lib
     if _lib is not None:
         return _lib

@@ -5,7 +5,7 @@
 // and the N partial points are added on the host (pc_hip_points_sum): the exchange is N * 96 bytes, so no
 // device-to-device collective is involved -- partial BUCKET arrays are never moved (75 MB per GPU at 2^20).
 // The one-process-per-GPU form of the same protocol (torch.distributed / RCCL all_gather of the partial
-// points) is poly-commit_amd/sharded.py, which bench.py --gpus N uses.
+// points) is poly_commit_amd/sharded.py, which bench.py --gpus N uses.
 #include <algorithm>
 #include <string>
 #include <thread>

@@ -1,6 +1,6 @@
 // Internal interfaces between the translation units of libpc_hip.so.
 //
-// The library is built from several .hip files compiled in parallel (poly-commit_amd/build.py):
+// The library is built from several .hip files compiled in parallel (poly_commit_amd/build.py):
 //   abi.hip            the extern "C" entry points (include/pc_hip.h): lifetime, staging, error translation
 //   curve_<name>.hip   everything templated on one curve: MSM pipeline, window table, key fold, fixed-base mul
 //   field_<name>.hip   everything templated on one scalar field: NTT, division scan, IPA vector kernels,

@@ -1,5 +1,5 @@
 """Worker for tests/test_sharded_gloo.py: one rank of a world_size-N gloo job.  Exercises the
-index / carry / fold logic of poly-commit_amd/sharded.py with an oracle-backed engine (a test
+index / carry / fold logic of poly_commit_amd/sharded.py with an oracle-backed engine (a test
 double for HipEngine -- there is no GPU here) and compares with the single-process oracle."""
 import os
 import sys

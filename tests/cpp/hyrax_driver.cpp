@@ -1,10 +1,10 @@
-// Test driver: HyraxPC::commit / open / check of the C++ host mirror (poly-commit_amd/host/hyrax.hpp) on inputs read from
+// Test driver: HyraxPC::commit / open / check of the C++ host mirror (poly_commit_amd/host/hyrax.hpp) on inputs read from
 // a file; commitment and proof written to a file -- tests/test_hyrax_gpu.py compares them with the oracle's restatement.
 //   file in : u32 curve, u32 n_vars | com_key dim*xy | h xy | evals 2^n Fr | rands dim Fr | point n Fr | r_eval | d dim Fr | r_d | r_b | c
 //   file out: row_coms dim*xy | com_eval, com_d, com_b xy | z dim Fr | z_d | z_b | eval
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../poly-commit_amd/host/hyrax.hpp"
+#include "../../poly_commit_amd/host/hyrax.hpp"
 using namespace pc_host;
 
 template <class E>

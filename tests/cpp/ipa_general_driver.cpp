@@ -1,12 +1,12 @@
 // Test driver: InnerProductArgPC commit / open / check WITH hiding and degree bounds through the C++ host mirror
-// (poly-commit_amd/host/ipa_pc.hpp: commit_general, open_general, check_general).
+// (poly_commit_amd/host/ipa_pc.hpp: commit_general, open_general, check_general).
 //   file in : u32 curve, u32 n, u32 k | comm_key n*xy | h xy | s xy |
 //             k x (u32 len, len*Fr, i32 degree_bound, u32 hiding, rand Fr, shifted_rand Fr) | point Fr | (2k+1) challenges Fr |
 //             hiding polynomial n*Fr | hiding_rand Fr
 //   file out: k x (comm xy, shifted_comm xy) | log2(n) x l xy | log2(n) x r xy | final_comm_key xy | c Fr | hiding_comm xy | rand Fr
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../poly-commit_amd/host/ipa_pc.hpp"
+#include "../../poly_commit_amd/host/ipa_pc.hpp"
 using namespace pc_host;
 
 template <class E>

@@ -1,11 +1,11 @@
-// Test driver: InnerProductArgPC::open of the C++ host mirror (poly-commit_amd/host/ipa_pc.hpp) on inputs read
+// Test driver: InnerProductArgPC::open of the C++ host mirror (poly_commit_amd/host/ipa_pc.hpp) on inputs read
 // from a file, proof written to a file -- tests/test_ipa_gpu.py compares it with the oracle's restatement of the
 // same open (Fiat-Shamir transcript included).  Also self-checks the host Blake2s against RFC 7693 appendix B.
 //   file in : u32 curve, u32 n, u32 k | comm_key n*xy | h xy | k x (u32 len, len*Fr) | k x commitment xy | point Fr | k x xi Fr
 //   file out: log2(n) x l xy | log2(n) x r xy | final_comm_key xy | c Fr
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../poly-commit_amd/host/ipa_pc.hpp"
+#include "../../poly_commit_amd/host/ipa_pc.hpp"
 using namespace pc_host;
 
 template <class E>

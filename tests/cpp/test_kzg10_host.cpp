@@ -1,14 +1,14 @@
-// Host-layer tests for pc_host::KZG10 (poly-commit_amd/host/kzg10.hpp), written after the
+// Host-layer tests for pc_host::KZG10 (poly_commit_amd/host/kzg10.hpp), written after the
 // reference's own KZG10 tests (poly-commit/src/kzg10/mod.rs:519-674).  The reference checks
 // openings with a pairing; no pairing exists here, so `check` is replaced by the same equation
 // evaluated in G1 with the test's known trapdoor beta:
 //     C - v*g - v_bar*gamma_g  ==  (beta - z) * W          (kzg10/mod.rs:314-333)
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../poly-commit_amd/host/marlin_kzg10.hpp"
-#include "../../poly-commit_amd/host/linear_codes.hpp"
-#include "../../poly-commit_amd/host/ipa_pc.hpp"
-#include "../../poly-commit_amd/host/hyrax.hpp"
+#include "../../poly_commit_amd/host/marlin_kzg10.hpp"
+#include "../../poly_commit_amd/host/linear_codes.hpp"
+#include "../../poly_commit_amd/host/ipa_pc.hpp"
+#include "../../poly_commit_amd/host/hyrax.hpp"
 
 using namespace pc_host;
 

@@ -1,17 +1,17 @@
 // TEST-ONLY single-threaded stepping backend for the MSM orchestration in
-// poly-commit_amd/csrc/msm.hpp.  It runs every kernel body as a plain loop over the lane
+// poly_commit_amd/csrc/msm.hpp.  It runs every kernel body as a plain loop over the lane
 // index so that the indexing logic (chunking, partial lists, reduction levels, host tail)
 // can be validated against the oracle on a machine without a GPU.  It is NOT part of the
 // product library (libpc_hip.so is built from csrc/ only and instantiates HipBackend only).
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../../poly-commit_amd/csrc/msm.hpp"
-#include "../../poly-commit_amd/csrc/poly.hpp"
-#include "../../poly-commit_amd/csrc/ipa.hpp"
-#include "../../poly-commit_amd/csrc/hash.hpp"
-#include "../../poly-commit_amd/csrc/glv.hpp"
-#include "../../poly-commit_amd/csrc/serialize.hpp"
+#include "../../poly_commit_amd/csrc/msm.hpp"
+#include "../../poly_commit_amd/csrc/poly.hpp"
+#include "../../poly_commit_amd/csrc/ipa.hpp"
+#include "../../poly_commit_amd/csrc/hash.hpp"
+#include "../../poly_commit_amd/csrc/glv.hpp"
+#include "../../poly_commit_amd/csrc/serialize.hpp"
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }

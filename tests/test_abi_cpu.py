@@ -105,7 +105,7 @@ def test_header_is_plain_c99_and_links(tmp_path):
                    ",\n".join(f"    (const void*)(size_t)&{n}" for n in names) +
                    "\n  };\n  printf(\"%d\\n\", (int)(sizeof fns / sizeof fns[0]));\n  return 0;\n}\n")
     exe = tmp_path / "abi"
-    libdir = os.path.join(root, "poly-commit_amd")
+    libdir = os.path.join(root, "poly_commit_amd")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", str(exe),
                            "-L" + libdir, "-lpc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)

@@ -24,7 +24,7 @@ def emu():
     if _emu is None:
         so = os.path.join(HERE, "emu", "libemu.so")
         srcs = [os.path.join(HERE, "emu", "emu_msm.cpp")] + [
-            os.path.join(HERE, "..", "poly-commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp", "ipa.hpp", "glv.hpp", "serialize.hpp")]
+            os.path.join(HERE, "..", "poly_commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp", "ipa.hpp", "glv.hpp", "serialize.hpp")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
         _emu = C.CDLL(so)

@@ -1,4 +1,4 @@
-"""C++ host mirror of KZG10 (poly-commit_amd/host/kzg10.hpp): the test binary
+"""C++ host mirror of KZG10 (poly_commit_amd/host/kzg10.hpp): the test binary
 tests/cpp/test_kzg10_host.cpp restates the reference's kzg10 tests
 (add_commitments_test, end_to_end_test, test_degree_is_too_large, kzg10/mod.rs:519-674)."""
 import os
@@ -11,7 +11,7 @@ BIN = os.path.join(ROOT, "tests", "cpp", "test_kzg10_host")
 
 
 def build():
-    libdir = os.path.join(ROOT, "poly-commit_amd")
+    libdir = os.path.join(ROOT, "poly_commit_amd")
     if not os.path.exists(os.path.join(libdir, "libpc_hip.so")):
         import importlib
         importlib.import_module("poly_commit_amd.build").build()
@@ -47,7 +47,7 @@ def test_kzg10_host_layer_like_reference_tests():
 def test_host_blake2s_rfc7693_vector():
     """CPU: the host mirror's Blake2s (host/transcript.hpp, the digest of the IPA transcript) against RFC 7693
     appendix B -- the driver checks it before it touches a device."""
-    libdir = os.path.join(ROOT, "poly-commit_amd")
+    libdir = os.path.join(ROOT, "poly_commit_amd")
     if not os.path.exists(os.path.join(libdir, "libpc_hip.so")):
         import importlib
         importlib.import_module("poly_commit_amd.build").build()
@@ -61,7 +61,7 @@ def test_host_blake2s_rfc7693_vector():
 def test_hyrax_and_general_ipa_host_mirrors_compile():
     """CPU: host/hyrax.hpp (HyraxPC commit / open / check) and the general IPA entry points of host/ipa_pc.hpp (hiding,
     degree bounds) compile and link against the library; the drivers built here are the ones the -m gpu tests run."""
-    libdir = os.path.join(ROOT, "poly-commit_amd")
+    libdir = os.path.join(ROOT, "poly_commit_amd")
     if not os.path.exists(os.path.join(libdir, "libpc_hip.so")):
         import importlib
         importlib.import_module("poly_commit_amd.build").build()

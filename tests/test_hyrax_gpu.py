@@ -1,4 +1,4 @@
-"""GPU parity for HyraxPC (poly-commit/src/hyrax/mod.rs) through poly-commit_amd/hyrax.py: the row commitments (one
+"""GPU parity for HyraxPC (poly-commit/src/hyrax/mod.rs) through poly_commit_amd/hyrax.py: the row commitments (one
 pc_hip_msm_many pass), the opening proof and the verifier against the Python big-int restatement in oracle/pyref.py,
 bit for bit; at the 2^20-evaluation size (1024 rows of 1024 pairs) through the verifier's equations and sampled rows."""
 import numpy as np
@@ -92,7 +92,7 @@ def test_hyrax_2p20_evaluations_bn254(ctx):
 
 @pytest.mark.parametrize("curve,n_vars", [("bn254", 8), ("pallas", 6), ("bls12_381", 4)])
 def test_hyrax_cpp_host_mirror(curve, n_vars, tmp_path):
-    """The same through the C++ host mirror (poly-commit_amd/host/hyrax.hpp): what the Rust shim would do, in the
+    """The same through the C++ host mirror (poly_commit_amd/host/hyrax.hpp): what the Rust shim would do, in the
     language that builds here.  The driver also runs the mirror's `check` (honest / altered / malformed inputs)."""
     import os
     import struct
@@ -102,7 +102,7 @@ def test_hyrax_cpp_host_mirror(curve, n_vars, tmp_path):
     key_i, h_i = O.array_to_points(curve, pts[:dim]), O.array_to_points(curve, pts[dim:dim + 1])[0]
     want_rows, mat_i = R.hyrax_commit(curve, key_i, h_i, evals, rands)
     want_proof, want_eval = R.hyrax_open(curve, key_i, h_i, mat_i, rands, point, rnd[0], rnd[1:1 + dim], rnd[1 + dim], rnd[2 + dim], c)
-    libdir = os.path.join(root, "poly-commit_amd")
+    libdir = os.path.join(root, "poly_commit_amd")
     exe = os.path.join(root, "tests", "cpp", "hyrax_driver")
     src = exe + ".cpp"
     deps = [src, os.path.join(libdir, "libpc_hip.so")] + [os.path.join(libdir, "host", f) for f in os.listdir(os.path.join(libdir, "host"))]

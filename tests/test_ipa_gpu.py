@@ -90,7 +90,7 @@ def test_ipa_open_whole_proof_python_host(ctx, curve, n):
 def test_ipa_device_proof_passes_reference_check(ctx, curve, n):
     """A proof made on the device satisfies the reference's verifier equations: InnerProductArgPC::check restated in
     Python big ints (oracle/pyref.py, independent of the prover's code paths) and the device-side check of
-    poly-commit_amd/ipa.py (succinct check on the host, the verifier's final-key MSM -- ipa_pc/mod.rs:759-765 -- on the
+    poly_commit_amd/ipa.py (succinct check on the host, the verifier's final-key MSM -- ipa_pc/mod.rs:759-765 -- on the
     GPU) both accept it, and both reject it once c, the claimed value or final_comm_key is altered."""
     import torch
     from poly_commit_amd import ipa
@@ -119,7 +119,7 @@ def test_ipa_device_proof_passes_reference_check(ctx, curve, n):
 
 @pytest.mark.parametrize("curve,n", [("pallas", 64), ("bn254", 16), ("bls12_381", 8)])
 def test_ipa_hiding_and_degree_bounds_device(ctx, curve, n):
-    """InnerProductArgPC with hiding and degree bounds through poly-commit_amd/ipa.py (commitments with the hiding term and
+    """InnerProductArgPC with hiding and degree bounds through poly_commit_amd/ipa.py (commitments with the hiding term and
     the shifted key, the combination with shifted polynomials, the hiding polynomial of open, the verifier's combination):
     bit for bit against the restatement in oracle/pyref.py, then through both verifiers."""
     import torch
@@ -161,7 +161,7 @@ def test_ipa_open_whole_proof_cpp_host_mirror(curve, n, tmp_path):
     """The same through the C++ host mirror (host/ipa_pc.hpp: InnerProductArgPC::open, host/transcript.hpp):
     what the Rust shim would do, in the language that builds here."""
     comm_key, h, polys, comms, xi, point = _open_inputs(curve, n)
-    libdir = os.path.join(ROOT, "poly-commit_amd")
+    libdir = os.path.join(ROOT, "poly_commit_amd")
     exe = os.path.join(ROOT, "tests", "cpp", "ipa_open_driver")
     src = exe + ".cpp"
     deps = [src, os.path.join(libdir, "libpc_hip.so")] + [os.path.join(libdir, "host", f) for f in os.listdir(os.path.join(libdir, "host"))]
@@ -193,7 +193,7 @@ def test_ipa_hiding_and_degree_bounds_cpp_host_mirror(curve, n, tmp_path):
     from test_oracle_cpu import _ipa_general_case
     key, h, s, polys_i, ch_i, point_i, hp_i, hr_i = _ipa_general_case(curve, n)
     want = R.ipa_open_general(curve, key, h, s, polys_i, point_i, ch_i, hp_i, hr_i)
-    libdir = os.path.join(ROOT, "poly-commit_amd")
+    libdir = os.path.join(ROOT, "poly_commit_amd")
     exe = os.path.join(ROOT, "tests", "cpp", "ipa_general_driver")
     src = exe + ".cpp"
     deps = [src, os.path.join(libdir, "libpc_hip.so")] + [os.path.join(libdir, "host", f) for f in os.listdir(os.path.join(libdir, "host"))]

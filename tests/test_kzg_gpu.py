@@ -116,7 +116,7 @@ def test_true_srs_end_to_end_trapdoor_check(ctx, curve, d):
 
 
 def test_sharded_engine_world1_matches_oracle(ctx):
-    """poly-commit_amd/sharded.py with the HIP engine (device-resident buffers, async pipelines)
+    """poly_commit_amd/sharded.py with the HIP engine (device-resident buffers, async pipelines)
     on one rank: same commitment / proof as the oracle."""
     import torch
     from poly_commit_amd import sharded

@@ -1,4 +1,4 @@
-"""GPU parity for LinearCodePCS (univariate Ligero) commit / open / check through poly-commit_amd/ligero.py against the
+"""GPU parity for LinearCodePCS (univariate Ligero) commit / open / check through poly_commit_amd/ligero.py against the
 Python restatement in oracle/pyref.py: commitment (root, shape), opening proof (v, queried columns, Merkle paths,
 well-formedness vector) bit for bit; then both verifiers on honest and altered proofs."""
 import numpy as np

@@ -1,5 +1,5 @@
 """CPU suite, part 4: the multi-GPU path (SRS / coefficient sharding with an all_gather of
-partial points and a one-element division carry, poly-commit_amd/sharded.py) run as a real
+partial points and a one-element division carry, poly_commit_amd/sharded.py) run as a real
 multi-process torch.distributed job on the gloo backend, world_size 2 and 3."""
 import os
 import subprocess

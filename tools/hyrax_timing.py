@@ -1,4 +1,4 @@
-"""Time HyraxPC commit / open / check through poly-commit_amd/hyrax.py on one GPU (bn254, 2^n evaluations).
+"""Time HyraxPC commit / open / check through poly_commit_amd/hyrax.py on one GPU (bn254, 2^n evaluations).
 Prints one JSON line per size.  Inputs are generated with the oracle's generators; nothing is checked here
 (tests/test_hyrax_gpu.py does that)."""
 import json

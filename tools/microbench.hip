@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <vector>
-#include "../poly-commit_amd/csrc/ec.hpp"
+#include "../poly_commit_amd/csrc/ec.hpp"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
