@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- KZG commit+open hot path on MI355X (BASELINE.json configs[1]).
+"""bench.py -- the commit/open hot path of arkworks-rs/poly-commit on MI355X (BASELINE.json).
 
-One step = one MarlinKZG10<Bls12_381> commit + one single-point open of one dense
-polynomial of degree 2^24 per GPU (primary; the 2^20 case BASELINE.json also names is reported in the
-`secondary` block of the same JSON line), hiding off (the shape bench-templates times,
-bench-templates/src/lib.rs:69-84,106-138):
+`value` (the driver's line): one step = one MarlinKZG10<Bls12_381> commit + one single-point open of one dense
+polynomial of degree 2^24 per GPU, hiding off -- the shape bench-templates times (bench-templates/src/lib.rs:69-84,
+106-138):
     commit : MSM of d+1 pairs over the resident SRS           (kzg10/mod.rs:175-178)
     open   : witness polynomial p/(x-z) on the device          (kzg10/mod.rs:217-240)
              MSM of d pairs                                    (kzg10/mod.rs:255-258)
-SRS, coefficients and the evaluation point's quotient stay in HBM; only the two 96-byte
-affine results come back to the host.  value = G1 (base, scalar) pairs per second, whole job.
+SRS, coefficients and the quotient stay in HBM; only the two 96-byte affine results come back.  value = G1 (base,
+scalar) pairs per second, whole job.  The same JSON line carries, timed in the same run:
+    secondary            the 2^20 case (BASELINE configs[1])
+    trait_shaped         the same commit+open through BLOCKING calls with HOST coefficients (what the trait's
+                         commit(&poly)/open(&poly) hands over) at 2^24 and 2^20
+    workloads.latency    blocking commit+open latency 2^10 .. 2^24 beside the CPU port (configs[0] = 2^12; crossover)
+    workloads.batch      configs[2]: 64 x MarlinKZG10<Bn254> commits of degree 2^20
+    workloads.ipa        configs[3]: InnerProductArgPC over Pallas, n = 2^22: commit + open
+    workloads.ligero     configs[4]: Ligero over BLS12-381 Fr, 2^24 coefficients: 512 NTTs of 2^17 + digests + tree
+    roofline, cpu_baseline, parity
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ONE polynomial of degree
-N*2^24 whose SRS and coefficients are sharded in contiguous chunks (weak scaling: fixed pairs
-per GPU); each rank runs the full Pippenger on its chunk and the partial commitments /
-opening proofs are combined with an all_gather + EC adds (RCCL has no EC reduce op); the
-division carry crosses ranks as one Fr element.  See poly_commit_amd/sharded.py.
+Every workload runs on a TRUE structured reference string beta^i g generated on the device, so that its results are
+checked in-line against closed forms (C = p(beta) g, W = q(beta) g -- the verifier's pairing equation with the
+trapdoor known) evaluated by the CPU oracle: `parity` in the line says what was compared.
+
+N > 1 (`--gpus N`: this script launches its own ranks with torch.distributed.run when WORLD_SIZE is not set; the
+driver's torchrun invocation works as well): ONE polynomial of degree N * 2^24 whose SRS and coefficients are sharded
+in contiguous chunks (weak scaling: fixed pairs per GPU); each rank runs the full Pippenger on its chunk of the SAME
+true SRS and the partial commitments / proofs are combined with one all_gather + EC adds per step (RCCL has no EC
+reduce op); the division carry crosses ranks as one Fr element.  See poly_commit_amd/sharded.py.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -36,7 +48,6 @@ import numpy as np  # noqa: E402
 _RESULT_FD = os.dup(1)
 os.dup2(2, 1)
 
-
 # The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The MSM
 # pipelines keep seven streams busy; once RCCL adds its own, independent streams share a queue and serialise
 # (measured with one rank: 76.2 ms/step at 4 queues, 72.5 at 8 = the figure without RCCL).  Must be set before HIP
@@ -49,8 +60,187 @@ def emit(obj):
     os.write(_RESULT_FD, (json.dumps(obj) + "\n").encode())
 
 
-PAIR_BYTES = {"bls12_381": 128, "bn254": 96, "pallas": 96}   # affine base + 32-byte scalar
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+PAIR_BYTES = {"bls12_381": 128, "bn254": 96, "pallas": 96}   # affine base + 32-byte scalar (SURVEY.md 8d)
 HBM_PEAK_GBPS = 8000.0                                        # MI355X_MICROARCH.md: 8 TB/s spec
+FR_BITS = {"bls12_381": 255, "bn254": 254, "pallas": 255}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# launching: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own ranks
+# ------------------------------------------------------------------------------------------------------------
+def self_launch(n_gpus, argv):
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("launching", " ".join(cmd))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if line is not None:
+        os.write(_RESULT_FD, (line + "\n").encode())
+    sys.exit(proc.returncode if proc.returncode else (0 if line is not None else 1))
+
+
+class Dist:
+    """World of this run: torch.distributed on RCCL ('nccl') -- or gloo when several ranks share one GPU
+    (PC_BENCH_DEVICES=0,0: RCCL refuses two ranks on one device; used by the GPU test on a one-GPU box)."""
+
+    def __init__(self, args):
+        import torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        devs = os.environ.get("PC_BENCH_DEVICES")
+        self.device = int(devs.split(",")[self.local_rank]) if devs else self.local_rank
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if self.device >= torch.cuda.device_count():
+            raise SystemExit(f"rank {self.rank}: device {self.device} requested, {torch.cuda.device_count()} visible "
+                             "(PC_BENCH_DEVICES=0,0,... maps ranks onto fewer GPUs)")
+        torch.cuda.set_device(self.device)
+        self.dist = None
+        self.backend = None
+        if self.world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
+            import torch.distributed as dist
+            shared = devs is not None and len(set(devs.split(","))) < len(devs.split(","))
+            self.backend = args.backend or ("gloo" if shared else "nccl")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            else:
+                dist.init_process_group("gloo")
+            self.dist = dist
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gather_floats(self, vals):
+        """list of floats -> (world, len) array on every rank."""
+        import torch
+        v = np.asarray(vals, dtype=np.float64).reshape(-1)
+        if self.dist is None:
+            return v.reshape(1, -1)
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.from_numpy(v.copy()).to(dev)
+        out = torch.empty(self.world * t.numel(), dtype=torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().reshape(self.world, -1)
+
+    def gather_u64(self, arr):
+        from poly_commit_amd import sharded
+        return sharded.all_gather_u64(self.dist, self.world, arr)
+
+    def info(self):
+        if self.dist is None:
+            return None
+        return {"backend": self.backend + (" (RCCL)" if self.backend == "nccl" else ""), "world_size": self.dist.get_world_size(),
+                "devices": os.environ.get("PC_BENCH_DEVICES") or "one GPU per rank"}
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# synthetic inputs, generated on the device
+# ------------------------------------------------------------------------------------------------------------
+def fr_modulus(curve):
+    from poly_commit_amd import sharded
+    return sharded.FR_MODULUS[curve]
+
+
+def mont_limbs(curve, v):
+    """Python int -> Montgomery-form Fr, (4,) uint64."""
+    p = fr_modulus(curve)
+    return np.frombuffer(((v % p) * (1 << 256) % p).to_bytes(32, "little"), dtype="<u8").astype(np.uint64)
+
+
+def from_mont_limbs(curve, limbs):
+    p = fr_modulus(curve)
+    v = int.from_bytes(np.ascontiguousarray(limbs, dtype="<u8").tobytes(), "little")
+    return v * pow(1 << 256, -1, p) % p
+
+
+def seed_fr(curve, seed):
+    """One reproducible field element as a Python int (the oracle's SplitMix64 stream)."""
+    import oracle_lib as O
+    return int.from_bytes(O.gen_scalars(curve, seed, 1).tobytes(), "little") % fr_modulus(curve)
+
+
+def rand_fr_device(seed, n):
+    """n field elements in their in-memory (Montgomery) form, uniformly below 2^252 < r for all three scalar fields:
+    what DensePolynomial::rand's coefficients look like in memory (marlin_pc/mod.rs:550-556), without 2^24 CPU draws."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    t[:, 3] &= (1 << 60) - 1
+    return t
+
+
+def host_u64(t):
+    """device / host int64 tensor -> contiguous uint64 numpy array."""
+    return np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
+
+
+def true_srs_points(ctx, curve, g_xy, beta, first_power, count):
+    """beta^(first_power + j) * g for j < count as a device tensor: KZG10::setup's `g.batch_mul(&powers_of_beta)`
+    (kzg10/mod.rs:68-83) through pc_hip_fr_powers / pc_hip_fr_lincomb / pc_hip_fixed_base_batch_mul."""
+    import torch
+    p = fr_modulus(curve)
+    pw = torch.empty((count, 4), dtype=torch.int64, device="cuda")
+    ctx.fr_powers(curve, mont_limbs(curve, beta), count, pw.data_ptr())
+    if first_power != 0:
+        lead = pow(beta, first_power, p) if first_power > 0 else pow(pow(beta, -1, p), -first_power, p)
+        sc = torch.empty_like(pw)
+        ctx.fr_lincomb(curve, [pw.data_ptr()], mont_limbs(curve, lead).reshape(1, 4), n_out=count, out=sc.data_ptr(), lens=[count])
+        pw = sc
+    fq_limbs = 6 if curve == "bls12_381" else 4
+    pts = torch.empty((count, 2 * fq_limbs), dtype=torch.int64, device="cuda")
+    ctx.fixed_base_batch_mul(curve, g_xy, pw.data_ptr(), count, pts.data_ptr())
+    torch.cuda.synchronize()
+    return pts
+
+
+def oracle_scalar_mul(curve, g_xy, k):
+    """k * g on the CPU oracle (one double-and-add): the closed forms the device results are compared with."""
+    import oracle_lib as O
+    p = fr_modulus(curve)
+    sc = np.frombuffer((k % p).to_bytes(32, "little"), dtype="<u8").astype(np.uint64).reshape(1, 4)
+    return O.msm_naive(curve, np.ascontiguousarray(g_xy).reshape(1, -1), np.ascontiguousarray(sc))
+
+
+def union_ms(intervals):
+    """Total length of the union of [a, b] intervals."""
+    tot, end = 0.0, -1e30
+    for a, b in sorted(intervals):
+        if b <= end:
+            continue
+        tot += b - max(a, end)
+        end = b
+    return tot
 
 
 _MADD_PEAK = {}
@@ -80,263 +270,157 @@ def madd_peak(curve):
     return res
 
 
-def cpu_baseline(curve, log_d, budget_s=15.0):
-    """CPU restatement of ark-ec's Pippenger (oracle/, 'port'), timed on this box's cores on a
-    bounded sample: the largest power-of-two MSM that fits the time budget."""
+def cpu_baseline(curve, srs, log_d, budget_s=30.0):
+    """The CPU port (oracle/: restated ark-ec signed-digit Pippenger) timed on this box's cores on a bounded sample of
+    the same workload: one MSM over the leading 2^k points of the resident SRS, k as large as fits the budget
+    (k = log_d when the box is fast enough)."""
     import oracle_lib as O
     cores = os.cpu_count() or 1
-    n0 = 1 << 14
-    b = O.gen_bases(curve, n0)
+    n0 = 1 << min(16, log_d)
+    b = srs.read(1, n0)
     s = O.gen_scalars(curve, 1, n0)
-    t = time.time()
+    t = time.perf_counter()
     O.msm_pippenger(curve, b, s, cores, 1)
-    rate = n0 / max(time.time() - t, 1e-6)
-    lg = 14
-    while lg < log_d and (1 << (lg + 1)) / rate < budget_s:
+    rate = n0 / max(time.perf_counter() - t, 1e-6)
+    lg = min(16, log_d)
+    while lg < log_d and (1 << (lg + 1)) / rate * 2.2 < budget_s:      # both schedules are tried
         lg += 1
     n = 1 << lg
-    b = O.gen_bases(curve, n)
+    b = srs.read(1, n)
     s = O.gen_scalars(curve, 2, n)
     best = None
     for mode in (1, 0):   # chunk-parallel and window-parallel schedules; keep the faster
-        t = time.time()
+        t = time.perf_counter()
         O.msm_pippenger(curve, b, s, cores, mode)
-        dt = time.time() - t
+        dt = time.perf_counter() - t
         best = dt if best is None else min(best, dt)
-        if dt > budget_s:
+        if dt > budget_s / 2:
             break
     return {"value": n / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs, restated ark-ec signed-digit Pippenger "
-                      f"(oracle/oracle.cpp), best of chunk-/window-parallel, {cores} threads"}
+            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs (the leading points of the same true SRS), restated ark-ec signed-digit "
+                      f"Pippenger (oracle/oracle.cpp), best of chunk-/window-parallel, {cores} threads",
+            "note": "context only: the port's rate swings 2.5x between boxes of the pool; never credit"}
 
 
-def bench_ntt(args):
-    """BASELINE configs[4]: LigeroPCS over BLS12-381 Fr, 2^24 coefficients, rho_inv = 4 ->
-    512 x 32768 matrix -> 512 forward NTTs of size 2^17 (linear_codes/mod.rs:118-138)."""
-    import torch
-    import oracle_lib as O
-    import poly_commit_amd as pc
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    curve = args.curve
-    poly_len = 1 << 24
-    n_rows, n_cols, _ = O.ligero_dims(255 if curve != "bn254" else 254, poly_len, 4)
-    log_n = (n_cols * 4 - 1).bit_length()
-    from poly_commit_amd import sharded
-    ctx = pc.Context(local_rank)
-    ctx.set_timing(True)
-    shard = sharded.ShardedRows(sharded.HipEngine(ctx, curve), rank, world)   # rows are independent: shard by rows, no collective
-    r_lo, r_hi = shard.row_range(n_rows)
-    rows = r_hi - r_lo
-    co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0500 + rank, rows * n_cols))
-    x = torch.from_numpy(co.view(np.int64)).cuda()
-    y = torch.empty((rows << log_n, 4), dtype=torch.int64, device="cuda")
-    # the step after the encoding in LinearCodePCS::commit (linear_codes/mod.rs:256-263): column digests
-    leaves = torch.empty((1 << log_n, 32), dtype=torch.uint8, device="cuda")
-    hash_ms = merkle_ms = None
-    if world == 1:
-        ctx.column_hash(curve, y.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=rows, n_cols=1 << log_n)
-        torch.cuda.synchronize()
+# ------------------------------------------------------------------------------------------------------------
+# KZG commit + open (configs[1], north star)
+# ------------------------------------------------------------------------------------------------------------
+class KzgSetup:
+    """One rank's resident state for a sharded KZG job on the TRUE SRS beta^i g: chunk r holds powers
+    [r n - 1, (r+1) n) (one below its coefficients, so that commit and open address the same resident chunk)."""
+
+    def __init__(self, ctx, D, args, curve, n, seed):
+        import torch
+        import oracle_lib as O
+        from poly_commit_amd import sharded
+        self.ctx, self.D, self.curve, self.n = ctx, D, curve, n
+        self.p = fr_modulus(curve)
+        self.g = O.gen_bases(curve, 1)[0]
+        self.beta = seed_fr(curve, 0xBE7A24)
+        self.z = seed_fr(curve, 0x2EE7)
+        self.eng = sharded.HipEngine(ctx, curve)
+        self.job = sharded.ShardedKzg(self.eng, curve, D.rank, D.world, D.dist)
         t0 = time.perf_counter()
-        for _ in range(3):
-            ctx.column_hash(curve, y.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=rows, n_cols=1 << log_n)
+        pts = true_srs_points(ctx, curve, self.g, self.beta, D.rank * n - 1, n + 1)
+        self.srs_gen_ms = (time.perf_counter() - t0) * 1e3
+        self.job.load_srs_chunk(pts.data_ptr(), precompute=bool(args.precompute), n=n + 1)
+        del pts
+        self.coeffs = rand_fr_device(seed + D.rank, n)
+        self.job.set_point(mont_limbs(curve, self.z))
         torch.cuda.synchronize()
-        hash_ms = (time.perf_counter() - t0) / 3 * 1e3
-        # ... and the Merkle tree over them (create_merkle_tree, linear_codes/mod.rs:506-521)
-        nodes = torch.empty(((1 << log_n) - 1, 32), dtype=torch.uint8, device="cuda")
-        ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=1 << log_n)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=1 << log_n)
-        torch.cuda.synchronize()
-        merkle_ms = (time.perf_counter() - t0) / 3 * 1e3
-    torch.cuda.synchronize()
-    ph = np.zeros(2)
-    for _ in range(args.warmup):
-        shard.encode(x, rows, n_cols, log_n, y)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        shard.encode(x, rows, n_cols, log_n, y)
-        ph += np.array(ctx.last_ntt_phases_ms())
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ph /= args.steps
-    alg_bytes = rows * (n_cols + (1 << log_n)) * 32
-    kern_ms = float(ph.sum())
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-    if rank == 0:
-        emit(({
-            "metric": "Ligero Reed-Solomon NTT input coefficients/sec (LigeroPCS over BLS12-381 Fr, 2^24 coeffs)",
-            "value": world * rows * n_cols * args.steps / dt, "unit": "coeffs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u32 limbs (255-bit Fr modular integer)", "data": "synthetic",
-            "config": {"workload": f"{n_rows} x {n_cols} matrix, {n_rows} forward NTTs of size 2^{log_n} (BASELINE configs[4])",
-                       "parallelism": "1 GPU" if world == 1 else f"rows sharded over {world} GPUs, no collective"},
-            "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
-            "column_hash_blake2s_ms": hash_ms,   # not part of `value`: the next steps of the commit, device-resident
-            "merkle_tree_sha256_ms": merkle_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
-                         "kernel": "k_ntt_pass_a + k_ntt_pass_b (one batched NTT = both)",
-                         "algorithmic_bytes_per_launch": alg_bytes}}))
-    if dist is not None:
-        dist.destroy_process_group()
+
+    def closed_forms(self):
+        """(commitment, proof) of the WHOLE polynomial from oracle evaluations of every rank's shard:
+        C = p(beta) g, W = ((p(beta) - p(z)) / (beta - z)) g."""
+        import oracle_lib as O
+        host = host_u64(self.coeffs)
+        ev = np.concatenate([O.poly_eval(self.curve, host, mont_limbs(self.curve, self.beta)),
+                             O.poly_eval(self.curve, host, mont_limbs(self.curve, self.z))])
+        # the device's own evaluation must agree with the oracle's Horner
+        dev_z = self.ctx.poly_eval(self.curve, self.coeffs.data_ptr(), mont_limbs(self.curve, self.z), n=self.n)
+        ok_eval = bool((dev_z == ev[4:]).all())
+        allv = self.D.gather_u64(ev)
+        p, n = self.p, self.n
+        pb = pz = 0
+        for r in range(self.D.world):
+            pb = (pb + pow(self.beta, r * n, p) * from_mont_limbs(self.curve, allv[r, :4])) % p
+            pz = (pz + pow(self.z, r * n, p) * from_mont_limbs(self.curve, allv[r, 4:])) % p
+        want_c = oracle_scalar_mul(self.curve, self.g, pb)
+        want_w = oracle_scalar_mul(self.curve, self.g, (pb - pz) * pow(self.beta - self.z, -1, p) % p)
+        return want_c, want_w, ok_eval
+
+    def free(self):
+        import torch
+        self.eng.srs.free()
+        del self.coeffs
+        torch.cuda.empty_cache()
 
 
-def bench_batch(args):
-    """BASELINE configs[2]: 64 polynomials of degree 2^20 over BN254 committed against ONE SRS
-    that is split into N contiguous chunks (one per GPU).  Every GPU runs the 64 partial MSMs of
-    its chunk as one pipelined batch (pc_hip_msm_batch); the 64 partial points per rank are
-    combined with one all_gather (64 x 64 B per rank) + EC adds.  Strong scaling: the job is
-    fixed (64 x (2^20 + 1) pairs), per-GPU work shrinks with N."""
-    import torch
-    import oracle_lib as O
-    import poly_commit_amd as pc
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    curve = "bn254" if args.curve == "bls12_381" else args.curve
-    from poly_commit_amd import sharded
-    total = (1 << args.log_degree) + 1
-    lo, hi = sharded.ShardedBatch.chunk_range(total, rank, world)
-    n = hi - lo
-    ctx = pc.Context(local_rank)
-    ctx.set_timing(True)
-    job = sharded.ShardedBatch(sharded.HipEngine(ctx, curve), curve, rank, world, dist)
-    job.load_srs_chunk(O.gen_bases(curve, n), precompute=bool(args.precompute))   # synthetic chunk (every rank the same points: throughput only)
-    polys = [torch.from_numpy(O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0100 + j, n)).view(np.int64)).cuda()
-             for j in range(args.polys)]
-    lens = [n] * args.polys
-    torch.cuda.synchronize()
-
-    def step():
-        return job.commit_batch(polys, lens)
-
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    if rank == 0:
-        pairs = args.polys * total
-        emit(({
-            "metric": "MSM G1-scalar-pairs/sec, batched MarlinKZG10<Bn254> commit (64 polys, deg 2^20, SRS sharded)",
-            "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32 limbs (254-bit modular integer)", "data": "synthetic",
-            "config": {"workload": f"{args.polys} x MarlinKZG10<{curve}> commit, deg 2^{args.log_degree}, one SRS in {world} "
-                                   f"contiguous chunk(s) (BASELINE configs[2])", "polys_per_s": args.polys * args.steps / dt,
-                       "parallelism": "1 GPU" if world == 1 else f"SRS sharded over {world} GPUs, all_gather of {args.polys} partial points"}}))
-    if dist is not None:
-        dist.destroy_process_group()
-
-
-def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, with_h2d):
-    """One KZG commit+open workload on this rank: timed legs + the post-region blocking MSMs.
-    Returns a dict (timings are this rank's; the caller takes the max over ranks)."""
+def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5EED0001):
+    """One KZG commit+open workload on this rank.  Returns a dict (timings are the max over ranks)."""
     import collections
-    import math
     import torch
-    import oracle_lib as O          # synthetic inputs only (never the measured path)
-    from poly_commit_amd import sharded
-
+    world, rank, dist = D.world, D.rank, D.dist
     d = 1 << log_degree
     n = d + 1 if world == 1 else d          # coefficients held by this rank
-    # ---- synthetic inputs (SURVEY.md 8d): bases (i+1)G, coefficients SplitMix64(seed) -------
-    eng = sharded.HipEngine(ctx, curve)
-    job = sharded.ShardedKzg(eng, curve, rank, world, dist)
-    bases = O.gen_bases(curve, n + 1)       # +1: the open of shard r > 0 reaches one base back
-    job.load_srs_chunk(bases, precompute=bool(args.precompute))
-    del bases
-    coeffs_h = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0001 + rank, n))
-    coeffs = torch.from_numpy(coeffs_h.view(np.int64)).cuda()
-    z_mont = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x2EE7, 1))[0]
-    job.set_point(z_mont)
-    torch.cuda.synchronize()
+    S = KzgSetup(ctx, D, args, curve, n, seed)
+    eng, job, coeffs = S.eng, S.job, S.coeffs
 
     depth = max(0, args.inflight)
     pending = collections.deque()
+    results = []                            # (kind, point) of everything that left the pipeline, in order
 
     def drain():
-        if dist is not None and pending and not os.environ.get("PC_DIAG_DIST_NO_EXCHANGE"):
-            job.exchange(None, 0, [pending.popleft() for _ in range(len(pending))])
+        if dist is not None and pending:
+            kinds = [k for k, _ in pending]
+            _, outs = job.exchange(None, 0, [f for _, f in pending])
+            pending.clear()
+            results.extend(zip(kinds, outs))
         while pending:
-            pending.popleft().result()
+            k, f = pending.popleft()
+            results.append((k, f.result()))
 
     def step_resident(_k):
-        # commit and open of one polynomial; up to `depth` results stay in flight so that the
-        # latency-bound tail of one MSM overlaps the bucket accumulation of the next
-        # (N > 1: the open's exchange step -- shard evaluation + all_gather of one Fr per rank -- runs first, while
-        # the previous step's MSMs are still in flight, so the blocking collective does not drain the pipelines)
-        if dist is not None and depth > 0 and not os.environ.get("PC_DIAG_DIST_NO_EXCHANGE"):
-            # N > 1, pipelined: ONE collective per step -- this step's shard evaluations (the division carries) travel
-            # with the partial points of the step that left the pipeline (ShardedKzg.exchange)
+        # commit and open of one polynomial; up to `depth` results stay in flight so that the latency-bound tail of one
+        # MSM overlaps the bucket accumulation of the next
+        if dist is not None and depth > 0:
+            # N > 1, pipelined: ONE collective per step -- this step's shard evaluations (the division carries) travel with
+            # the partial points of the step that left the pipeline (ShardedKzg.exchange), issued while the previous
+            # step's MSMs are still in flight
             done = [pending.popleft() for _ in range(max(0, len(pending) - 2 * (depth - 1)))]
-            carry, _results = job.exchange(coeffs, n, done)
-            pending.append(job.commit_async(coeffs, n))
-            pending.append(job.open_async(coeffs, n, prepared=True, carry=carry))
+            carry, outs = job.exchange(coeffs, n, [f for _, f in done])
+            results.extend(zip([k for k, _ in done], outs))
+            pending.append(("commit", job.commit_async(coeffs, n)))
+            pending.append(("open", job.open_async(coeffs, n, prepared=True, carry=carry)))
             return
         carry = job.open_prepare(coeffs, n)
-        pending.append(job.commit_async(coeffs, n))
+        pending.append(("commit", job.commit_async(coeffs, n)))
         if depth == 0:                       # strictly blocking calls: the commitment is back before the open starts
-            pending.popleft().result()
-        pending.append(job.open_async(coeffs, n, prepared=True, carry=carry))
+            k, f = pending.popleft()
+            results.append((k, f.result()))
+        pending.append(("open", job.open_async(coeffs, n, prepared=True, carry=carry)))
         while len(pending) > depth:
-            pending.popleft().result()
+            k, f = pending.popleft()
+            results.append((k, f.result()))
 
     def timed(step_fn, steps, warmup):
         for k in range(warmup):
             step_fn(k)
         drain()
-        eng.phases = []
-        if dist is not None:
-            dist.barrier()
+        eng.phases, eng.marks = [], []
+        results.clear()
+        D.barrier()
         torch.cuda.synchronize()
+        ctx.set_timing(True)                 # re-bases the absolute marks at the start of the timed region
         t0 = time.perf_counter()
         for k in range(warmup, warmup + steps):
             step_fn(k)
         drain()                              # every commitment and proof is on the host here
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        D.barrier()
         dt = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt, list(eng.phases)
+        per_rank = D.gather_floats([dt])[:, 0]
+        return float(per_rank.max()), [float(x) for x in per_rank], list(eng.phases), list(eng.marks)
 
     if steps is None and dist is not None:
         steps = 20          # every rank must run the same number of steps
@@ -346,15 +430,36 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
         torch.cuda.synchronize()
         est = time.perf_counter() - t0
         steps = max(10, int(math.ceil(1.2 / max(est, 1e-4))))
-    dt, phases = timed(step_resident, steps, warmup)
-    ph = np.mean(np.array(phases), axis=0) if phases else np.zeros(8)
+    dt, per_rank_dt, phases, marks = timed(step_resident, steps, warmup)
+    timed_results = list(results)
+
+    # accumulate launches of the timed region: [marks[3], marks[4]] of every MSM of this rank.  Launches of different
+    # pipelines overlap, so the per-launch duration the region sustains is the UNION of the intervals / launches
+    # (<= step time / 2 by construction); the plain average of the brackets is reported beside it.
+    acc_iv = [(m[3], m[4]) for m in marks if m is not None and m[3] >= 0 and m[4] >= m[3]]
+    acc_union_ms = union_ms(acc_iv) / max(1, len(acc_iv))
+    acc_bracket_ms = float(np.mean([b - a for a, b in acc_iv])) if acc_iv else 0.0
+
+    # ---- in-line parity: every commitment / proof of the timed region against the closed forms ---------------
+    want_c, want_w, ok_eval = S.closed_forms()
+    n_c = sum(1 for k, _ in timed_results if k == "commit")
+    n_w = sum(1 for k, _ in timed_results if k == "open")
+    ok_c = n_c == steps and all((pt == want_c).all() for k, pt in timed_results if k == "commit")
+    ok_w = n_w == steps and all((pt == want_w).all() for k, pt in timed_results if k == "open")
+    parity = {"commitments_checked": n_c, "proofs_checked": n_w, "commit_ok": bool(ok_c), "open_ok": bool(ok_w),
+              "device_poly_eval_ok": ok_eval,
+              "method": "true SRS beta^i g built on the device; every commitment / proof of the timed region == p(beta) g / "
+                        "((p(beta) - p(z)) / (beta - z)) g, with p(beta), p(z) from the CPU oracle's Horner over every rank's "
+                        "shard and the scalar multiplication of g by the oracle (the verifier's pairing equation, "
+                        "kzg10/mod.rs:314-333, with the trapdoor known)"}
 
     # ---- the same steps with the coefficients handed over as HOST memory (what the Rust shim holds):
-    # one pinned H2D copy per polynomial (commit and open share it), double-buffered so that the copy of
+    # one pinned H2D copy per polynomial (commit and open share it), triple-buffered so that the copy of
     # step k+1 overlaps the MSMs of step k.  Reported beside `value`, never as `value`.
     h2d = None
+    host = None
     if with_h2d and world == 1:
-        host = torch.from_numpy(coeffs_h.view(np.int64)).pin_memory()
+        host = coeffs.cpu().pin_memory()
         bufs = [torch.empty_like(coeffs) for _ in range(3)]
         cs = torch.cuda.Stream()
         evs = [torch.cuda.Event() for _ in range(3)]
@@ -371,25 +476,57 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
                 issue_copy(k); started.add(k)
             issue_copy(k + 1); started.add(k + 1)     # its buffer was last read by step k-2, drained by now
             evs[k % 3].synchronize()
-            pending.append(job.commit_async(bufs[k % 3], n))
+            pending.append(("commit", job.commit_async(bufs[k % 3], n)))
             if depth == 0:
-                pending.popleft().result()
-            pending.append(job.open_async(bufs[k % 3], n))
+                kk, f = pending.popleft(); results.append((kk, f.result()))
+            pending.append(("open", job.open_async(bufs[k % 3], n)))
             while len(pending) > min(depth, 2):
-                pending.popleft().result()
+                kk, f = pending.popleft(); results.append((kk, f.result()))
 
-        dt_h, _ = timed(step_h2d, steps, warmup)
+        dt_h, _, _, _ = timed(step_h2d, steps, warmup)
         torch.cuda.synchronize()
         h2d = {"ms_per_step": dt_h / steps * 1e3, "value": (2 * n - 1) * steps / dt_h, "unit": "pairs/s",
                "note": "coefficients start in pinned HOST memory every step: one H2D copy of the polynomial per "
                        "commit+open (32 B/coefficient), triple-buffered on its own stream so it overlaps the previous "
                        "step's MSMs (SURVEY.md 8d: scalars H2D included)"}
-        del bufs, host
+        del bufs
 
-    # The kernels without a second pipeline competing for the CUs: strictly serial MSMs after the
-    # timed region.  msm_phase_ms and roofline.serial come from these (they agree with rocprofv3's
-    # per-kernel averages); the timed-region brackets include queueing behind the other pipeline.
-    eng.phases = []
+    # ---- trait-shaped: what a PolynomialCommitment::commit(&poly) / open(&poly) caller gets -- blocking calls, the
+    # coefficients in (pageable) host memory at every call, nothing kept on the device in between:
+    #   commit = pc_hip_msm(PC_MEM_HOST, MONTGOMERY)                             (kzg10/mod.rs:157-210)
+    #   open   = pc_hip_witness_poly(host -> device) + pc_hip_msm(PC_MEM_DEVICE) (kzg10/mod.rs:287-310)
+    trait = None
+    if world == 1:
+        hostc = host_u64(host if host is not None else coeffs)
+        qdev = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        zm = mont_limbs(curve, S.z)
+        reps = 3 if log_degree >= 22 else 10
+
+        def trait_step():
+            c, _ = eng.srs.msm(hostc, n=n, base_offset=1, montgomery=True)
+            ctx.witness_poly(curve, hostc, zm, out=qdev.data_ptr(), n=n)
+            w, _ = eng.srs.msm(qdev, n=n - 1, base_offset=1, montgomery=True)
+            return c, w
+        c, w = trait_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            trait_step()
+        dt_t = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):                 # the commit alone
+            eng.srs.msm(hostc, n=n, base_offset=1, montgomery=True)
+        dt_c = (time.perf_counter() - t0) / reps
+        trait = {"ms_per_commit_open": dt_t * 1e3, "commit_ms": dt_c * 1e3, "open_ms": (dt_t - dt_c) * 1e3,
+                 "commit_open_per_s": 1.0 / dt_t, "value": (2 * n - 1) / dt_t, "unit": "pairs/s",
+                 "parity_ok": bool((c == want_c).all() and (w == want_w).all()),
+                 "note": "blocking pc_hip_msm with PC_MEM_HOST coefficients (pageable numpy memory, one H2D inside the call), "
+                         "then pc_hip_witness_poly host -> device + blocking pc_hip_msm: the call sequence of the trait's "
+                         "commit(&poly) / open(&poly) with nothing cached between them"}
+        del qdev
+
+    # The kernels without a second pipeline competing for the CUs: strictly serial MSMs after the timed region.
+    eng.phases, eng.marks = [], []
     for _ in range(3):
         job.commit_async(coeffs, n).result()
     sp = np.mean(np.array(eng.phases), axis=0) if eng.phases else np.zeros(8)
@@ -398,89 +535,349 @@ def kzg_case(ctx, args, curve, log_degree, steps, warmup, world, rank, dist, wit
         job.commit_async(coeffs, n).result()
     blocking_msm_ms = (time.perf_counter() - t0) / 3 * 1e3
 
-    pairs_per_step = world * (2 * n - 1) if world == 1 else world * (2 * n) - 1
-    acc_ms, acc_serial_ms = float(ph[3]), float(sp[3])
-    pairs_per_launch = (2 * n - 1) / 2.0
-    bytes_per_launch = pairs_per_launch * PAIR_BYTES[curve]
-    achieved = bytes_per_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+    pairs_per_step = (2 * n - 1) if world == 1 else world * (2 * n) - 1
+    acc_serial_ms = float(sp[3])
+    launch_pairs = (2 * n - 1) / 2.0 if world == 1 else n - 0.5 / world
+    bytes_per_launch = launch_pairs * PAIR_BYTES[curve]
+    achieved = bytes_per_launch / (acc_union_ms * 1e-3) / 1e9 if acc_union_ms > 0 else None
     ach_serial = n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 if acc_serial_ms > 0 else None
-    traffic = traffic_raw = None
-    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")       # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py);
-    if os.path.exists(tf):                                            # keyed by size and table mode, null when not measured
-        try:
-            key = f"{curve}:2^{log_degree}:{'table' if args.precompute else 'table-free'}"
-            doc = json.load(open(tf))
-            traffic = doc.get("accumulate_hbm_bytes_per_launch", {}).get(key)
-            traffic_raw = doc.get("accumulate_fetch_raw_plus_write_bytes_per_launch", {}).get(key)
-        except Exception:
-            traffic = None
-    # The bound that actually binds: the kernel is modular arithmetic on the VALU.  One mixed addition per signed
-    # digit of every scalar (zero digits, 2^-c of them, skipped) against a memory-free loop of the same additions.
     shape = ctx.last_msm_shape()
     arith = None
     pk = madd_peak(curve) if rank == 0 else None
-    if pk and acc_serial_ms > 0:
-        adds = float(n) * shape["digits_per_scalar"]
+    if pk and acc_union_ms > 0:
+        adds = launch_pairs * shape["digits_per_scalar"]
         arith = {"bound": "valu", "unit": "mixed additions/s (XYZZ += affine, 8M + 2S in Fq)",
-                 "achieved": adds / (acc_serial_ms * 1e-3), "peak": pk["madd_per_s"],
-                 "frac": adds / (acc_serial_ms * 1e-3) / pk["madd_per_s"], "peak_source": pk["source"],
+                 "achieved": adds / (acc_union_ms * 1e-3), "peak": pk["madd_per_s"],
+                 "frac": adds / (acc_union_ms * 1e-3) / pk["madd_per_s"], "peak_source": pk["source"],
                  "additions_per_launch": adds, "window_bits": shape["window_bits"],
                  "digits_per_scalar": shape["digits_per_scalar"], "buckets": shape["buckets"],
-                 "note": "reported beside the prescribed HBM roofline: k_accumulate in the blocking MSMs (roofline.serial) "
-                         "against a pure-arithmetic loop of the same addition on this GPU"}
-    valu_busy = None                      # SQ counters are a separate rocprofv3 pass (tools/sq_summary.py), like the PMC traffic
-    vf = os.path.join(ROOT, "profiles", "r02_valu.json")
-    if os.path.exists(vf) and args.precompute:
-        try:
-            ks = json.load(open(vf)).get("workloads", {}).get(f"kzg_2p{log_degree}", {})
-            valu_busy = next((v.get("valu_busy") for k, v in ks.items() if "k_accumulate<" in k), None)
-        except Exception:
-            valu_busy = None
-    if arith is not None:
-        arith["valu_busy"] = valu_busy
-        arith["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel time * 2.4 GHz) from profiles/r02_valu.json (separate rocprofv3 "
-                                   "--pmc pass of this workload); the nominal clock understates it under sustained VALU load")
+                 "note": "reported beside the prescribed HBM roofline: the kernel is modular arithmetic on the VALU; peak = a "
+                         "memory-free loop of the same addition on this GPU (the builder's own micro-benchmark: a "
+                         "self-referential bound; against the bare v_mad_u64_u32 issue rate the kernel is at ~53 %)"}
     res = {
         "log_degree": log_degree, "steps": steps, "warmup": warmup, "dt": dt, "pairs_per_step": pairs_per_step,
         "value": pairs_per_step * steps / dt, "ms_per_step": dt / steps * 1e3,
-        "commit_open_per_s": steps / dt if world == 1 else None,
-        "value_h2d_inclusive": h2d,
-        "srs_window_table_build_ms": eng.precompute_ms,
+        "per_rank_ms_per_step": [x / steps * 1e3 for x in per_rank_dt],
+        "commit_open_per_s": steps / dt,
+        "value_h2d_inclusive": h2d, "trait_shaped": trait, "parity": parity,
+        "srs_gen_ms": S.srs_gen_ms, "srs_window_table_build_ms": eng.precompute_ms,
         "exchange_host_ms": ({k: (v / max(1, job.exchange_ms["calls"]) if k != "calls" else v) for k, v in job.exchange_ms.items()}
                              if dist is not None else None),
         "blocking_msm_ms": blocking_msm_ms,
         "msm_phase_ms": {k: float(v) for k, v in zip(
             ["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], sp[:6])},
-        # achieved: algorithmic bytes of one launch / the kernel's launch duration, hipEvent brackets on the pipeline's own
-        # stream, in blocking MSMs issued right after the timed region -- the duration rocprofv3's per-kernel average
-        # reproduces (profiles/).  Inside the pipelined region consecutive accumulations of different pipelines overlap
-        # (the next one fills the SIMDs as the previous one's workgroups retire), so a launch's bracket there includes
-        # time it shares with its neighbour: reported beside it as `timed_region`, together with the per-launch share of
-        # the step time.
-        "roofline": {"bound": "hbm", "achieved": ach_serial, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": (ach_serial / HBM_PEAK_GBPS) if ach_serial else None, "traffic": traffic,
-                     "traffic_note": "PMC FETCH_SIZE (doubled per the gfx950 note of MI355X_MICROARCH.md) + WRITE_SIZE per launch, separate "
-                                     "rocprofv3 passes of this workload (profiles/r02_pmc_traffic.json); undoubled: "
-                                     + (f"{traffic_raw:.4g} B" if traffic_raw else "n/a") + " -- for this kernel's 16-byte gathers the raw figure is the plausible one",
-                     "kernel": "k_accumulate (bucket accumulation): average hipEvent bracket of its launches on the MSM pipeline's stream, "
-                               "3 blocking commit MSMs after the timed region (no second pipeline sharing the SIMDs)",
-                     "kernel_ms": acc_serial_ms,
-                     "algorithmic_bytes_per_launch": n * PAIR_BYTES[curve],
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                     "traffic": None,
+                     "traffic_note": "PMC FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes (profiles/): not a live figure, so "
+                                     "not in this line",
+                     "kernel": "pc::k_accumulate (bucket accumulation), launched twice per step (commit MSM, open MSM)",
+                     "kernel_ms": acc_union_ms,
+                     "kernel_ms_definition": "hipEvent marks on the MSM pipelines' own streams INSIDE the timed region "
+                                             "(pc_hip_last_msm_marks_ms): union of the [start, end] intervals of all accumulate launches / "
+                                             "launches -- consecutive launches of different pipelines overlap, the union is what the region "
+                                             "spent per launch (2 x kernel_ms <= ms_per_step by construction)",
+                     "launches": len(acc_iv),
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
                      "arithmetic": arith,
-                     "timed_region": {"bracket_ms": acc_ms, "achieved_from_bracket": achieved,
-                                      "ms_per_step_over_launches": dt / steps * 1e3 / 2,
-                                      "achieved_from_step_time": (pairs_per_step / world) * PAIR_BYTES[curve] / (dt / steps) / 1e9,
-                                      "note": "brackets of overlapping launches inside the timed region; step time / 2 launches is the "
-                                              "per-launch time the pipelined run sustains"},
-                     # kept under its round-1 name for readers of earlier lines
+                     "bracket_ms_mean": acc_bracket_ms,
                      "serial": {"kernel_ms": acc_serial_ms, "achieved": ach_serial,
                                 "frac": ach_serial / HBM_PEAK_GBPS if ach_serial else None,
-                                "algorithmic_bytes_per_launch": n * PAIR_BYTES[curve]}},
+                                "algorithmic_bytes_per_launch": n * PAIR_BYTES[curve],
+                                "note": "3 blocking commit MSMs after the timed region (no second pipeline sharing the SIMDs): the "
+                                        "duration rocprofv3's per-kernel average of an --inflight 0 run reproduces"}},
     }
-    eng.srs.free()
-    del coeffs
-    torch.cuda.empty_cache()
+    S.free()
     return res
+
+
+# ------------------------------------------------------------------------------------------------------------
+# blocking latency by size, CPU port beside it (configs[0] = 2^12; the crossover SURVEY 8(b) asks for)
+# ------------------------------------------------------------------------------------------------------------
+def latency_sweep(ctx, curve, logs, cpu_max_log):
+    import torch
+    import oracle_lib as O
+    g = O.gen_bases(curve, 1)[0]
+    p = fr_modulus(curve)
+    beta, z = seed_fr(curve, 0xBE7A24), seed_fr(curve, 0x2EE7)
+    zm = mont_limbs(curve, z)
+    nmax = (1 << max(logs)) + 1
+    pts = true_srs_points(ctx, curve, g, beta, 0, nmax)
+    cores = os.cpu_count() or 1
+    rows = {}
+    crossover = None
+    for lg in logs:
+        n = (1 << lg) + 1
+        srs = ctx.upload_srs(curve, pts.data_ptr(), n=n)         # the key trimmed to this degree (MarlinKZG10::trim)
+        t0 = time.perf_counter()
+        srs.precompute()
+        tbl_ms = (time.perf_counter() - t0) * 1e3
+        co = rand_fr_device(0x5EED1000 + lg, n)
+        hostc = host_u64(co)
+        qdev = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+
+        def gpu_step():
+            c, _ = srs.msm(hostc, n=n, montgomery=True)
+            ctx.witness_poly(curve, hostc, zm, out=qdev.data_ptr(), n=n)
+            w, _ = srs.msm(qdev, n=n - 1, montgomery=True)
+            return c, w
+        for _ in range(3):
+            c, w = gpu_step()
+        reps = 3 if lg >= 22 else 10 if lg >= 18 else 30
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            gpu_step()
+        gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            srs.msm(hostc, n=n, montgomery=True)
+        gpu_commit_ms = (time.perf_counter() - t0) / reps * 1e3
+        row = {"gpu_commit_open_ms": gpu_ms, "gpu_commit_ms": gpu_commit_ms, "srs_window_table_build_ms": tbl_ms}
+        # closed-form parity of this size's commitment and proof
+        pb = from_mont_limbs(curve, O.poly_eval(curve, hostc, mont_limbs(curve, beta)))
+        pz = from_mont_limbs(curve, O.poly_eval(curve, hostc, zm))
+        row["parity_ok"] = bool((c == oracle_scalar_mul(curve, g, pb)).all() and
+                                (w == oracle_scalar_mul(curve, g, (pb - pz) * pow(beta - z, -1, p) % p)).all())
+        if lg <= cpu_max_log:
+            bh = srs.read(0, n)
+            creps = 5 if lg <= 14 else 2
+            best = None
+            for threads in ((1, cores) if lg <= 14 else (cores,)):        # small MSMs: one thread can beat the fork/join of all cores
+                t0 = time.perf_counter()
+                for _ in range(creps):
+                    O.kzg_commit(curve, bh, hostc, threads)
+                    O.kzg_open(curve, bh, hostc, zm, threads)
+                dtc = (time.perf_counter() - t0) / creps * 1e3
+                best = dtc if best is None else min(best, dtc)
+            row["cpu_port_commit_open_ms"] = best
+            row["gpu_over_cpu"] = best / gpu_ms
+            if best < gpu_ms:
+                crossover = lg
+        rows[f"2^{lg}"] = row
+        srs.free()
+        del co, qdev
+    del pts
+    torch.cuda.empty_cache()
+    return {"curve": curve, "rows": rows,
+            "cpu_faster_up_to_log_degree": crossover,
+            "note": "blocking trait-shaped commit+open (host coefficients, key trimmed to the degree, window table built at trim) "
+                    f"against the CPU port (oracle kzg_commit + kzg_open, best of 1 and {cores} threads up to 2^14, {cores} above); "
+                    "cpu_faster_up_to_log_degree = largest measured size at which the CPU port wins (null: the GPU wins at every "
+                    "measured size) -- the threshold below which the shim keeps ark-ec's msm_bigint"}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[2]: 64 x MarlinKZG10<Bn254> commits of degree 2^20, SRS sharded in contiguous chunks
+# ------------------------------------------------------------------------------------------------------------
+def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
+    import torch
+    import oracle_lib as O
+    from poly_commit_amd import sharded
+    curve = "bn254"
+    world, rank = D.world, D.rank
+    p = fr_modulus(curve)
+    total = (1 << log_degree) + 1
+    lo, hi = sharded.ShardedBatch.chunk_range(total, rank, world)
+    n = hi - lo
+    g = O.gen_bases(curve, 1)[0]
+    beta = seed_fr(curve, 0xBE7A25)
+    eng = sharded.HipEngine(ctx, curve)
+    job = sharded.ShardedBatch(eng, curve, rank, world, D.dist)
+    pts = true_srs_points(ctx, curve, g, beta, lo, n)            # this rank's REAL chunk of the one SRS
+    job.load_srs_chunk(pts.data_ptr(), precompute=bool(args.precompute), n=n)
+    del pts
+    vec = [rand_fr_device(0x5EED0100 + j * 131 + rank * 7919, n) for j in range(polys)]
+    lens = [n] * polys
+    torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = job.commit_batch(vec, lens)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = job.commit_batch(vec, lens)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = D.gather_floats([dt])[:, 0]
+    dt = float(per_rank.max())
+    # parity: C_j = p_j(beta) g with p_j(beta) = sum_r beta^(lo_r) p_{j,r}(beta); every polynomial from the device's
+    # evaluation kernel, a few of them also from the oracle's Horner
+    bm = mont_limbs(curve, beta)
+    dev_ev = np.stack([ctx.poly_eval(curve, v.data_ptr(), bm, n=n) for v in vec])
+    n_oracle = min(4, polys)
+    pick = sorted(set(int(round(i * (polys - 1) / max(1, n_oracle - 1))) for i in range(n_oracle)))
+    ok_eval = all((O.poly_eval(curve, host_u64(vec[j]), bm) == dev_ev[j]).all() for j in pick)
+    allv = D.gather_u64(dev_ev.reshape(-1)).reshape(world, polys, 4)
+    ok = True
+    for j in range(polys):
+        pb = 0
+        for r in range(world):
+            lo_r, _ = sharded.ShardedBatch.chunk_range(total, r, world)
+            pb = (pb + pow(beta, lo_r, p) * from_mont_limbs(curve, allv[r, j])) % p
+        ok = ok and bool((out[j] == oracle_scalar_mul(curve, g, pb)).all())
+    eng.srs.free()
+    del vec
+    torch.cuda.empty_cache()
+    pairs = polys * total
+    return {"workload": f"{polys} x MarlinKZG10<Bn254> commit, deg 2^{log_degree}, one SRS in {world} contiguous chunk(s) (BASELINE configs[2])",
+            "value": pairs * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "ms_per_commitment": dt / steps * 1e3 / polys, "per_rank_ms_per_step": [float(x) / steps * 1e3 for x in per_rank],
+            "srs_window_table_build_ms": eng.precompute_ms,
+            "parity": {"all_commitments_closed_form_ok": bool(ok), "oracle_horner_checked": len(pick), "oracle_horner_ok": bool(ok_eval),
+                       "method": "every C_j == p_j(beta) g on the true SRS (p_j(beta) from the device's evaluation kernel, "
+                                 f"{len(pick)} of them re-evaluated by the oracle's Horner; scalar multiplication by the oracle)"}}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[3]: InnerProductArgPC over Pallas, n = 2^22
+# ------------------------------------------------------------------------------------------------------------
+def ipa_case(ctx, log_n, reps):
+    import torch
+    import oracle_lib as O
+    from poly_commit_amd import ipa
+    curve = "pallas"
+    n = 1 << log_n
+    p = fr_modulus(curve)
+    g = O.gen_bases(curve, 1)[0]
+    t0 = time.perf_counter()
+    # hash-free synthetic generators a^i g (the reference derives them by try-and-increment,
+    # ipa_pc/mod.rs:302-325): n for the committer key + h' as one more
+    a = seed_fr(curve, 0xA11CE5)
+    pts = true_srs_points(ctx, curve, g, a, 0, n + 1)
+    key_gen_ms = (time.perf_counter() - t0) * 1e3
+    srs = ctx.upload_srs(curve, pts.data_ptr(), n=n)
+    h_prime = host_u64(pts[n])
+    del pts
+    cdev = rand_fr_device(0xA11CE, n)
+    point = mont_limbs(curve, seed_fr(curve, 0xB0B))
+    ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, log_n))
+    torch.cuda.synchronize()
+    for _ in range(3):      # every pipeline of the SRS exists (streams + workspace are created on first use)
+        comm, _ = srs.msm(cdev.data_ptr(), n=n, montgomery=True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        comm, _ = srs.msm(cdev.data_ptr(), n=n, montgomery=True)
+    t_commit = (time.perf_counter() - t0) / reps
+    best, tm_best, proof = None, None, None
+    for _ in range(reps):
+        it = iter(range(log_n))
+        tm = {}
+        work = cdev.clone()                 # the folds act in place on the coefficient vector
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proof = ipa.ipa_open_rounds(ctx, curve, srs, work, n, point, h_prime, lambda L, R_: ch[next(it)], timings=tm)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, tm_best = dt, tm
+    per_round = tm_best.pop("per_round_ms", [])
+    host = host_u64(cdev)
+    pa = from_mont_limbs(curve, O.poly_eval(curve, host, mont_limbs(curve, a)))
+    ok_commit = bool((comm == oracle_scalar_mul(curve, g, pa)).all())
+    # final_comm_key = sum_j (prod_i u_i^{bit_{log_n-1-i}(j)}) a^j g = prod_i (1 + u_i a^(2^(log_n-1-i))) g
+    us = [from_mont_limbs(curve, ch[i]) for i in range(log_n)]
+    fk = 1
+    for i, u in enumerate(us):
+        fk = fk * (1 + u * pow(a, 1 << (log_n - 1 - i), p)) % p
+    final_key = np.asarray(proof[2]).reshape(-1)
+    ok_key = bool((final_key == oracle_scalar_mul(curve, g, fk)).all())
+    srs.free()
+    del cdev
+    torch.cuda.empty_cache()
+    return {"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: cm_commit MSM + open's {log_n} halving rounds (BASELINE configs[3])",
+            "commit_ms": t_commit * 1e3, "open_ms": best * 1e3, "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / best,
+            "open_breakdown_ms": {k: round(v, 2) for k, v in tm_best.items()}, "per_round_ms": [round(x, 2) for x in per_round],
+            "key_gen_ms": key_gen_ms,
+            "parity": {"commit_ok": ok_commit, "final_comm_key_ok": ok_key,
+                       "method": "generators a^i g built on the device: commitment == p(a) g (oracle Horner + scalar multiplication); "
+                                 "final_comm_key == prod_i (1 + u_i a^(2^(log n - 1 - i))) g for the supplied round challenges u_i "
+                                 "(ipa_pc/mod.rs:699-701 folded in closed form); the whole Proof is compared with the oracle at this "
+                                 "size in tests/test_baseline_sizes_gpu.py"}}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[4]: Ligero over BLS12-381 Fr, 2^24 coefficients
+# ------------------------------------------------------------------------------------------------------------
+def ligero_case(ctx, D, curve, log_len, steps, warmup):
+    import torch
+    import oracle_lib as O
+    from poly_commit_amd import sharded
+    world, rank = D.world, D.rank
+    poly_len = 1 << log_len
+    n_rows, n_cols, _ = O.ligero_dims(FR_BITS[curve], poly_len, 4)
+    log_n = (n_cols * 4 - 1).bit_length()
+    N = 1 << log_n
+    shard = sharded.ShardedRows(sharded.HipEngine(ctx, curve), rank, world)   # rows are independent: shard by rows, no collective
+    r_lo, r_hi = shard.row_range(n_rows)
+    rows = r_hi - r_lo
+    x = rand_fr_device(0x5EED0500 + rank, rows * n_cols)
+    y = torch.empty((rows * N, 4), dtype=torch.int64, device="cuda")
+    ph = np.zeros(2)
+    ctx.set_timing(True)
+    for _ in range(warmup):
+        shard.encode(x, rows, n_cols, log_n, y)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        shard.encode(x, rows, n_cols, log_n, y)
+        ph += np.array(ctx.last_ntt_phases_ms())
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = D.gather_floats([dt])[:, 0]
+    dt = float(per_rank.max())
+    ph /= steps
+    # the next steps of LinearCodePCS::commit on the resident matrix (linear_codes/mod.rs:256-277)
+    hash_ms = merkle_ms = None
+    if world == 1:
+        leaves = torch.empty((N, 32), dtype=torch.uint8, device="cuda")
+        nodes = torch.empty((N - 1, 32), dtype=torch.uint8, device="cuda")
+        ctx.column_hash(curve, y.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=rows, n_cols=N)
+        ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=N)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.column_hash(curve, y.data_ptr(), "blake2s", out=leaves.data_ptr(), rows=rows, n_cols=N)
+        torch.cuda.synchronize()
+        hash_ms = (time.perf_counter() - t0) / 3 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=N)
+        torch.cuda.synchronize()
+        merkle_ms = (time.perf_counter() - t0) / 3 * 1e3
+    # parity (test_reed_solomon's property, linear_codes/utils.rs:303-331): out[r][j] == row_r(omega^j), a few rows and
+    # columns by the oracle's Horner; one whole row against the oracle's NTT
+    w = from_mont_limbs(curve, O.root_of_unity(curve, log_n))
+    p = fr_modulus(curve)
+    ok = True
+    ym = y.view(rows, N, 4)
+    xm = x.view(rows, n_cols, 4)
+    for r, j in ((0, 0), (0, 1), (rows // 2, N // 3), (rows - 1, N - 1), (rows - 1, N // 2 + 5)):
+        want = O.poly_eval(curve, host_u64(xm[r]), mont_limbs(curve, pow(w, j, p)))
+        ok = ok and bool((host_u64(ym[r, j]) == want).all())
+    row = host_u64(xm[rows - 1]).reshape(1, n_cols, 4)
+    ok_row = bool((O.ntt_batch(curve, row, log_n, os.cpu_count() or 8)[0] == host_u64(ym[rows - 1])).all())
+    del x, y
+    torch.cuda.empty_cache()
+    alg_bytes = rows * (n_cols + N) * 32
+    kern_ms = float(ph.sum())
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+    return {"workload": f"LigeroPCS over {curve} Fr, 2^{log_len} coefficients: {n_rows} x {n_cols} matrix, {n_rows} forward NTTs of size 2^{log_n} "
+                        f"(BASELINE configs[4]); rows sharded over {world} GPU(s), no collective",
+            "value": world * rows * n_cols * steps / dt, "unit": "coeffs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "per_rank_ms_per_step": [float(v) / steps * 1e3 for v in per_rank],
+            "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
+            "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
+                         "kernel": "pc::k_ntt_pass_a + pc::k_ntt_pass_b (one batched NTT = both), hipEvent brackets on the context's stream inside the timed region",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "parity": {"horner_spot_checks_ok": bool(ok), "one_row_vs_oracle_ntt_ok": ok_row,
+                       "method": "out[r][j] == row_r(omega^j) by the oracle's Horner at 5 (row, column) spots (test_reed_solomon's property, "
+                                 "linear_codes/utils.rs:303-331) and one whole row against the oracle's NTT"}}
 
 
 def main():
@@ -501,73 +898,139 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="commit/open results allowed in flight (0 = strictly sequential, blocking calls)")
     ap.add_argument("--workload", default="kzg", choices=["kzg", "ntt", "batch"],
-                    help="kzg (default, BASELINE configs[1]), ntt (configs[4]: Ligero 2^24 coefficients) or "
-                         "batch (configs[2]: 64 x MarlinKZG10<Bn254> commits, SRS sharded over the GPUs)")
+                    help="what `value` measures: kzg (default, BASELINE configs[1] / north star), ntt (configs[4]) or batch (configs[2])")
+    ap.add_argument("--workloads", default=None,
+                    help="comma list of the extra blocks timed in the same run at N = 1 (latency,batch,ipa,ligero); "
+                         "default: all for the default kzg run; 'none' disables")
+    ap.add_argument("--small", action="store_true", help="scaled-down sizes for every block (tests on a shared box); says so in the line")
     ap.add_argument("--polys", type=int, default=64)
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="default: nccl (RCCL); gloo when ranks share a GPU")
     ap.add_argument("--precompute", type=int, default=1,
                     help="1 (default): build the SRS window table in HBM once after the upload "
                          "(pc_hip_srs_precompute; part of SRS residency, outside the timed region); 0: table-free MSM")
     args = ap.parse_args()
-    if args.workload == "ntt":
-        if args.steps is None:
-            args.steps = 100
-        return bench_ntt(args)
-    if args.workload == "batch":
-        if args.steps is None:
-            args.steps = 10
-        if args.log_degree == 24:
-            args.log_degree = 20
-        return bench_batch(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])
 
-    import torch
+    import torch  # noqa: F401
     import poly_commit_amd as pc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):      # the latter: exercise the RCCL path on one GPU
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
+    D = Dist(args)
+    world, rank = D.world, D.rank
     curve = args.curve
-    ctx = pc.Context(local_rank)
+    ctx = pc.Context(D.device)
     if args.window_bits or args.chunk:
         ctx.set_msm_tuning(args.window_bits, args.chunk)
     ctx.set_timing(True)
+    small = args.small
+    t_start = time.perf_counter()
 
-    prim = kzg_case(ctx, args, curve, args.log_degree, args.steps, args.warmup, world, rank, dist, with_h2d=not args.no_h2d)
+    if args.workload == "ntt":
+        r = ligero_case(ctx, D, curve, 16 if small else 24, args.steps or (5 if small else 100), args.warmup)
+        if rank == 0:
+            emit({"metric": "Ligero Reed-Solomon NTT input coefficients/sec (LigeroPCS over BLS12-381 Fr, 2^24 coeffs)",
+                  "value": r["value"], "unit": "coeffs/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
+                  "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                  "dtype": "u32 limbs (255-bit Fr modular integer)", "data": "synthetic", "dist": D.info(),
+                  "config": {"workload": r["workload"], "parallelism": "1 GPU" if world == 1 else f"rows sharded over {world} GPUs, no collective"},
+                  **{k: r[k] for k in ("per_rank_ms_per_step", "ntt_phase_ms", "column_hash_blake2s_ms", "merkle_tree_sha256_ms", "roofline", "parity")}})
+        ok = r["parity"]["horner_spot_checks_ok"] and r["parity"]["one_row_vs_oracle_ntt_ok"]
+        D.close()
+        if not ok:
+            raise SystemExit("parity check FAILED")
+        return
+    if args.workload == "batch":
+        r = batch_case(ctx, D, args, 14 if small else (20 if args.log_degree == 24 else args.log_degree), args.polys, args.steps or 10, args.warmup)
+        if rank == 0:
+            emit({"metric": "MSM G1-scalar-pairs/sec, batched MarlinKZG10<Bn254> commit (64 polys, deg 2^20, SRS sharded)",
+                  "value": r["value"], "unit": "pairs/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
+                  "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                  "dtype": "u32 limbs (254-bit modular integer)", "data": "synthetic", "dist": D.info(),
+                  "config": {"workload": r["workload"], "polys_per_s": args.polys / (r["ms_per_step"] * 1e-3),
+                             "parallelism": "1 GPU" if world == 1 else f"SRS sharded over {world} GPUs, all_gather of {args.polys} partial points"},
+                  **{k: r[k] for k in ("per_rank_ms_per_step", "ms_per_commitment", "srs_window_table_build_ms", "parity")}})
+        ok = r["parity"]["all_commitments_closed_form_ok"] and r["parity"]["oracle_horner_ok"]
+        D.close()
+        if not ok:
+            raise SystemExit("parity check FAILED")
+        return
+
+    log_degree = min(args.log_degree, 16) if small else args.log_degree
+    sec_log = args.secondary_log_degree if not small else (12 if args.secondary_log_degree else 0)
+    prim = kzg_case(ctx, D, args, curve, log_degree, args.steps, args.warmup, with_h2d=not args.no_h2d)
+    log(f"primary 2^{log_degree}: {prim['ms_per_step']:.2f} ms/step, parity {prim['parity']['commit_ok']}/{prim['parity']['open_ok']} "
+        f"({time.perf_counter() - t_start:.1f} s)")
     sec = None
-    if world == 1 and args.secondary_log_degree and args.secondary_log_degree != args.log_degree:
-        sec = kzg_case(ctx, args, curve, args.secondary_log_degree, None, args.warmup, world, rank, dist,
-                       with_h2d=not args.no_h2d)
+    if world == 1 and sec_log and sec_log != log_degree:
+        sec = kzg_case(ctx, D, args, curve, sec_log, None, args.warmup, with_h2d=not args.no_h2d)
+        log(f"secondary 2^{sec_log}: {sec['ms_per_step']:.2f} ms/step ({time.perf_counter() - t_start:.1f} s)")
 
+    # ---- the other BASELINE configs, timed in the same run (N = 1) ------------------------------------------
+    want = args.workloads
+    if want is None:
+        want = "latency,batch,ipa,ligero" if world == 1 else "none"
+    want = [] if want == "none" else [w.strip() for w in want.split(",") if w.strip()]
+    workloads = {}
+    if world == 1:
+        for name in want:
+            t0 = time.perf_counter()
+            try:
+                if name == "latency":
+                    logs = (10, 12, 14) if small else (10, 12, 14, 16, 18, 20, 22, 24)
+                    workloads[name] = latency_sweep(ctx, curve, logs, cpu_max_log=14 if small else 20)
+                elif name == "batch":
+                    workloads[name] = batch_case(ctx, D, args, 14 if small else 20, 8 if small else args.polys, 3, 1)
+                elif name == "ipa":
+                    workloads[name] = ipa_case(ctx, 14 if small else 22, 2)
+                elif name == "ligero":
+                    workloads[name] = ligero_case(ctx, D, curve, 16 if small else 24, 5 if small else 20, 2)
+                else:
+                    workloads[name] = {"error": "unknown workload"}
+            except Exception as e:      # one block failing must not lose the driver's line
+                import traceback
+                traceback.print_exc()
+                workloads[name] = {"error": f"{type(e).__name__}: {e}"}
+            workloads[name]["block_wall_s"] = time.perf_counter() - t0
+            log(f"workload {name}: {time.perf_counter() - t0:.1f} s")
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:      # reported baseline: rank 0 at N = 1 only
+        t0 = time.perf_counter()
+        import oracle_lib as O
+        g = O.gen_bases(curve, 1)[0]
+        lgc = min(log_degree, 14) if small else log_degree
+        pts = true_srs_points(ctx, curve, g, seed_fr(curve, 0xBE7A24), -1, (1 << lgc) + 1)
+        srs = ctx.upload_srs(curve, pts.data_ptr(), n=(1 << lgc) + 1)
+        del pts
+        cpu = cpu_baseline(curve, srs, lgc, budget_s=3.0 if small else 30.0)
+        srs.free()
+        log(f"cpu baseline: {time.perf_counter() - t0:.1f} s")
+
+    all_ok = prim["parity"]["commit_ok"] and prim["parity"]["open_ok"] and (sec is None or (sec["parity"]["commit_ok"] and sec["parity"]["open_ok"]))
     if rank == 0:
         def cfg(lg):
-            return (f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{lg} per GPU, SRS resident, hiding off "
-                    f"(BASELINE metric sizes: 2^20 = configs[1], 2^24 = north-star target)")
+            return (f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{lg} per GPU, true SRS resident, hiding off "
+                    f"(BASELINE metric sizes: 2^20 = configs[1], 2^24 = north-star target)" + (" [--small test sizes]" if small else ""))
         out = {
             "metric": "MSM G1-scalar-pairs/sec inside KZG commit+open (MarlinKZG10<Bls12_381> shape, hiding off)",
             "value": prim["value"], "unit": "pairs/s", "n_gpus": world, "steps": prim["steps"], "warmup": prim["warmup"],
             "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer)", "data": "synthetic",
-            "parity": "oracle-only (the reference holds no golden vector on this path; its arithmetic crates are not "
-                      "buildable here) -- see DESIGN.md section 2",
-            "config": {"workload": cfg(args.log_degree), "curve": curve, "log_degree": args.log_degree,
+            "dist": D.info(), "per_rank_ms_per_step": prim["per_rank_ms_per_step"],
+            "parity": dict(prim["parity"], reference_pinned="no -- oracle-only: the reference holds no golden vector on this path and its "
+                                                            "arithmetic crates are not buildable here (DESIGN.md section 2)"),
+            "config": {"workload": cfg(log_degree), "curve": curve, "log_degree": log_degree,
                        "pairs_per_step": prim["pairs_per_step"], "inflight": max(0, args.inflight),
                        "srs_window_table": bool(args.precompute),
                        "srs_window_table_build_ms": prim["srs_window_table_build_ms"],    # once per key, outside the timed region
+                       "srs_gen_ms": prim["srs_gen_ms"],
                        "coefficients": "device-resident when the timed region starts (value); pinned host memory "
-                                       "(value_h2d_inclusive)",
-                       "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients sharded in {world} contiguous chunks, "
-                                                                 f"all_gather of partial points"},
+                                       "(value_h2d_inclusive); pageable host memory, blocking calls (trait_shaped)",
+                       "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients of ONE polynomial of {world} x 2^{log_degree} coefficients sharded in "
+                                                                 f"{world} contiguous chunks, one all_gather of partial points + division carries per step"},
             "commit_open_per_s": prim["commit_open_per_s"],
             "value_h2d_inclusive": prim["value_h2d_inclusive"],
+            "trait_shaped": prim["trait_shaped"],
             "blocking_msm_ms": prim["blocking_msm_ms"],
             "exchange_host_ms": prim["exchange_host_ms"],
             "msm_phase_ms": prim["msm_phase_ms"],
@@ -580,13 +1043,18 @@ def main():
                            "srs_window_table_build_ms": sec["srs_window_table_build_ms"]},
                 "value": sec["value"], "unit": "pairs/s", "steps": sec["steps"], "warmup": sec["warmup"],
                 "ms_per_step": sec["ms_per_step"], "commit_open_per_s": sec["commit_open_per_s"],
-                "value_h2d_inclusive": sec["value_h2d_inclusive"], "blocking_msm_ms": sec["blocking_msm_ms"],
+                "value_h2d_inclusive": sec["value_h2d_inclusive"], "trait_shaped": sec["trait_shaped"],
+                "blocking_msm_ms": sec["blocking_msm_ms"], "parity": sec["parity"],
                 "msm_phase_ms": sec["msm_phase_ms"], "roofline": sec["roofline"]}
-        if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(curve, args.log_degree)
+        if workloads:
+            out["workloads"] = workloads
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        out["bench_wall_s"] = time.perf_counter() - t_start
         emit(out)
-    if dist is not None:
-        dist.destroy_process_group()
+    D.close()
+    if not all_ok:
+        raise SystemExit("parity check FAILED (see the `parity` block of the line)")
 
 
 if __name__ == "__main__":

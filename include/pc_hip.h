@@ -119,6 +119,11 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
 /* Kernel-only timing of the last MSM issued on this ctx, in milliseconds, by phase
  * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py. */
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
+/* The same phase boundaries of the last completed MSM as offsets (ms) from the moment pc_hip_set_timing(ctx, 1) was last
+ * called: out[0] = the call was queued, out[1..6] = end of digits+hist, scan, scatter, accumulate, seg-reduce,
+ * bucket-reduce (-1: not recorded).  MSMs of different pipelines overlap on the device; with absolute marks a caller can
+ * take the UNION of the accumulate intervals [out[3], out[4]] of a timed region (bench.py's roofline.kernel_ms). */
+int pc_hip_last_msm_marks_ms(const pc_ctx* ctx, float out[8]);
 /* Geometry the last completed MSM ran with: {window bits c, signed digits per scalar (= mixed additions per pair),
  * buckets, 1 if the window table was used}.  For bench.py's arithmetic roofline. */
 int pc_hip_last_msm_shape(const pc_ctx* ctx, uint32_t out[4]);

@@ -423,8 +423,8 @@ extern "C++" {
 //      their published behaviour:
 //        field element            canonical residue, little-endian, ceil(bits / 8) bytes
 //        short-Weierstrass point  (generic impl: BN254, Pallas)  x as above, then y in ceil((bits + 2) / 8) bytes
-//                                 with the SWFlags in the top bits of the LAST byte: 0x80 = y is the larger of
-//                                 {y, -y} ("negative"), 0x40 = point at infinity (x = y = 0)
+//                                 with the SWFlags in the top bits of the LAST byte: 0x80 = YIsNegative = y is the larger of
+//                                 {y, -y} (y > -y; YIsPositive, y <= -y, sets no bit), 0x40 = point at infinity (x = y = 0)
 //        BLS12-381 G1             ark-bls12-381 overrides the generic impl with the zcash / IETF encoding:
 //                                 x, y big-endian, 48 bytes each; top bits of byte 0: 0x80 compressed (clear here),
 //                                 0x40 infinity (all other bytes zero), 0x20 unused in the uncompressed form
@@ -448,11 +448,11 @@ static void ser_point(int curve, const Aff<C>& p, std::vector<uint8_t>& out) {
   if (p.is_inf()) { out.insert(out.end(), xb + yb, 0); out.back() |= 0x40; return; }
   ser_field(p.x, xb, out);
   ser_field(p.y, yb, out);
-  // y <= -y  ->  YIsNegative ... no flag is set for the smaller ("positive") root
+  // SWFlags::from_y_coordinate: y <= -y -> YIsPositive (no bit); y > -y -> YIsNegative (0x80)
   uint64_t a[Fq::N], b[Fq::N]; p.y.to_canonical(a); p.y.neg().to_canonical(b);
   bool y_gt_neg = false;
   for (int i = Fq::N - 1; i >= 0; i--) if (a[i] != b[i]) { y_gt_neg = a[i] > b[i]; break; }
-  if (!y_gt_neg) out.back() |= 0x80;
+  if (y_gt_neg) out.back() |= 0x80;
 }
 // Field::from_random_bytes (ark-ff): the first 8 N bytes as a little-endian integer with the bits above
 // MODULUS_BIT_SIZE cleared; None if that integer is >= the modulus.

@@ -397,7 +397,7 @@ def ser_point(curve, P):
         out[-1] |= 0x40
         return bytes(out)
     out = bytearray(P[0].to_bytes(xb, "little") + P[1].to_bytes(yb, "little"))
-    if P[1] <= (p - P[1]) % p:                     # SWFlags::YIsNegative unless y > -y
+    if P[1] > (p - P[1]) % p:                      # SWFlags::from_y_coordinate: YIsPositive (no bit) for y <= -y, YIsNegative (0x80) for y > -y
         out[-1] |= 0x80
     return bytes(out)
 
@@ -421,7 +421,7 @@ def ser_point_compressed(curve, P):
         out[-1] |= 0x40
         return bytes(out)
     out[:] = P[0].to_bytes(yb, "little")
-    if P[1] <= (p - P[1]) % p:
+    if P[1] > (p - P[1]) % p:                      # YIsNegative: y is the larger of {y, -y}
         out[-1] |= 0x80
     return bytes(out)
 
@@ -927,6 +927,12 @@ def ligero_check(field, commitment, z, value, proof, indices, r=None, rho_inv=4,
     p = FIELDS[field]["p"]
     n_rows, n_cols, n_ext = commitment["n_rows"], commitment["n_cols"], commitment["n_ext_cols"]
     if (r is not None) != (proof["well_formedness"] is not None):
+        raise ValueError("InvalidCommitment")
+    # the reference indexes columns[j] / paths[j] for every query index (linear_codes/mod.rs:443-489): a short proof cannot pass
+    t = len(indices)
+    if (len(proof["columns"]) != t or len(proof["paths"]) != t or len(proof["v"]) != n_cols
+            or any(len(c) != n_rows for c in proof["columns"]) or any(not 0 <= i < n_ext for i in indices)
+            or (r is not None and (len(proof["well_formedness"]) != n_cols or len(r) != n_rows))):
         raise ValueError("InvalidCommitment")
     col_hashes = [column_digest(field, c, col_hash) for c in proof["columns"]]
     for leaf, q_j, (idx, sib, path) in zip(col_hashes, indices, proof["paths"]):

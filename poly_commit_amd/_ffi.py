@@ -75,6 +75,7 @@ def load_library():
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
     lib.pc_hip_set_timing.argtypes = [vp, ip]
     lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pc_hip_last_msm_marks_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_last_msm_shape.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.pc_hip_matrix_columns.argtypes = [vp, vp, sz, sz, vp, sz, vp, ip]
     lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
@@ -159,6 +160,12 @@ class Context:
     def last_msm_phases_ms(self):
         out = (C.c_float * 8)()
         self.check(self.lib.pc_hip_last_msm_phases_ms(self.h, out))
+        return list(out)
+
+    def last_msm_marks_ms(self):
+        """Phase boundaries of the last completed MSM as offsets from the last set_timing(True) (pc_hip_last_msm_marks_ms)."""
+        out = (C.c_float * 8)()
+        self.check(self.lib.pc_hip_last_msm_marks_ms(self.h, out))
         return list(out)
 
     def last_msm_shape(self):
@@ -447,6 +454,7 @@ class MsmJob:
                                            PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL, where, n,
                                            C.c_void_p(self.out.ctypes.data), C.byref(self.inf), C.byref(self.h)))
         self.phases = None
+        self.marks = None
 
     def wait(self):
         ctx = self.srs.ctx
@@ -454,6 +462,7 @@ class MsmJob:
             ctx.check(ctx.lib.pc_hip_job_wait(ctx.h, self.h))
             self.h = None
             self.phases = ctx.last_msm_phases_ms()
+            self.marks = ctx.last_msm_marks_ms()
         return self.out, bool(self.inf.value)
 
 

@@ -39,6 +39,8 @@ struct pc_ctx {
   std::string last_error;
   pc::MsmConfig msm_cfg;
   float phases[8] = {0};
+  float marks[8] = {0};          // the same marks as offsets from `epoch` (pc_hip_last_msm_marks_ms)
+  hipEvent_t epoch = nullptr;    // recorded by pc_hip_set_timing(on)
   uint32_t shape[4] = {0};
 };
 
@@ -121,6 +123,8 @@ static void complete_job(pc_ctx* ctx, pc_job* job) {
   for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
   L->runner->shape(ctx->shape);
   if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
+  for (int i = 0; i < 8; i++) ctx->marks[i] = -1.0f;
+  if (L->be.timing && ctx->epoch) for (int i = 0; i < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->marks[i], ctx->epoch, L->be.ev[i]);
   job->status = PC_OK;
 }
 
@@ -195,6 +199,7 @@ void pc_hip_shutdown(pc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   ctx->ntt_plans.clear();
+  if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
   ctx->be.destroy();
   delete ctx;
 }
@@ -529,7 +534,25 @@ int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* sc
   });
 }
 
-int pc_hip_set_timing(pc_ctx* ctx, int on) { if (!ctx) return PC_ERR_INVALID_ARG; ctx->be.timing = on != 0; return PC_OK; }
+int pc_hip_set_timing(pc_ctx* ctx, int on) {
+  if (!ctx) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    ctx->be.timing = on != 0;
+    if (on) {     // the reference point of pc_hip_last_msm_marks_ms
+      if (!ctx->epoch) PC_HIP_CHECK(hipEventCreate(&ctx->epoch));
+      PC_HIP_CHECK(hipEventRecord(ctx->epoch, ctx->be.stream));
+      PC_HIP_CHECK(hipEventSynchronize(ctx->epoch));
+    }
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_last_msm_marks_ms(const pc_ctx* ctx, float out[8]) {
+  if (!ctx || !out) return PC_ERR_INVALID_ARG;
+  for (int i = 0; i < 8; i++) out[i] = ctx->marks[i];
+  return PC_OK;
+}
 
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]) {
   if (!ctx || !out) return PC_ERR_INVALID_ARG;

@@ -8,7 +8,7 @@
 //   generic short Weierstrass (BN254 G1, Pallas)
 //     uncompressed  x: ceil(bits/8) bytes LE, y: ceil((bits+2)/8) bytes LE, flags in the top bits of the LAST byte
 //     compressed    x: ceil((bits+2)/8) bytes LE with the flags in the top bits of the last byte
-//     flags         0x80 YIsNegative (y is the smaller of {y, -y}... i.e. y <= -y), 0x40 PointAtInfinity
+//     flags         0x80 YIsNegative (y > -y: the larger of the two roots; no bit = YIsPositive = the smaller), 0x40 PointAtInfinity
 //   BLS12-381 G1 (zcash / IETF)
 //     uncompressed  x, y: 48 bytes big-endian each; byte 0: 0x80 clear, 0x40 infinity
 //     compressed    x: 48 bytes big-endian; byte 0: 0x80 set, 0x40 infinity, 0x20 y is the lexicographically larger root
@@ -65,7 +65,7 @@ struct SrsDecodeBody {
       xc = load_bytes(p, XB, true, 0x1f);
       if (!compressed) yc = load_bytes(p + XB, XB, true, 0xff);
     } else if (compressed) {
-      inf = (p[YB - 1] & 0x40) != 0; want_larger = (p[YB - 1] & 0x80) == 0;     // YIsPositive (no flag) = the larger root
+      inf = (p[YB - 1] & 0x40) != 0; want_larger = (p[YB - 1] & 0x80) != 0;     // YIsNegative (0x80) = the larger root, YIsPositive (no flag) = the smaller
       xc = load_bytes(p, YB, false, 0x3f);
     } else {
       inf = (p[XB + YB - 1] & 0x40) != 0;

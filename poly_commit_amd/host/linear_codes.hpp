@@ -196,7 +196,15 @@ struct LinearCodePCS {
     ok = false;
     const size_t n_rows = com.metadata.n_rows, n_cols = com.metadata.n_cols, n_ext = com.metadata.n_ext_cols, t = indices.size();
     if ((r != nullptr) != proof.has_well_formedness) return invalid_commitment("well-formedness proof missing or unexpected");
-    if (proof.columns.size() != t || proof.paths.size() != t || proof.v.size() != n_cols) return invalid_commitment("proof shape");
+    // every container the loops below index is sized against the t query indices first (an untrusted prover's proof must end in
+    // InvalidCommitment, never in an out-of-bounds read; the reference indexes all of them per query, linear_codes/mod.rs:443-489)
+    unsigned height = 1; while (((size_t)1 << height) < n_ext) height++;
+    if (proof.columns.size() != t || proof.paths.size() != t || proof.leaf_index.size() != t || proof.leaf_sibling.size() != t ||
+        proof.v.size() != n_cols || (r && proof.well_formedness.size() != n_cols) || (r && r->size() != n_rows) ||
+        n_ext == 0 || (n_ext & (n_ext - 1)) || n_ext < n_cols)
+      return invalid_commitment("proof shape");
+    for (size_t j = 0; j < t; j++)
+      if (indices[j] >= n_ext || proof.paths[j].size() != (size_t)32 * (height - 1)) return invalid_commitment("proof shape");
     // 3. hash the received columns (device: they are the columns of an n_rows x t matrix)
     std::vector<FrT<E>> m(n_rows * t);
     for (size_t j = 0; j < t; j++) { if (proof.columns[j].size() != n_rows) return invalid_commitment("column length"); for (size_t row = 0; row < n_rows; row++) m[row * t + j] = proof.columns[j][row]; }

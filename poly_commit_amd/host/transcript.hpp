@@ -12,8 +12,9 @@
 // (INTEGRATION.md lists them as assertions of the shim):
 //   field element     canonical residue, little-endian, ceil(MODULUS_BIT_SIZE / 8) bytes
 //   SW affine point   generic short_weierstrass impl (BN254 G1, Pallas): x, then y in ceil((bits + 2) / 8) bytes with
-//                     SWFlags in the top bits of the LAST byte -- 0x80 YIsNegative (y <= -y ... i.e. y is not the larger
-//                     root), 0x40 PointAtInfinity (x = y = 0)
+//                     SWFlags in the top bits of the LAST byte -- 0x80 YIsNegative (y > -y: y is the larger root;
+//                     SWFlags::from_y_coordinate gives YIsPositive = no bit for y <= -y), 0x40 PointAtInfinity (x = y = 0)
+//                     [round 2 had the 0x80 condition inverted; the BN254 generator (1, 2) must end in 0x00, its negation in 0x80]
 //   BLS12-381 G1      zcash / IETF encoding: x, y big-endian 48 bytes each; byte 0: 0x80 compressed (clear), 0x40 infinity
 //   from_random_bytes the first 8 N bytes little-endian, bits above MODULUS_BIT_SIZE cleared, None if >= modulus
 // This is a handful of hashes of < 200 bytes per round: host work, exactly where the reference does it.
@@ -147,7 +148,7 @@ struct Transcript {
     canonical_le<FqP>(n.y, yb, ny);
     bool y_gt_neg = false;
     for (size_t i = yb; i-- > 0;) if (y[i] != ny[i]) { y_gt_neg = y[i] > ny[i]; break; }
-    if (!y_gt_neg) y.back() |= 0x80;                    // SWFlags::YIsNegative
+    if (y_gt_neg) y.back() |= 0x80;                     // SWFlags::YIsNegative <=> y > -y (from_y_coordinate: y <= -y is YIsPositive, no bit)
     bytes.insert(bytes.end(), y.begin(), y.end());
   }
 

@@ -46,7 +46,7 @@ def ser_point(curve, xy_mont):
         out[-1] |= 0x40
         return bytes(out)
     out[:] = x.to_bytes(xb, "little") + y.to_bytes(yb, "little")
-    if y <= (q - y) % q:
+    if y > (q - y) % q:                 # SWFlags::YIsNegative (0x80): y is the larger of {y, -y}; YIsPositive sets no bit
         out[-1] |= 0x80
     return bytes(out)
 

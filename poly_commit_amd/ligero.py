@@ -157,8 +157,23 @@ def check(ctx, curve, commitment, z_mont, value_mont, proof, indices, r_mont=Non
     n_rows, n_cols, n_ext = commitment["n_rows"], commitment["n_cols"], commitment["n_ext_cols"]
     if (r_mont is not None) != (proof["well_formedness"] is not None):
         raise InvalidCommitment("well-formedness proof missing or unexpected")
-    cols = np.ascontiguousarray(proof["columns"], dtype=np.uint64)                     # (t, n_rows, 4)
-    t = cols.shape[0]
+    # Shape of the proof against the t query indices the sponge produced: the reference indexes
+    # proof.opening.columns[transcript_index] and .paths[..] for EVERY one of them (linear_codes/mod.rs:443-489), so a proof
+    # with fewer columns or paths can never be accepted there (round-2 advisor finding: zip() stopped at the shorter list).
+    indices = [int(i) for i in indices]
+    t = len(indices)
+    try:
+        cols = np.ascontiguousarray(proof["columns"], dtype=np.uint64)                 # (t, n_rows, 4)
+        v_arr = np.ascontiguousarray(proof["v"], dtype=np.uint64)
+        wf_arr = None if proof["well_formedness"] is None else np.ascontiguousarray(proof["well_formedness"], dtype=np.uint64)
+    except (TypeError, ValueError):
+        raise InvalidCommitment("proof shape")
+    height = max(1, (n_ext - 1).bit_length())
+    if (cols.shape != (t, n_rows, 4) or len(proof["paths"]) != t or v_arr.shape != (n_cols, 4)
+            or (wf_arr is not None and wf_arr.shape != (n_cols, 4)) or n_ext & (n_ext - 1) or n_ext < n_cols
+            or any(not 0 <= i < n_ext for i in indices)
+            or any(len(pth) != 3 or len(pth[1]) not in (0, 32) or len(pth[2]) != height - 1 or any(len(s) != 32 for s in pth[2]) for pth in proof["paths"])):
+        raise InvalidCommitment("proof shape")
     # 3. hash the received columns on the device: they are the columns of an n_rows x t matrix
     digests = ctx.column_hash(curve, np.ascontiguousarray(cols.transpose(1, 0, 2)), col_hash)       # (t, 32)
     # 4. the paths
@@ -174,11 +189,11 @@ def check(ctx, curve, commitment, z_mont, value_mont, proof, indices, r_mont=Non
         ctx.ntt_batch(curve, x.data_ptr(), log_n, out=y.data_ptr(), rows=1, in_cols=n_cols)
         return y
     sel = torch.tensor(list(indices), dtype=torch.long, device="cuda")
-    w = _ints(curve, encode(proof["v"])[sel].cpu().numpy().view(np.uint64))
+    w = _ints(curve, encode(v_arr)[sel].cpu().numpy().view(np.uint64))
     a, b = tensors if tensors is not None else tensor(curve, z_mont, n_cols, n_rows)
     col_ints = [_ints(curve, cols[j]) for j in range(t)]
     if r_mont is not None:
-        wwf = _ints(curve, encode(proof["well_formedness"])[sel].cpu().numpy().view(np.uint64))
+        wwf = _ints(curve, encode(wf_arr)[sel].cpu().numpy().view(np.uint64))
         r = _ints(curve, r_mont)
         for j in range(t):
             if sum(x * y for x, y in zip(r, col_ints[j])) % p != wwf[j]:
@@ -187,4 +202,4 @@ def check(ctx, curve, commitment, z_mont, value_mont, proof, indices, r_mont=Non
         if sum(x * y for x, y in zip(b, col_ints[j])) % p != w[j]:
             raise InvalidCommitment(f"b.column != w at column {indices[j]}")
     value = _limbs_to_int(value_mont) * pow(_R, -1, p) % p
-    return sum(x * y for x, y in zip(_ints(curve, proof["v"]), a)) % p == value
+    return sum(x * y for x, y in zip(_ints(curve, v_arr), a)) % p == value

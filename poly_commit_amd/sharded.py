@@ -36,6 +36,39 @@ def _int_to_limbs(v):
     return np.frombuffer(int(v).to_bytes(32, "little"), dtype="<u8").astype(np.uint64)
 
 
+def all_gather_u64(dist, world, arr, cache=None):
+    """Small uint64 numpy array -> (world, len) array, the same on every rank.  The exchange of this protocol is a few
+    hundred bytes per rank (one point / one Fr): one all_gather_into_tensor on persistent buffers -- pinned host staging
+    and a device tensor per payload length under RCCL, plain host tensors under gloo."""
+    import torch
+    flat = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+    if dist is None or world == 1:
+        return flat.reshape(1, -1).copy()
+    nccl = dist.get_backend() == "nccl"
+    key = (flat.size, nccl)
+    bufs = cache.get(key) if cache is not None else None
+    if bufs is None:
+        if nccl:
+            bufs = (torch.empty(flat.size, dtype=torch.int64).pin_memory(), torch.empty(flat.size, dtype=torch.int64, device="cuda"),
+                    torch.empty(world * flat.size, dtype=torch.int64, device="cuda"), torch.empty(world * flat.size, dtype=torch.int64).pin_memory())
+        else:
+            bufs = (torch.empty(flat.size, dtype=torch.int64), None, torch.empty(world * flat.size, dtype=torch.int64), None)
+        if cache is not None:
+            cache[key] = bufs
+    h_in, d_in, d_out, h_out = bufs
+    h_in.numpy().view(np.uint64)[:] = flat
+    if nccl:
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        res = h_out
+    else:
+        dist.all_gather_into_tensor(d_out, h_in)
+        res = d_out
+    return res.numpy().view(np.uint64).reshape(world, -1).copy()
+
+
 class HipEngine:
     """Device engine: everything stays in HBM; only 96-byte points / 32-byte carries return."""
 
@@ -44,9 +77,11 @@ class HipEngine:
         self.srs = None
         self._scratch = None
         self.phases = []
+        self.marks = []      # absolute phase boundaries of the same MSMs (Context.last_msm_marks_ms)
 
-    def load_srs(self, bases, precompute=False):
-        self.srs = self.ctx.upload_srs(self.curve, np.ascontiguousarray(bases))
+    def load_srs(self, bases, precompute=False, n=None):
+        """bases: host array of affine points, or a device pointer with `n` (a chunk generated on the device)."""
+        self.srs = self.ctx.upload_srs(self.curve, bases if isinstance(bases, int) else np.ascontiguousarray(bases), n=n)
         self.precompute_ms = None
         if precompute:          # window table in HBM (pc_hip_srs_precompute): once per key, like the upload
             import time
@@ -78,6 +113,7 @@ class HipEngine:
                 out, _ = job.wait()
                 if job.phases is not None:
                     eng.phases.append(job.phases)
+                    eng.marks.append(job.marks)
                 return out
         return _Pending()
 
@@ -118,6 +154,7 @@ class ShardedKzg:
         self.p = FR_MODULUS[curve]
         self.z = None
         self.last_phases = []
+        self._coll = {}
         self.exchange_ms = {"wait_local_msm": 0.0, "shard_eval": 0.0, "all_gather": 0.0, "calls": 0}
 
     # bases: n+1 affine points; bases[0] = the power just below this chunk (unused on rank 0),
@@ -133,12 +170,7 @@ class ShardedKzg:
         """arr: small uint64 numpy array -> (world, len) array, same on every rank."""
         if self.dist is None:
             return arr.reshape(1, -1)
-        import torch
-        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(arr.reshape(-1).view(np.int64).copy()).to(dev)
-        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
+        return all_gather_u64(self.dist, self.world, arr, self._coll)
 
     def _combine_points(self, local_xy):
         pts = self._all_gather(local_xy)
@@ -241,6 +273,7 @@ class ShardedBatch:
 
     def __init__(self, engine, curve, rank=0, world=1, dist=None):
         self.e, self.curve, self.rank, self.world, self.dist = engine, curve, rank, world, dist
+        self._coll = {}
 
     @staticmethod
     def chunk_range(total, rank, world):
@@ -255,12 +288,7 @@ class ShardedBatch:
         part = self.e.msm_batch(polys, lens)
         if self.dist is None or self.world == 1:
             return part
-        import torch
-        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(part.reshape(-1).view(np.int64).copy()).to(dev)
-        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(out, t)
-        allp = out.cpu().numpy().view(np.uint64).reshape(self.world, len(polys), -1)
+        allp = all_gather_u64(self.dist, self.world, part, self._coll).reshape(self.world, len(polys), -1)
         return np.stack([self.e.points_sum(np.ascontiguousarray(allp[:, j])) for j in range(len(polys))])
 
 

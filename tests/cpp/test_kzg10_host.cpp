@@ -246,6 +246,14 @@ static void run(pc_ctx* ctx, const char* name) {
         { auto bad = pr; bad.columns[2][1] = bad.columns[2][1] + FrT<E>::one(); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
         { auto bad = idx; bad[0] = idx[1]; CHECK(pcs.check(ctx, com, param, z, value, pr, bad, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
         CHECK(pcs.check(ctx, com, param, z, value, pr, idx, wf ? nullptr : &r, ok).kind == Error::InvalidCommitment);
+        // malformed proofs from an untrusted prover end in InvalidCommitment, not in an out-of-bounds read (round-2 advisor finding)
+        { auto bad = pr; bad.leaf_index.pop_back(); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        { auto bad = pr; bad.leaf_sibling.clear(); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        { auto bad = pr; bad.paths[1].resize(bad.paths[1].size() - 32); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        { auto bad = pr; bad.columns.resize(1); bad.paths.resize(1); bad.leaf_index.resize(1); bad.leaf_sibling.resize(1);
+          CHECK(pcs.check(ctx, com, param, z, value, bad, idx, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        { auto bad = idx; bad[0] = com.metadata.n_ext_cols; CHECK(pcs.check(ctx, com, param, z, value, pr, bad, wf ? &r : nullptr, ok).kind == Error::InvalidCommitment); }
+        if (wf) { auto bad = pr; bad.well_formedness.pop_back(); CHECK(pcs.check(ctx, com, param, z, value, bad, idx, &r, ok).kind == Error::InvalidCommitment); }
       }
     }
   }

@@ -1,0 +1,67 @@
+"""bench.py end to end on a GPU box: the line the driver parses, the blocks it carries, and the N > 1 path launched the way
+the driver launches N = 1 (`python bench.py --gpus N` with no WORLD_SIZE: the script starts its own ranks).  A one-GPU box
+runs the two ranks on device 0 (PC_BENCH_DEVICES=0,0; RCCL refuses two ranks on one device, so that run uses gloo for the
+collective -- the per-rank chunks, the exchange protocol and the in-line parity check are the same code)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(argv, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"expected ONE line on stdout, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_default_line_small():
+    """Every block of the default (N = 1) line, at scaled-down sizes."""
+    d = run_bench(["--small", "--steps", "3"])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "pairs/s" and d["value"] > 0
+    assert d["parity"]["commit_ok"] and d["parity"]["open_ok"] and d["parity"]["device_poly_eval_ok"]
+    assert d["parity"]["commitments_checked"] == 3 and d["parity"]["proofs_checked"] == 3
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["launches"] == 6
+    assert 2 * rf["kernel_ms"] <= d["ms_per_step"] * 1.0001          # by construction (union of the launches' intervals)
+    assert d["trait_shaped"]["parity_ok"] and d["trait_shaped"]["ms_per_commit_open"] > 0
+    assert d["secondary"]["parity"]["commit_ok"] and d["secondary"]["parity"]["open_ok"]
+    w = d["workloads"]
+    assert all(r["parity_ok"] for r in w["latency"]["rows"].values())
+    assert "cpu_port_commit_open_ms" in w["latency"]["rows"]["2^12"]          # BASELINE configs[0]
+    assert w["batch"]["parity"]["all_commitments_closed_form_ok"] and w["batch"]["parity"]["oracle_horner_ok"]
+    assert w["ipa"]["parity"]["commit_ok"] and w["ipa"]["parity"]["final_comm_key_ok"]
+    assert w["ligero"]["parity"]["horner_spot_checks_ok"] and w["ligero"]["parity"]["one_row_vs_oracle_ntt_ok"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+def test_two_ranks_self_launched_kzg():
+    """`python bench.py --gpus 2 --log-degree 16`: ranks started by the script, each with its REAL chunk of the one true
+    SRS, every commitment / proof of the timed region checked against the closed form of the whole polynomial."""
+    d = run_bench(["--gpus", "2", "--log-degree", "16", "--steps", "4", "--no-cpu-baseline"], {"PC_BENCH_DEVICES": "0,0"})
+    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["config"]["pairs_per_step"] == 2 * 2 * (1 << 16) - 1
+    assert d["parity"]["commit_ok"] and d["parity"]["open_ok"]
+    assert d["parity"]["commitments_checked"] == 4 and d["parity"]["proofs_checked"] == 4
+    assert d["roofline"]["frac"] > 0 and d["exchange_host_ms"]["calls"] >= 4
+
+
+def test_two_ranks_blocking_kzg():
+    d = run_bench(["--gpus", "2", "--log-degree", "14", "--steps", "3", "--inflight", "0", "--no-cpu-baseline"], {"PC_BENCH_DEVICES": "0,0"})
+    assert d["n_gpus"] == 2 and d["parity"]["commit_ok"] and d["parity"]["open_ok"]
+
+
+def test_two_ranks_batch_and_rows():
+    d = run_bench(["--gpus", "2", "--workload", "batch", "--small", "--polys", "8", "--steps", "2"], {"PC_BENCH_DEVICES": "0,0"})
+    assert d["n_gpus"] == 2 and d["parity"]["all_commitments_closed_form_ok"] and d["parity"]["oracle_horner_ok"]
+    d = run_bench(["--gpus", "2", "--workload", "ntt", "--small", "--steps", "2"], {"PC_BENCH_DEVICES": "0,0"})
+    assert d["n_gpus"] == 2 and d["parity"]["horner_spot_checks_ok"] and d["parity"]["one_row_vs_oracle_ntt_ok"]
