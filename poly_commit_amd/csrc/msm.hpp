@@ -126,7 +126,11 @@ struct ScalarDigits {
   PC_HD void for_each_window(uint32_t c, uint32_t Wd, F f) const {
     uint64_t buf = 0; uint32_t have = 0, w = 0;
     const uint32_t mask = (1u << c) - 1u;
+    // preconditions (asserted where the geometry is made, plan_geometry): 2 <= c <= 24 and Wd * c > 32 * (N - 1), i.e. the
+    // windows consume every limb but possibly the last; a caller that asked for fewer windows stops the limb loop instead
+    // of letting `have` grow past the register (round-2 advisor finding)
     PC_UNROLL for (int i = 0; i < FrP::N; i++) {
+      if (w >= Wd) break;
       buf |= (uint64_t)s[i] << have; have += 32;                 // have < c <= 24 before: no bit is lost
       while (have >= c && w < Wd) { f(w, (uint32_t)buf & mask); buf >>= c; have -= c; w++; }
     }
@@ -830,6 +834,7 @@ class MsmPlan {
   void plan_geometry(size_t n) {
     const bool tbl = subs_ || (cfg_.tbl && cfg_.tbl_c && n >= cfg_.tbl_min_n);
     uint32_t c = tbl ? cfg_.tbl_c : cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
+    if (c < 2 || c > 24) throw std::runtime_error("MsmPlan: window width out of range (2..24)");   // ScalarDigits' shift register, the sort passes
     g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = subs_ ? subs_ : tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u; g_.m_sub = 0;
     g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.pt_stride = tbl ? cfg_.tbl_pt_stride : (uint32_t)AW;

@@ -40,6 +40,8 @@ inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   uint32_t cb = bbits > fine_target ? bbits - fine_target : 0;
   if (cb > cb_max) cb = cb_max;
   s.cb = cb; s.fine_bits = bbits - cb; s.ncw = 1u << cb; s.NC = g.W * s.ncw;
+  // fine_bits can exceed 11 (k_sort_fine's LDS histogram holds 2^11 buckets) when cb clamps to cb_max with many bucket sets
+  // (c = 24 with W >= 11; 64 sub-MSMs at c >= 22): HipBackend::sort_entries checks fine_bits / NC and takes the atomic sort then
   // The top window holds tb = bits - (W-1)*c scalar bits, i.e. only 2^tb of its 2^(c-1) buckets are reachable.
   // With the common fine width all of its n entries would land in one or two coarse bins (one
   // workgroup of the fine sort walking n records alone); give it fine width (tb-1) - cb instead so

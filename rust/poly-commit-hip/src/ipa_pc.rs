@@ -1,0 +1,374 @@
+//! `HipIpaPC<G, D, P>`: `PolynomialCommitment` with the associated types of the reference's `InnerProductArgPC`
+//! (`poly-commit/src/ipa_pc/mod.rs:338-345`): `setup` / `trim` / `check` delegate, `commit` (`:403-473`) and `open`
+//! (`:475-723`) are restated with `cm_commit`'s MSM (`:54-72`) and the body of the halving loop (`:664-711`) on the device.
+//!
+//! Per round of `open` (n -> n/2) the reference does two MSMs of n/2 pairs, two inner products, the folds of the
+//! coefficient and z vectors, `k_l += k_r * u` with one full-width scalar multiplication PER ELEMENT plus
+//! `normalize_batch`, and one Blake2s challenge.  Here the three vectors live in HBM for all rounds:
+//!   l, r          `pc_hip_msm_async` x2 on the resident key (halves addressed by `base_offset`)   `:671,674`
+//!   <c_r, z_l>..  `pc_hip_fr_dot` x2                                                               `:672,675`, `utils.rs:150-155`
+//!   h' * <..>     `pc_hip_point_mul` (one point, host -- as in the reference)
+//!   transcript    `serialize_uncompressed` + `compute_random_oracle_challenge`: the reference's own Rust, two points a round
+//!   folds         `pc_hip_fr_fold` x2                                                               `:691-697`
+//!   key fold      `pc_hip_ec_fold` (GLV ladder per element + batched normalisation) while n > 2^17; from there on the key
+//!                 stays FIXED and the folds act on per-base factors s_j (`pc_hip_ipa_key_scalars`): the round's MSMs run
+//!                 over the fixed key with scalars c * s, `final_comm_key = sum_j s_j K_j` is one last MSM -- the same
+//!                 points, bit for bit, without a latency-bound ladder pass per round                  `:699-707`
+//! `compute_random_oracle_challenge`, `check_degrees_and_bounds`, `shift_polynomial` are private in the reference
+//! (`:74-87`, `:205-239`) and restated verbatim.
+use ark_crypto_primitives::sponge::CryptographicSponge;
+use ark_ec::{AffineRepr, CurveGroup, VariableBaseMSM};
+use ark_ff::{Field, One, PrimeField, UniformRand, Zero};
+use ark_poly::{DenseUVPolynomial, Polynomial};
+use ark_poly_commit::{
+    ipa_pc::{Commitment, CommitterKey, InnerProductArgPC, Proof, Randomness, UniversalParams, VerifierKey},
+    Error, LabeledCommitment, LabeledPolynomial, PCCommitmentState, PCCommitterKey, PolynomialCommitment, CHALLENGE_SIZE,
+};
+use ark_serialize::CanonicalSerialize;
+use ark_std::{marker::PhantomData, rand::RngCore};
+use core::ffi::c_void;
+use digest::Digest;
+
+use crate::curve::{HipCurve, HipField};
+use crate::device::{self, check, ctx, DevicePoly};
+use crate::ffi;
+use crate::kzg10_hip::{msm, Scalars};
+
+/// Rounds with n at most this keep the key fixed (see the module doc); `PC_HIP_IPA_FIXED_KEY_BELOW` overrides.
+const FIXED_KEY_BELOW: usize = 1 << 17;
+
+pub struct HipIpaPC<G: AffineRepr, D: Digest, P: DenseUVPolynomial<G::ScalarField>> {
+    _projective: PhantomData<G>,
+    _digest: PhantomData<D>,
+    _poly: PhantomData<P>,
+}
+
+impl<G, D, P> HipIpaPC<G, D, P>
+where
+    G: HipCurve,
+    G::ScalarField: HipField,
+    G::Group: VariableBaseMSM<MulBase = G>,
+    D: Digest,
+    P: DenseUVPolynomial<G::ScalarField>,
+{
+    /// `cm_commit` (`ipa_pc/mod.rs:54-72`): the MSM on the device, the optional `hiding_generator * randomizer` on the host.
+    fn cm_commit(comm_key: &[G], scalars: Scalars<G::ScalarField>, hiding_generator: Option<G>, randomizer: Option<G::ScalarField>)
+        -> Result<G::Group, Error> {
+        let mut comm = msm::<G>(comm_key, scalars)?;
+        if randomizer.is_some() {
+            assert!(hiding_generator.is_some());
+            comm += &hiding_generator.unwrap().mul(randomizer.unwrap());
+        }
+        Ok(comm)
+    }
+
+    // ipa_pc/mod.rs:74-87
+    fn compute_random_oracle_challenge(bytes: &[u8]) -> G::ScalarField {
+        let mut i = 0u64;
+        let mut challenge = None;
+        while challenge.is_none() {
+            let mut hash_input = bytes.to_vec();
+            hash_input.extend(i.to_le_bytes());
+            let hash = D::digest(hash_input.as_slice());
+            challenge = <G::ScalarField as Field>::from_random_bytes(&hash);
+            i += 1;
+        }
+        challenge.unwrap()
+    }
+
+    // ipa_pc/mod.rs:205-228
+    fn check_degrees_and_bounds(supported_degree: usize, p: &LabeledPolynomial<G::ScalarField, P>) -> Result<(), Error> {
+        if p.degree() > supported_degree {
+            return Err(Error::TooManyCoefficients { num_coefficients: p.degree() + 1, num_powers: supported_degree + 1 });
+        }
+        if let Some(bound) = p.degree_bound() {
+            if bound < p.degree() || bound > supported_degree {
+                return Err(Error::IncorrectDegreeBound { poly_degree: p.degree(), degree_bound: bound, supported_degree, label: p.label().to_string() });
+            }
+        }
+        Ok(())
+    }
+
+    // ipa_pc/mod.rs:230-239
+    fn shift_polynomial(ck: &CommitterKey<G>, p: &P, degree_bound: usize) -> P {
+        if p.is_zero() {
+            P::zero()
+        } else {
+            let mut shifted_polynomial_coeffs = vec![G::ScalarField::zero(); ck.supported_degree() - degree_bound];
+            shifted_polynomial_coeffs.extend_from_slice(p.coeffs());
+            P::from_coefficients_vec(shifted_polynomial_coeffs)
+        }
+    }
+
+    /// The halving loop (`ipa_pc/mod.rs:641-711`) on device-resident vectors.  `coeffs`: the d + 1 padded coefficients of
+    /// the combined polynomial (consumed); returns `(l_vec, r_vec, final_comm_key, c)`.
+    fn open_rounds(ck: &CommitterKey<G>, coeffs: DevicePoly, point: G::ScalarField, h_prime: G, mut round_challenge: G::ScalarField)
+        -> Result<(Vec<G>, Vec<G>, G, G::ScalarField), Error> {
+        let c = ctx()?;
+        let fid = <G::ScalarField as HipField>::FIELD_OF;
+        let d1 = ck.comm_key.len();
+        let log_d = ark_std::log2(d1) as usize;
+        let limbs = |x: &G::ScalarField| x.to_mont_limbs();
+
+        // the folds are destructive: work on a device-to-device copy of the resident key
+        let (resident, off) = device::resident(&ck.comm_key[..])?;
+        let mut key = core::ptr::null_mut();
+        let key_src = (unsafe { ffi::pc_hip_srs_device_ptr(resident.srs) } as usize + off * 16 * G::FQ_LIMBS) as *const c_void;
+        check(c, unsafe { ffi::pc_hip_srs_upload(c.raw, G::CURVE, key_src, d1, 0, ffi::PC_MEM_DEVICE, &mut key) })?;
+        struct KeyGuard(*mut ffi::pc_srs);
+        impl Drop for KeyGuard {
+            fn drop(&mut self) {
+                unsafe { ffi::pc_hip_srs_free(self.0) }
+            }
+        }
+        let _guard = KeyGuard(key);
+
+        // powers of z (:641-649)
+        let z = DevicePoly::alloc(d1)?;
+        check(c, unsafe { ffi::pc_hip_fr_powers(c.raw, fid, limbs(&point).as_ptr() as *const c_void, d1, z.dev) })?;
+
+        let mut h_xy = vec![0u64; 2 * G::FQ_LIMBS];
+        h_prime.write_xy(&mut h_xy);
+        let fixed_below = std::env::var("PC_HIP_IPA_FIXED_KEY_BELOW").ok().and_then(|v| v.parse().ok()).unwrap_or(FIXED_KEY_BELOW);
+        let mut fixed: Option<(usize, DevicePoly, DevicePoly, DevicePoly)> = None;      // (n0, s, scalars of l, scalars of r)
+
+        let mut l_vec = Vec::with_capacity(log_d);
+        let mut r_vec = Vec::with_capacity(log_d);
+        let mut n = d1;
+        while n > 1 {
+            let h = n / 2;
+            if fixed.is_none() && n <= fixed_below {
+                let s = DevicePoly::alloc(n)?;
+                check(c, unsafe { ffi::pc_hip_fr_powers(c.raw, fid, limbs(&G::ScalarField::one()).as_ptr() as *const c_void, n, s.dev) })?;   // s = (1, 1, ...)
+                fixed = Some((n, s, DevicePoly::alloc(n)?, DevicePoly::alloc(n)?));
+            }
+            // l = cm_commit(key_l, coeffs_r) + h' * <coeffs_r, z_l>;  r = cm_commit(key_r, coeffs_l) + h' * <coeffs_l, z_r>   (:671-675)
+            let w = 2 * G::FQ_LIMBS;
+            let (mut l_xy, mut r_xy) = (vec![0u64; w], vec![0u64; w]);
+            let (mut l_inf, mut r_inf) = (0i32, 0i32);
+            let (mut jl, mut jr) = (core::ptr::null_mut(), core::ptr::null_mut());
+            if let Some((n0, s, al, ar)) = fixed.as_ref() {
+                check(c, unsafe { ffi::pc_hip_ipa_key_scalars(c.raw, fid, coeffs.dev, n, s.dev, *n0, core::ptr::null(), 0, al.dev, ar.dev) })?;
+                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, al.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
+                                                        l_xy.as_mut_ptr() as *mut c_void, &mut l_inf, &mut jl) })?;
+                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, ar.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
+                                                        r_xy.as_mut_ptr() as *mut c_void, &mut r_inf, &mut jr) })?;
+            } else {
+                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, coeffs.at(h), ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
+                                                        l_xy.as_mut_ptr() as *mut c_void, &mut l_inf, &mut jl) })?;
+                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, h, coeffs.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
+                                                        r_xy.as_mut_ptr() as *mut c_void, &mut r_inf, &mut jr) })?;
+            }
+            let (mut ip_l, mut ip_r) = ([0u64; 4], [0u64; 4]);
+            check(c, unsafe { ffi::pc_hip_fr_dot(c.raw, fid, coeffs.at(h), z.dev, h, ip_l.as_mut_ptr() as *mut c_void) })?;
+            check(c, unsafe { ffi::pc_hip_fr_dot(c.raw, fid, coeffs.dev, z.at(h), h, ip_r.as_mut_ptr() as *mut c_void) })?;
+            let (mut hl, mut hr) = (vec![0u64; w], vec![0u64; w]);
+            check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, ip_l.as_ptr() as *const c_void, hl.as_mut_ptr() as *mut c_void) })?;
+            check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, ip_r.as_ptr() as *const c_void, hr.as_mut_ptr() as *mut c_void) })?;
+            check(c, unsafe { ffi::pc_hip_job_wait(c.raw, jl) })?;
+            check(c, unsafe { ffi::pc_hip_job_wait(c.raw, jr) })?;
+            let l = (G::read_xy(&l_xy).into_group() + G::read_xy(&hl).into_group()).into_affine();     // normalize_batch(&[l, r]) (:677)
+            let r = (G::read_xy(&r_xy).into_group() + G::read_xy(&hr).into_group()).into_affine();
+            l_vec.push(l);
+            r_vec.push(r);
+
+            // :681-689, the reference's own transcript code
+            let mut byte_vec = Vec::new();
+            round_challenge.serialize_uncompressed(&mut byte_vec).unwrap();
+            l.serialize_uncompressed(&mut byte_vec).unwrap();
+            r.serialize_uncompressed(&mut byte_vec).unwrap();
+            round_challenge = Self::compute_random_oracle_challenge(byte_vec.as_slice());
+            let round_challenge_inv = round_challenge.inverse().unwrap();
+
+            check(c, unsafe { ffi::pc_hip_fr_fold(c.raw, fid, coeffs.dev, coeffs.at(h), h, limbs(&round_challenge_inv).as_ptr() as *const c_void) })?;   // :691-693
+            check(c, unsafe { ffi::pc_hip_fr_fold(c.raw, fid, z.dev, z.at(h), h, limbs(&round_challenge).as_ptr() as *const c_void) })?;                  // :695-697
+            if let Some((n0, s, _, _)) = fixed.as_ref() {                                                                                                  // :699-707
+                check(c, unsafe { ffi::pc_hip_ipa_key_scalars(c.raw, fid, core::ptr::null(), 0, s.dev, *n0, limbs(&round_challenge).as_ptr() as *const c_void, n,
+                                                              core::ptr::null_mut(), core::ptr::null_mut()) })?;
+            } else {
+                check(c, unsafe { ffi::pc_hip_ec_fold(c.raw, key, h, limbs(&round_challenge).as_ptr() as *const c_void) })?;
+            }
+            n = h;
+        }
+        let w = 2 * G::FQ_LIMBS;
+        let mut fk = vec![0u64; w];
+        if let Some((n0, s, _, _)) = fixed.as_ref() {
+            let mut inf = 0i32;
+            check(c, unsafe { ffi::pc_hip_msm(c.raw, key, 0, s.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0, fk.as_mut_ptr() as *mut c_void, &mut inf) })?;
+        } else {
+            check(c, unsafe { ffi::pc_hip_srs_read(c.raw, key, 0, 1, fk.as_mut_ptr() as *mut c_void) })?;
+        }
+        let c0: Vec<G::ScalarField> = coeffs.download(1)?;
+        Ok((l_vec, r_vec, G::read_xy(&fk), c0[0]))
+    }
+}
+
+impl<G, D, P> PolynomialCommitment<G::ScalarField, P> for HipIpaPC<G, D, P>
+where
+    G: HipCurve,
+    G::ScalarField: HipField,
+    G::Group: VariableBaseMSM<MulBase = G>,
+    D: Digest,
+    P: DenseUVPolynomial<G::ScalarField, Point = G::ScalarField>,
+{
+    type UniversalParams = UniversalParams<G>;
+    type CommitterKey = CommitterKey<G>;
+    type VerifierKey = VerifierKey<G>;
+    type Commitment = Commitment<G>;
+    type CommitmentState = Randomness<G>;
+    type Proof = Proof<G>;
+    type BatchProof = Vec<Self::Proof>;
+    type Error = Error;
+
+    fn setup<R: RngCore>(max_degree: usize, num_vars: Option<usize>, rng: &mut R) -> Result<Self::UniversalParams, Self::Error> {
+        InnerProductArgPC::<G, D, P>::setup(max_degree, num_vars, rng)                         // ipa_pc/mod.rs:347-373
+    }
+
+    fn trim(pp: &Self::UniversalParams, supported_degree: usize, supported_hiding_bound: usize, enforced_degree_bounds: Option<&[usize]>)
+        -> Result<(Self::CommitterKey, Self::VerifierKey), Self::Error> {
+        InnerProductArgPC::<G, D, P>::trim(pp, supported_degree, supported_hiding_bound, enforced_degree_bounds)   // :375-401; the key is uploaded at first use
+    }
+
+    fn commit<'a>(ck: &Self::CommitterKey, polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<G::ScalarField, P>>,
+                  rng: Option<&mut dyn RngCore>) -> Result<(Vec<LabeledCommitment<Self::Commitment>>, Vec<Self::CommitmentState>), Self::Error>
+    where
+        P: 'a,
+    {
+        let rng = &mut ark_poly_commit::optional_rng::OptionalRng(rng);
+        let mut comms = Vec::new();
+        let mut states = Vec::new();
+        for labeled_polynomial in polynomials {
+            Self::check_degrees_and_bounds(ck.supported_degree(), labeled_polynomial)?;
+            let polynomial: &P = labeled_polynomial.polynomial();
+            let label = labeled_polynomial.label();
+            let hiding_bound = labeled_polynomial.hiding_bound();
+            let degree_bound = labeled_polynomial.degree_bound();
+
+            let state = if let Some(h) = hiding_bound { Randomness::rand(h, degree_bound.is_some(), None, rng) } else { Randomness::empty() };
+
+            // the polynomial's device copy serves both MSMs here and the combination in `open`
+            let coeffs = polynomial.coeffs();
+            let dev = if coeffs.len() >= device::min_pairs() { Some(device::device_poly(coeffs)?) } else { None };
+            let sc = || match dev.as_ref() {
+                Some(d) => Scalars::Device { buf: d, first: 0, n: coeffs.len() },
+                None => Scalars::Host(coeffs),
+            };
+            let comm = Self::cm_commit(&ck.comm_key[..(polynomial.degree() + 1)], sc(), Some(ck.s), Some(state.rand))?.into();      // :443-449
+            let shifted_comm = match degree_bound {                                                                                   // :451-459
+                Some(d) => Some(Self::cm_commit(&ck.comm_key[(ck.supported_degree() - d)..], sc(), Some(ck.s), state.shifted_rand)?.into()),
+                None => None,
+            };
+            let commitment = Commitment { comm, shifted_comm };
+            comms.push(LabeledCommitment::new(label.to_string(), commitment, degree_bound));
+            states.push(state);
+        }
+        Ok((comms, states))
+    }
+
+    fn open<'a>(ck: &Self::CommitterKey, labeled_polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<G::ScalarField, P>>,
+                commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>, point: &'a P::Point,
+                sponge: &mut impl CryptographicSponge, states: impl IntoIterator<Item = &'a Self::CommitmentState>,
+                rng: Option<&mut dyn RngCore>) -> Result<Self::Proof, Self::Error>
+    where
+        Self::Commitment: 'a,
+        Self::CommitmentState: 'a,
+        P: 'a,
+    {
+        // :489-560, the reference's combination loop; `combined_polynomial += (cur_challenge, polynomial)` is kept on the host
+        // for the shifted (zero-padded) polynomials and gathered as (challenge, polynomial) terms for the plain ones
+        let mut combined_polynomial = P::zero();
+        let mut combined_rand = G::ScalarField::zero();
+        let mut combined_commitment_proj = G::Group::zero();
+        let mut has_hiding = false;
+        let mut cur_challenge: G::ScalarField = sponge.squeeze_field_elements_with_sizes(&[CHALLENGE_SIZE])[0];
+
+        for (labeled_polynomial, (labeled_commitment, state)) in labeled_polynomials.into_iter().zip(commitments.into_iter().zip(states)) {
+            let label = labeled_polynomial.label();
+            assert_eq!(labeled_polynomial.label(), labeled_commitment.label());
+            Self::check_degrees_and_bounds(ck.supported_degree(), labeled_polynomial)?;
+            let polynomial = labeled_polynomial.polynomial();
+            let degree_bound = labeled_polynomial.degree_bound();
+            let hiding_bound = labeled_polynomial.hiding_bound();
+            let commitment = labeled_commitment.commitment();
+
+            combined_polynomial += (cur_challenge, polynomial);
+            combined_commitment_proj += &commitment.comm.mul(cur_challenge);
+            if hiding_bound.is_some() {
+                has_hiding = true;
+                combined_rand += &(cur_challenge * &state.rand);
+            }
+            cur_challenge = sponge.squeeze_field_elements_with_sizes(&[CHALLENGE_SIZE])[0];
+
+            let has_degree_bound = degree_bound.is_some();
+            assert_eq!(has_degree_bound, commitment.shifted_comm.is_some(), "shifted_comm mismatch for {}", label);
+            assert_eq!(degree_bound, labeled_commitment.degree_bound(), "labeled_comm degree bound mismatch for {}", label);
+            if let Some(degree_bound) = degree_bound {
+                let shifted_polynomial = Self::shift_polynomial(ck, polynomial, degree_bound);
+                combined_polynomial += (cur_challenge, &shifted_polynomial);
+                combined_commitment_proj += &commitment.shifted_comm.unwrap().mul(cur_challenge);
+                if hiding_bound.is_some() {
+                    let shifted_rand = state.shifted_rand;
+                    assert!(shifted_rand.is_some(), "shifted_rand.is_none() for {}", label);
+                    combined_rand += &(cur_challenge * &shifted_rand.unwrap());
+                }
+            }
+            cur_challenge = sponge.squeeze_field_elements_with_sizes(&[CHALLENGE_SIZE])[0];
+        }
+
+        let combined_v = combined_polynomial.evaluate(point);
+        let d = ck.supported_degree();
+        let mut combined_commitment;
+        let mut hiding_commitment = None;
+
+        if has_hiding {                                                                                            // :573-609
+            let mut rng = rng.expect("hiding commitments require randomness");
+            let mut hiding_polynomial = P::rand(d, &mut rng);
+            hiding_polynomial -= &P::from_coefficients_slice(&[hiding_polynomial.evaluate(point)]);
+            let hiding_rand = G::ScalarField::rand(&mut rng);
+            let hiding_commitment_proj = Self::cm_commit(ck.comm_key.as_slice(), Scalars::Host(hiding_polynomial.coeffs()), Some(ck.s), Some(hiding_rand))?;
+            let mut batch = G::Group::normalize_batch(&[combined_commitment_proj, hiding_commitment_proj]);
+            hiding_commitment = Some(batch.pop().unwrap());
+            combined_commitment = batch.pop().unwrap();
+
+            let mut byte_vec = Vec::new();
+            combined_commitment.serialize_uncompressed(&mut byte_vec).unwrap();
+            point.serialize_uncompressed(&mut byte_vec).unwrap();
+            combined_v.serialize_uncompressed(&mut byte_vec).unwrap();
+            hiding_commitment.unwrap().serialize_uncompressed(&mut byte_vec).unwrap();
+            let hiding_challenge = Self::compute_random_oracle_challenge(byte_vec.as_slice());
+            combined_polynomial += (hiding_challenge, &hiding_polynomial);
+            combined_rand += &(hiding_challenge * &hiding_rand);
+            combined_commitment_proj += &(hiding_commitment.unwrap().mul(hiding_challenge) - &ck.s.mul(combined_rand));
+        }
+        let combined_rand = if has_hiding { Some(combined_rand) } else { None };
+
+        combined_commitment = combined_commitment_proj.into_affine();
+        let mut byte_vec = Vec::new();                                                                             // :621-629
+        combined_commitment.serialize_uncompressed(&mut byte_vec).unwrap();
+        point.serialize_uncompressed(&mut byte_vec).unwrap();
+        combined_v.serialize_uncompressed(&mut byte_vec).unwrap();
+        let round_challenge = Self::compute_random_oracle_challenge(byte_vec.as_slice());
+        let h_prime = ck.h.mul(round_challenge).into_affine();
+
+        // Pads the coefficients with zeroes to get the number of coeff to be d+1 (:632-638)
+        let mut coeffs = combined_polynomial.coeffs().to_vec();
+        if coeffs.len() < d + 1 {
+            coeffs.resize(d + 1, G::ScalarField::zero());
+        }
+
+        let (l_vec, r_vec, final_comm_key, c) = Self::open_rounds(ck, DevicePoly::upload(&coeffs)?, *point, h_prime, round_challenge)?;
+        Ok(Proof { l_vec, r_vec, final_comm_key, c, hiding_comm: hiding_commitment, rand: combined_rand })
+    }
+
+    fn check<'a>(vk: &Self::VerifierKey, commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>, point: &'a P::Point,
+                 values: impl IntoIterator<Item = G::ScalarField>, proof: &Self::Proof, sponge: &mut impl CryptographicSponge,
+                 rng: Option<&mut dyn RngCore>) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        // The verifier's one large computation, cm_commit(vk.comm_key, check_poly.compute_coeffs()) (:759-765), has a device
+        // form as well (pc_hip_ipa_key_scalars + pc_hip_msm; C++ rendering: poly_commit_amd/host/ipa_pc.hpp::check).  The
+        // succinct part (:91-203) is private to the reference, so the drop-in verifier stays the reference's own.
+        InnerProductArgPC::<G, D, P>::check(vk, commitments, point, values, proof, sponge, rng)
+    }
+}

@@ -4,6 +4,7 @@ the CPU (there is no fallback path)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -110,3 +111,28 @@ def test_header_is_plain_c99_and_links(tmp_path):
                            "-L" + libdir, "-lpc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and int(out.stdout) == len(names)
+
+
+def test_rust_shim_ffi_declarations_match_the_header(tmp_path):
+    """rust/poly-commit-hip/src/ffi.rs declares every function of include/pc_hip.h with the same arity, types and
+    constants (tools/check_ffi_decls.py; there is no Rust toolchain here, so this is what keeps the crate's extern block in
+    step with the ABI), and the checker does notice a drifted declaration."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_ffi_decls", os.path.join(ROOT, "tools", "check_ffi_decls.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    problems, hfuncs = chk.check()
+    assert not problems, problems
+    assert len(hfuncs) >= 56 and "pc_hip_msm" in hfuncs and "pc_hip_group_kzg_open" in hfuncs
+    # every exported symbol of the built library is in the header too (and hence in ffi.rs)
+    names = set(hfuncs)
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "poly_commit_amd", "libpc_hip.so")], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("pc_hip_")}
+    assert exported <= names, exported - names
+    # negative: a drifted copy is reported
+    bad = tmp_path / "ffi.rs"
+    src = open(chk.FFI_RS).read().replace("pub fn pc_hip_msm(ctx: *mut pc_ctx, srs: *const pc_srs, base_offset: usize,", "pub fn pc_hip_msm(ctx: *mut pc_ctx, srs: *const pc_srs, base_offset: u32,")
+    assert src != open(chk.FFI_RS).read()
+    bad.write_text(src)
+    rf, _ = chk.parse_ffi_rs(str(bad))
+    assert rf["pc_hip_msm"][0][2][1] == "u32" != hfuncs["pc_hip_msm"][0][2][1]
