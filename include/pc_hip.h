@@ -258,6 +258,13 @@ int pc_hip_fr_fold(pc_ctx* ctx, pc_curve field_of, void* lo_dev, const void* hi_
 /* out = <a, b> over n elements (utils.rs:150-155, used at ipa_pc/mod.rs:672,675). */
 int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void* b_dev, size_t n,
                   void* out_host);
+/* A round's vector work in one pass, 64 bytes back: with u_host / u_inv_host != NULL first the folds by the PREVIOUS round's
+ * challenge at size 2m -- coeffs[i] += u^-1 * coeffs[m + i], z[i] += u * z[m + i], i < m (:691-697) -- then, on the folded
+ * vectors of size m, the two inner products of the round (:672,675):
+ *   out[0] = <coeffs[m/2 .. m), z[0 .. m/2)>   (the h' term of l),   out[1] = <coeffs[0 .. m/2), z[m/2 .. m)>   (of r).
+ * m = 1 (the last fold) returns zeros.  m must be a power of two; both NULL: inner products only (the first round). */
+int pc_hip_ipa_fold_dots(pc_ctx* ctx, pc_curve field_of, void* coeffs_dev, void* z_dev, size_t m, const void* u_host,
+                         const void* u_inv_host, void* out_dots_host);
 /* out[i] = z^i, i < n (ipa_pc/mod.rs:641-649). */
 int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t n, void* out_dev);
 /* In-place key fold on the resident comm_key: key[i] = affine(key[i] + u * key[n_half + i]) for

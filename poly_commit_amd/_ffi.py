@@ -88,6 +88,7 @@ def load_library():
     lib.pc_hip_fr_lincomb.argtypes = [vp, ip, C.POINTER(vp), ip, C.POINTER(sz), sz, vp, vp, ip, sz]
     lib.pc_hip_fr_fold.argtypes = [vp, ip, vp, vp, sz, vp]
     lib.pc_hip_fr_dot.argtypes = [vp, ip, vp, vp, sz, vp]
+    lib.pc_hip_ipa_fold_dots.argtypes = [vp, ip, vp, vp, sz, vp, vp, vp]
     lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
     lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
     lib.pc_hip_ipa_key_scalars.argtypes = [vp, ip, vp, sz, vp, sz, vp, sz, vp, vp]
@@ -322,6 +323,16 @@ class Context:
     def fr_dot(self, curve, a_dev, b_dev, n):
         out = np.zeros(4, dtype=np.uint64)
         self.check(self.lib.pc_hip_fr_dot(self.h, CURVES[curve], a_dev, b_dev, n, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def ipa_fold_dots(self, curve, coeffs_dev, z_dev, m, u=None, u_inv=None):
+        """pc_hip_ipa_fold_dots: optional fold at size 2m by (u, u^-1), then the round's two inner products at size m -> (2, 4) uint64."""
+        out = np.zeros((2, 4), dtype=np.uint64)
+        pu = pi = None
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.uint64); u_inv = np.ascontiguousarray(u_inv, dtype=np.uint64)
+            pu, pi = C.c_void_p(u.ctypes.data), C.c_void_p(u_inv.ctypes.data)
+        self.check(self.lib.pc_hip_ipa_fold_dots(self.h, CURVES[curve], coeffs_dev, z_dev, m, pu, pi, C.c_void_p(out.ctypes.data)))
         return out
 
     def fr_powers(self, curve, z, n, out_dev):

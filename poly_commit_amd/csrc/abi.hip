@@ -707,6 +707,18 @@ int pc_hip_fr_dot(pc_ctx* ctx, pc_curve field_of, const void* a_dev, const void*
     return (int)PC_OK;
   });
 }
+int pc_hip_ipa_fold_dots(pc_ctx* ctx, pc_curve field_of, void* coeffs_dev, void* z_dev, size_t m, const void* u_host, const void* u_inv_host,
+                         void* out_dots_host) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !coeffs_dev || !z_dev || !out_dots_host || !m || (m & (m - 1))) return PC_ERR_INVALID_ARG;
+  if ((u_host != nullptr) != (u_inv_host != nullptr)) return PC_ERR_INVALID_ARG;
+  if (m >= (1ull << 31)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    pc::field_ops(field_of).ipa_fold_dots(ctx->be, (uint32_t*)coeffs_dev, (uint32_t*)z_dev, m, (const uint32_t*)u_host, (const uint32_t*)u_inv_host,
+                                          (uint32_t*)out_dots_host);
+    return (int)PC_OK;
+  });
+}
 int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t n, void* out_dev) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && !out_dev)) return PC_ERR_INVALID_ARG;
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;

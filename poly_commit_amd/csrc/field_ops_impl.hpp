@@ -56,6 +56,22 @@ struct FieldOpsImpl {
     for (uint32_t t = 0; t < lanes; t++) acc = acc.add(F::load(&h[(size_t)t * FrP::N]));
     acc.store(out);
   }
+  static void ipa_fold_dots(HipBackend& be, uint32_t* c, uint32_t* z, size_t m, const uint32_t* u, const uint32_t* ui, uint32_t* out_host) {
+    const uint32_t q = (uint32_t)(m >> 1);
+    uint32_t blocks = (q + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks == 0) blocks = 1;
+    const size_t need = ((size_t)blocks + 1) * 2 * FrP::N * 4;
+    if (need > be.scan_tmp_bytes) {      // reuse the backend's small scratch buffer (as fr_dot does)
+      if (be.scan_tmp) { be.sync(); (void)hipFree(be.scan_tmp); be.scan_tmp = nullptr; be.scan_tmp_bytes = 0; }
+      PC_HIP_CHECK(hipMalloc(&be.scan_tmp, need)); be.scan_tmp_bytes = need;
+    }
+    uint32_t* partial = (uint32_t*)be.scan_tmp; uint32_t* fin = partial + (size_t)blocks * 2 * FrP::N;
+    const F fu = u ? F::load(u) : F::zero(), fui = ui ? F::load(ui) : F::zero();
+    hipLaunchKernelGGL(k_ipa_fold_dots<FrP>, dim3(blocks), dim3(256), 0, be.stream, c, z, (uint32_t)m, u ? 1u : 0u, fu, fui, partial);
+    PC_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_ipa_dots_final<FrP>, dim3(1), dim3(256), 0, be.stream, (const uint32_t*)partial, blocks, fin);
+    PC_HIP_CHECK(hipGetLastError());
+    be.copy_d2h(out_host, fin, (size_t)2 * FrP::N * 4);
+  }
   static void fr_powers(HipBackend& be, const uint32_t* z, size_t n, uint32_t* out) {
     FrPowersBody<FrP> body; body.out = out;
     F w = F::load(z);
@@ -77,7 +93,7 @@ struct FieldOpsImpl {
     else { ColumnHashBody<FrP, Blake2s256> b{e, rows, n_cols, o}; be.launch(b, n_cols, 64); }
   }
   static FieldOps table() {
-    return FieldOps{&make_ntt, &poly_eval_f, &div_scan_f, &witness_f, &fr_fold, &fr_dot, &fr_powers, &ipa_key_scalars, &fr_lincomb, &column_hash};
+    return FieldOps{&make_ntt, &poly_eval_f, &div_scan_f, &witness_f, &fr_fold, &fr_dot, &ipa_fold_dots, &fr_powers, &ipa_key_scalars, &fr_lincomb, &column_hash};
   }
 };
 

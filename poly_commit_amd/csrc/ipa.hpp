@@ -89,6 +89,72 @@ struct IpaFixedKeyScalarsBody {      // scalar vectors of L and R for the round 
   }
 };
 
+// One round's vector work in ONE pass (ipa_pc/mod.rs:672,675 and :691-697): the optional fold by the previous round's
+// challenge at size 2m (c_l += u^-1 c_r, z_l += u z_r) and, on the folded values still in registers, the two inner products
+// of the round at size m:  l = <c[m/2..m), z[0..m/2)>,  r = <c[0..m/2), z[m/2..m)>.  Lane t owns positions t and t + m/2 of
+// the (folded) vectors; workgroup sums go through LDS, a second one-workgroup kernel adds them: 64 bytes come back.
+// (Round 2: two fr_dot calls -- two launches, a blocking download of 256 partials and a host fold each -- plus two fr_fold
+// launches per round: 18 + 1 ms of host time over the 22 rounds of an opening at 2^22.)
+#if defined(__HIPCC__)
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ipa_fold_dots(uint32_t* c, uint32_t* z, uint32_t m, uint32_t fold, Fd<FrP> u, Fd<FrP> ui,
+                                                       uint32_t* partial) {
+  typedef Fd<FrP> F;
+  constexpr int N = FrP::N;
+  __shared__ uint32_t red[2][256][N];
+  const uint32_t q = m >> 1;
+  F al = F::zero(), ar = F::zero();
+  if (q == 0) {                       // m == 1: the last fold, no inner products left
+    if (fold && blockIdx.x == 0 && threadIdx.x == 0) {
+      F::load(c).add(ui.mul(F::load(c + N))).store(c);
+      F::load(z).add(u.mul(F::load(z + N))).store(z);
+    }
+  } else {
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < q; t += gridDim.x * 256) {
+      F c0 = F::load(c + (size_t)t * N), c1 = F::load(c + (size_t)(t + q) * N);
+      F z0 = F::load(z + (size_t)t * N), z1 = F::load(z + (size_t)(t + q) * N);
+      if (fold) {                     // reads at >= m, writes at < m: no lane reads what another writes
+        c0 = c0.add(ui.mul(F::load(c + (size_t)(t + m) * N))); c1 = c1.add(ui.mul(F::load(c + (size_t)(t + q + m) * N)));
+        z0 = z0.add(u.mul(F::load(z + (size_t)(t + m) * N))); z1 = z1.add(u.mul(F::load(z + (size_t)(t + q + m) * N)));
+        c0.store(c + (size_t)t * N); c1.store(c + (size_t)(t + q) * N);
+        z0.store(z + (size_t)t * N); z1.store(z + (size_t)(t + q) * N);
+      }
+      al = al.add(c1.mul(z0)); ar = ar.add(c0.mul(z1));
+    }
+  }
+  al.store(red[0][threadIdx.x]); ar.store(red[1][threadIdx.x]);
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      F::load(red[0][threadIdx.x]).add(F::load(red[0][threadIdx.x + s])).store(red[0][threadIdx.x]);
+      F::load(red[1][threadIdx.x]).add(F::load(red[1][threadIdx.x + s])).store(red[1][threadIdx.x]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2 * N) partial[(size_t)blockIdx.x * 2 * N + threadIdx.x] = threadIdx.x < N ? red[0][0][threadIdx.x] : red[1][0][threadIdx.x - N];
+}
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ipa_dots_final(const uint32_t* partial, uint32_t nblocks, uint32_t* out) {
+  typedef Fd<FrP> F;
+  constexpr int N = FrP::N;
+  __shared__ uint32_t red[2][256][N];
+  F al = F::zero(), ar = F::zero();
+  for (uint32_t b = threadIdx.x; b < nblocks; b += 256) {
+    al = al.add(F::load(partial + (size_t)b * 2 * N)); ar = ar.add(F::load(partial + (size_t)b * 2 * N + N));
+  }
+  al.store(red[0][threadIdx.x]); ar.store(red[1][threadIdx.x]);
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      F::load(red[0][threadIdx.x]).add(F::load(red[0][threadIdx.x + s])).store(red[0][threadIdx.x]);
+      F::load(red[1][threadIdx.x]).add(F::load(red[1][threadIdx.x + s])).store(red[1][threadIdx.x]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2 * N) out[threadIdx.x] = threadIdx.x < N ? red[0][0][threadIdx.x] : red[1][0][threadIdx.x - N];
+}
+#endif
+
 // scalar * affine point with a NAF-recoded scalar shared by all lanes (branch-uniform), Jacobian
 template <class C, int NW>
 PC_HD JacD<C> naf_mul(const NafMasks<NW>& naf, const AffD<C>& p) {

@@ -53,6 +53,7 @@ struct FieldOps {
   void (*witness)(HipBackend& be, const uint32_t* p, size_t n, const uint32_t* z_host, uint32_t* q, uint32_t fan);
   void (*fr_fold)(HipBackend& be, uint32_t* lo, const uint32_t* hi, size_t n, const uint32_t* s);
   void (*fr_dot)(HipBackend& be, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out_host);
+  void (*ipa_fold_dots)(HipBackend& be, uint32_t* c, uint32_t* z, size_t m, const uint32_t* u_host, const uint32_t* u_inv_host, uint32_t* out_host);
   void (*fr_powers)(HipBackend& be, const uint32_t* z, size_t n, uint32_t* out);
   void (*ipa_key_scalars)(HipBackend& be, const uint32_t* c, size_t m, uint32_t* s, size_t n0, const uint32_t* fold_u, size_t fold_m,
                           uint32_t* out_l, uint32_t* out_r);

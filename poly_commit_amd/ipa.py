@@ -7,6 +7,7 @@ ark-serialize bytes) is host work on two points and stays with the caller: it is
 `next_challenge(l_xy, r_xy) -> u (Montgomery Fr limbs)`.
 """
 import hashlib
+import os
 
 import numpy as np
 
@@ -119,7 +120,14 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     ctx.fr_powers(curve, point_mont, n, z.data_ptr())
     cptr, zptr = coeffs_dev.data_ptr(), z.data_ptr()
     l_vec, r_vec = [], []
-    n0, s_dev, al, ar = 0, None, None, None
+    n0, s_dev, alr = 0, None, None
+    # PC_IPA_FIXED_MANY=1: the two MSMs of a fixed-key round as ONE two-row pc_hip_msm_many pass.  Measured slower than two
+    # pipelined pc_hip_msm_async calls (1.40 vs 1.20 ms per round at n0 = 2^17, plus 8 ms for the pass's window table): off.
+    many = os.environ.get("PC_IPA_FIXED_MANY", "0") == "1"
+    # the inner products of the first round; later rounds get theirs from the fused fold (pc_hip_ipa_fold_dots)
+    with _T("fold_dots"):
+        dots = ctx.ipa_fold_dots(curve, cptr, zptr, n)
+    u_prev = None
     while n > 1:
         h = n // 2
         t_round = time.perf_counter()
@@ -129,40 +137,48 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
             one = _int_to_limbs(_R % p)
             s_dev = torch.empty((n0, 4), dtype=torch.int64, device=coeffs_dev.device)
             ctx.fr_powers(curve, one, n0, s_dev.data_ptr())                # s = (1, 1, ...)
-            al, ar = torch.empty_like(s_dev), torch.empty_like(s_dev)
+            alr = torch.empty((2 * n0, 4), dtype=torch.int64, device=coeffs_dev.device)   # scalars of l | scalars of r
+            u_prev = None                                                  # the key itself carries every fold so far
         # l = cm_commit(key_l, coeffs_r) + h' * <coeffs_r, z_l>;  r = cm_commit(key_r, coeffs_l) + h' * <coeffs_l, z_r>
         with _T("msm_enqueue"):
             if n0:
-                ctx.ipa_key_scalars(curve, cptr, n, s_dev.data_ptr(), n0, out_l_dev=al.data_ptr(), out_r_dev=ar.data_ptr())
-                jl = srs.msm_async(al.data_ptr(), n=n0, base_offset=0, montgomery=True)
-                jr = srs.msm_async(ar.data_ptr(), n=n0, base_offset=0, montgomery=True)
+                # fold of the factors by the previous challenge (size 2n), then this round's scalar vectors (size n): one call
+                ctx.ipa_key_scalars(curve, cptr, n, s_dev.data_ptr(), n0, fold_u=u_prev, fold_m=2 * n if u_prev is not None else 0,
+                                    out_l_dev=alr.data_ptr(), out_r_dev=alr.data_ptr() + 32 * n0)
+                if not many:
+                    jl = srs.msm_async(alr.data_ptr(), n=n0, base_offset=0, montgomery=True)
+                    jr = srs.msm_async(alr.data_ptr() + 32 * n0, n=n0, base_offset=0, montgomery=True)
             else:
                 jl = srs.msm_async(cptr + 32 * h, n=h, base_offset=0, montgomery=True)
                 jr = srs.msm_async(cptr, n=h, base_offset=h, montgomery=True)
-        with _T("fr_dot"):
-            ip_l = ctx.fr_dot(curve, cptr + 32 * h, zptr, h)
-            ip_r = ctx.fr_dot(curve, cptr, zptr + 32 * h, h)
         with _T("host_point_mul"):
-            hl = _ffi.point_mul(curve, h_prime_xy, ip_l)               # h'.mul(inner_product): one point, host
-            hr = _ffi.point_mul(curve, h_prime_xy, ip_r)
+            hl = _ffi.point_mul(curve, h_prime_xy, dots[0])            # h'.mul(inner_product): one point, host
+            hr = _ffi.point_mul(curve, h_prime_xy, dots[1])
         with _T("msm_wait"):
-            l = _ffi.points_sum(curve, np.stack([jl.wait()[0], hl]))
-            r = _ffi.points_sum(curve, np.stack([jr.wait()[0], hr]))
+            if n0 and many:
+                pts, _ = srs.msm_many(alr.data_ptr(), m=n0, n_msms=2, base_offset=0, montgomery=True)
+                ml, mr = pts[0], pts[1]
+            else:
+                ml, mr = jl.wait()[0], jr.wait()[0]
+            l = _ffi.points_sum(curve, np.stack([ml, hl]))
+            r = _ffi.points_sum(curve, np.stack([mr, hr]))
         l_vec.append(l)
         r_vec.append(r)
         u = np.ascontiguousarray(next_challenge(l, r), dtype=np.uint64)
         ui = pow(_limbs_to_int(u) * rinv % p, -1, p) * _R % p          # u^-1, Montgomery
-        with _T("fr_fold"):
-            ctx.fr_fold(curve, cptr, cptr + 32 * h, h, _int_to_limbs(ui))   # coeffs_l += u^-1 coeffs_r
-            ctx.fr_fold(curve, zptr, zptr + 32 * h, h, u)                   # z_l += u z_r
+        with _T("fold_dots"):
+            # coeffs_l += u^-1 coeffs_r, z_l += u z_r, and the next round's two inner products in the same pass
+            dots = ctx.ipa_fold_dots(curve, cptr, zptr, h, u, _int_to_limbs(ui))
         with _T("ec_fold"):
             if n0:
-                ctx.ipa_key_scalars(curve, None, 0, s_dev.data_ptr(), n0, fold_u=u, fold_m=n)   # the same fold, on the factors
+                u_prev = u                                                  # applied to the factors at the top of the next round
             else:
                 srs.ec_fold(h, u)                                           # key_l += u key_r, normalised
         if timings is not None:
             timings.setdefault("per_round_ms", []).append(round((time.perf_counter() - t_round) * 1e3, 3))
         n = h
+    if n0 and u_prev is not None:
+        ctx.ipa_key_scalars(curve, None, 0, s_dev.data_ptr(), n0, fold_u=u_prev, fold_m=2)     # the last fold (size 2)
     if n0:
         final_key = srs.msm(s_dev.data_ptr(), n=n0, base_offset=0, montgomery=True)[0]   # sum_j s_j K0_j
     else:

@@ -6,10 +6,10 @@
 //! coefficient and z vectors, `k_l += k_r * u` with one full-width scalar multiplication PER ELEMENT plus
 //! `normalize_batch`, and one Blake2s challenge.  Here the three vectors live in HBM for all rounds:
 //!   l, r          `pc_hip_msm_async` x2 on the resident key (halves addressed by `base_offset`)   `:671,674`
-//!   <c_r, z_l>..  `pc_hip_fr_dot` x2                                                               `:672,675`, `utils.rs:150-155`
+//!   <c_r, z_l>..  both inner products of a round come out of the pass that folds the vectors (`pc_hip_ipa_fold_dots`) `:672,675`
 //!   h' * <..>     `pc_hip_point_mul` (one point, host -- as in the reference)
 //!   transcript    `serialize_uncompressed` + `compute_random_oracle_challenge`: the reference's own Rust, two points a round
-//!   folds         `pc_hip_fr_fold` x2                                                               `:691-697`
+//!   folds         `pc_hip_ipa_fold_dots`: c_l += u^-1 c_r, z_l += u z_r + the next round's inner products, 64 bytes back `:691-697`
 //!   key fold      `pc_hip_ec_fold` (GLV ladder per element + batched normalisation) while n > 2^17; from there on the key
 //!                 stays FIXED and the folds act on per-base factors s_j (`pc_hip_ipa_key_scalars`): the round's MSMs run
 //!                 over the fixed key with scalars c * s, `final_comm_key = sum_j s_j K_j` is one last MSM -- the same
@@ -130,7 +130,13 @@ where
         let mut h_xy = vec![0u64; 2 * G::FQ_LIMBS];
         h_prime.write_xy(&mut h_xy);
         let fixed_below = std::env::var("PC_HIP_IPA_FIXED_KEY_BELOW").ok().and_then(|v| v.parse().ok()).unwrap_or(FIXED_KEY_BELOW);
-        let mut fixed: Option<(usize, DevicePoly, DevicePoly, DevicePoly)> = None;      // (n0, s, scalars of l, scalars of r)
+        let mut fixed: Option<(usize, DevicePoly, DevicePoly)> = None;      // (n0, s, scalars of l | scalars of r)
+        let w = 2 * G::FQ_LIMBS;
+
+        // the inner products of the first round; every later round gets its pair from the pass that folds the vectors
+        let mut dots = [[0u64; 4]; 2];
+        check(c, unsafe { ffi::pc_hip_ipa_fold_dots(c.raw, fid, coeffs.dev, z.dev, d1, core::ptr::null(), core::ptr::null(), dots.as_mut_ptr() as *mut c_void) })?;
+        let mut u_prev: Option<G::ScalarField> = None;
 
         let mut l_vec = Vec::with_capacity(log_d);
         let mut r_vec = Vec::with_capacity(log_d);
@@ -140,35 +146,39 @@ where
             if fixed.is_none() && n <= fixed_below {
                 let s = DevicePoly::alloc(n)?;
                 check(c, unsafe { ffi::pc_hip_fr_powers(c.raw, fid, limbs(&G::ScalarField::one()).as_ptr() as *const c_void, n, s.dev) })?;   // s = (1, 1, ...)
-                fixed = Some((n, s, DevicePoly::alloc(n)?, DevicePoly::alloc(n)?));
+                fixed = Some((n, s, DevicePoly::alloc(2 * n)?));
+                u_prev = None;                      // the key itself carries every fold so far
             }
             // l = cm_commit(key_l, coeffs_r) + h' * <coeffs_r, z_l>;  r = cm_commit(key_r, coeffs_l) + h' * <coeffs_l, z_r>   (:671-675)
-            let w = 2 * G::FQ_LIMBS;
-            let (mut l_xy, mut r_xy) = (vec![0u64; w], vec![0u64; w]);
-            let (mut l_inf, mut r_inf) = (0i32, 0i32);
+            let mut lr_xy = vec![0u64; 2 * w];
+            let mut lr_inf = [0i32; 2];
             let (mut jl, mut jr) = (core::ptr::null_mut(), core::ptr::null_mut());
-            if let Some((n0, s, al, ar)) = fixed.as_ref() {
-                check(c, unsafe { ffi::pc_hip_ipa_key_scalars(c.raw, fid, coeffs.dev, n, s.dev, *n0, core::ptr::null(), 0, al.dev, ar.dev) })?;
-                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, al.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
-                                                        l_xy.as_mut_ptr() as *mut c_void, &mut l_inf, &mut jl) })?;
-                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, ar.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
-                                                        r_xy.as_mut_ptr() as *mut c_void, &mut r_inf, &mut jr) })?;
+            let (lp, rp) = lr_xy.split_at_mut(w);
+            let rc = if let Some((n0, s, alr)) = fixed.as_ref() {
+                // fold of the factors by the previous challenge (size 2n) + this round's scalar vectors in one call, then the two
+                // commitments on two pipelines of the fixed key
+                let (fu, fm) = match u_prev.as_ref() { Some(u) => (limbs(u), 2 * n), None => ([0u64; 4], 0) };
+                check(c, unsafe { ffi::pc_hip_ipa_key_scalars(c.raw, fid, coeffs.dev, n, s.dev, *n0, if fm != 0 { fu.as_ptr() as *const c_void } else { core::ptr::null() }, fm,
+                                                              alr.dev, alr.at(*n0)) })?;
+                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, alr.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
+                                                        lp.as_mut_ptr() as *mut c_void, &mut lr_inf[0], &mut jl) })?;
+                unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, alr.at(*n0), ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
+                                               rp.as_mut_ptr() as *mut c_void, &mut lr_inf[1], &mut jr) }
             } else {
                 check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, coeffs.at(h), ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
-                                                        l_xy.as_mut_ptr() as *mut c_void, &mut l_inf, &mut jl) })?;
-                check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, h, coeffs.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
-                                                        r_xy.as_mut_ptr() as *mut c_void, &mut r_inf, &mut jr) })?;
-            }
-            let (mut ip_l, mut ip_r) = ([0u64; 4], [0u64; 4]);
-            check(c, unsafe { ffi::pc_hip_fr_dot(c.raw, fid, coeffs.at(h), z.dev, h, ip_l.as_mut_ptr() as *mut c_void) })?;
-            check(c, unsafe { ffi::pc_hip_fr_dot(c.raw, fid, coeffs.dev, z.at(h), h, ip_r.as_mut_ptr() as *mut c_void) })?;
-            let (mut hl, mut hr) = (vec![0u64; w], vec![0u64; w]);
-            check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, ip_l.as_ptr() as *const c_void, hl.as_mut_ptr() as *mut c_void) })?;
-            check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, ip_r.as_ptr() as *const c_void, hr.as_mut_ptr() as *mut c_void) })?;
-            check(c, unsafe { ffi::pc_hip_job_wait(c.raw, jl) })?;
+                                                        lp.as_mut_ptr() as *mut c_void, &mut lr_inf[0], &mut jl) })?;
+                unsafe { ffi::pc_hip_msm_async(c.raw, key, h, coeffs.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
+                                               rp.as_mut_ptr() as *mut c_void, &mut lr_inf[1], &mut jr) }
+            };
+            let w1 = unsafe { ffi::pc_hip_job_wait(c.raw, jl) };                          // always reap the queued job
+            check(c, rc)?;
+            check(c, w1)?;
             check(c, unsafe { ffi::pc_hip_job_wait(c.raw, jr) })?;
-            let l = (G::read_xy(&l_xy).into_group() + G::read_xy(&hl).into_group()).into_affine();     // normalize_batch(&[l, r]) (:677)
-            let r = (G::read_xy(&r_xy).into_group() + G::read_xy(&hr).into_group()).into_affine();
+            let (mut hl, mut hr) = (vec![0u64; w], vec![0u64; w]);
+            check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, dots[0].as_ptr() as *const c_void, hl.as_mut_ptr() as *mut c_void) })?;
+            check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, dots[1].as_ptr() as *const c_void, hr.as_mut_ptr() as *mut c_void) })?;
+            let l = (G::read_xy(&lr_xy[..w]).into_group() + G::read_xy(&hl).into_group()).into_affine();     // normalize_batch(&[l, r]) (:677)
+            let r = (G::read_xy(&lr_xy[w..]).into_group() + G::read_xy(&hr).into_group()).into_affine();
             l_vec.push(l);
             r_vec.push(r);
 
@@ -180,19 +190,22 @@ where
             round_challenge = Self::compute_random_oracle_challenge(byte_vec.as_slice());
             let round_challenge_inv = round_challenge.inverse().unwrap();
 
-            check(c, unsafe { ffi::pc_hip_fr_fold(c.raw, fid, coeffs.dev, coeffs.at(h), h, limbs(&round_challenge_inv).as_ptr() as *const c_void) })?;   // :691-693
-            check(c, unsafe { ffi::pc_hip_fr_fold(c.raw, fid, z.dev, z.at(h), h, limbs(&round_challenge).as_ptr() as *const c_void) })?;                  // :695-697
-            if let Some((n0, s, _, _)) = fixed.as_ref() {                                                                                                  // :699-707
-                check(c, unsafe { ffi::pc_hip_ipa_key_scalars(c.raw, fid, core::ptr::null(), 0, s.dev, *n0, limbs(&round_challenge).as_ptr() as *const c_void, n,
-                                                              core::ptr::null_mut(), core::ptr::null_mut()) })?;
+            // coeffs_l += u^-1 coeffs_r, z_l += u z_r (:691-697) and the next round's two inner products, one pass, 64 bytes back
+            check(c, unsafe { ffi::pc_hip_ipa_fold_dots(c.raw, fid, coeffs.dev, z.dev, h, limbs(&round_challenge).as_ptr() as *const c_void,
+                                                        limbs(&round_challenge_inv).as_ptr() as *const c_void, dots.as_mut_ptr() as *mut c_void) })?;
+            if fixed.is_some() {                                                                                                                           // :699-707
+                u_prev = Some(round_challenge);             // applied to the factors at the top of the next round
             } else {
                 check(c, unsafe { ffi::pc_hip_ec_fold(c.raw, key, h, limbs(&round_challenge).as_ptr() as *const c_void) })?;
             }
             n = h;
         }
-        let w = 2 * G::FQ_LIMBS;
         let mut fk = vec![0u64; w];
-        if let Some((n0, s, _, _)) = fixed.as_ref() {
+        if let Some((n0, s, _)) = fixed.as_ref() {
+            if let Some(u) = u_prev.as_ref() {      // the last fold (size 2)
+                check(c, unsafe { ffi::pc_hip_ipa_key_scalars(c.raw, fid, core::ptr::null(), 0, s.dev, *n0, limbs(u).as_ptr() as *const c_void, 2,
+                                                              core::ptr::null_mut(), core::ptr::null_mut()) })?;
+            }
             let mut inf = 0i32;
             check(c, unsafe { ffi::pc_hip_msm(c.raw, key, 0, s.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0, fk.as_mut_ptr() as *mut c_void, &mut inf) })?;
         } else {
