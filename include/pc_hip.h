@@ -66,13 +66,25 @@ void pc_hip_srs_free(pc_srs* srs);
  * then the points, compressed or not -- which is how kzg10::UniversalParams begins (its CanonicalSerialize writes
  * powers_of_g first: poly-commit/src/kzg10/data_structures.rs:57-77; deserialisation :80-112) and what an IPA key is
  * (ipa_pc/data_structures.rs:17-36).  At most max_points points (0 = all) are decoded ON THE DEVICE (compressed points:
- * y = (x^3 + b)^((p+1)/4), BLS12-381 and BN254) into a resident SRS; *out_bytes_consumed = 8 + len * point size, where
- * the next field of the structure starts.  Every decoded point is checked to be on the curve (PC_ERR_INVALID_ARG
+ * y = (x^3 + b)^((p+1)/4) for BLS12-381 and BN254) into a resident SRS; *out_bytes_consumed = 8 + len * point size, where
+ * the next field of the structure starts.  Pallas (p = 1 mod 2^32) takes its square roots by Tonelli-Shanks.  Every decoded point is checked to be on the curve (PC_ERR_INVALID_ARG
  * otherwise); the subgroup check of Validate::Yes is the verifier-side `check()` and is not repeated here.
  * Point encodings: host/transcript.hpp / csrc/serialize.hpp (ark-ec's generic short-Weierstrass flags; the zcash
  * encoding for BLS12-381). */
 int pc_hip_srs_load_serialized(pc_ctx* ctx, pc_curve curve, const void* bytes, size_t n_bytes, int compressed,
                                size_t max_points, pc_srs** out, size_t* out_points, size_t* out_bytes_consumed);
+/* The inverse: `count` resident points from `offset` on as the ark-serialize image of a Vec<G1Affine> (u64 LE length, then the
+ * points, compressed or not; encoded on the device) -- what CanonicalSerialize writes for `powers_of_g` (kzg10/data_structures.rs:
+ * 57-63) or an IPA `comm_key`.  *out_written = 8 + count * point size, also when out_bytes_host is NULL (size query) . */
+int pc_hip_srs_serialize(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, int compressed, void* out_bytes_host,
+                         size_t capacity, size_t* out_written);
+/* Byte layout of a serialized kzg10::UniversalParams (host only, nothing is decoded): CanonicalSerialize writes powers_of_g:
+ * Vec<G1Affine>, powers_of_gamma_g: BTreeMap<usize, G1Affine>, h, beta_h: G2Affine, neg_powers_of_h: BTreeMap<usize, G2Affine>
+ * in this order (kzg10/data_structures.rs:57-77; deserialisation :80-112).  out = {offset of powers_of_g, its length, offset of
+ * powers_of_gamma_g, its length, offset of h, offset of beta_h, offset of neg_powers_of_h, its length, total bytes}; offsets
+ * point at the u64 length prefixes (map entries: u64 LE key, then the point).  The committer's half goes to the device with
+ * pc_hip_srs_load_serialized(bytes + out[0]); the G2 fields stay with the verifier-side Rust.  BLS12-381 and BN254. */
+int pc_hip_universal_params_layout(pc_curve curve, const void* bytes, size_t n_bytes, int compressed, size_t out[9]);
 /* Optional, once per committer key (same place as the upload, i.e. `trim`): build the window
  * table T[w][i] = 2^(c w) * bases[i] in HBM, (bits/c + 1) x the size of the SRS (BLS12-381: every 96-byte point in its
  * own 128-byte line, so 4/3 of that: 25.8 GB for 2^24 points at c = 22; PC_HIP_TBL_PAD=0 packs them).  MSMs of at least

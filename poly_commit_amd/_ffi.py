@@ -55,6 +55,8 @@ def load_library():
     lib.pc_hip_last_error.restype = C.c_char_p
     lib.pc_hip_srs_upload.argtypes = [vp, ip, vp, sz, sz, ip, C.POINTER(vp)]
     lib.pc_hip_srs_load_serialized.argtypes = [vp, ip, vp, sz, ip, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    lib.pc_hip_srs_serialize.argtypes = [vp, vp, sz, sz, ip, vp, sz, C.POINTER(sz)]
+    lib.pc_hip_universal_params_layout.argtypes = [ip, vp, sz, ip, C.POINTER(sz)]
     lib.pc_hip_srs_free.argtypes = [vp]
     lib.pc_hip_srs_precompute.argtypes = [vp, vp, C.c_uint, sz]
     lib.pc_hip_srs_free.restype = None
@@ -441,6 +443,15 @@ class Srs:
         """A second resident copy (device-to-device): what a destructive consumer -- the IPA key fold -- works on."""
         return Srs(self.ctx, self.curve, self.device_ptr(), n=self.n)
 
+    def serialize(self, offset=0, count=None, compressed=False):
+        """ark-serialize bytes of resident points as a Vec<G1Affine> (pc_hip_srs_serialize)."""
+        count = self.n - offset if count is None else count
+        need = C.c_size_t()
+        self.ctx.check(self.ctx.lib.pc_hip_srs_serialize(self.ctx.h, self.h, offset, count, 1 if compressed else 0, None, 0, C.byref(need)))
+        buf = (C.c_char * need.value)()
+        self.ctx.check(self.ctx.lib.pc_hip_srs_serialize(self.ctx.h, self.h, offset, count, 1 if compressed else 0, buf, need.value, C.byref(need)))
+        return bytes(buf)
+
     def read(self, offset, count):
         out = np.zeros((count, 2 * FQ_BYTES[self.curve] // 8), dtype=np.uint64)
         self.ctx.check(self.ctx.lib.pc_hip_srs_read(self.ctx.h, self.h, offset, count, C.c_void_p(out.ctypes.data)))
@@ -475,6 +486,18 @@ class MsmJob:
             self.phases = ctx.last_msm_phases_ms()
             self.marks = ctx.last_msm_marks_ms()
         return self.out, bool(self.inf.value)
+
+
+def universal_params_layout(curve, data, compressed):
+    """Field offsets of a serialized kzg10::UniversalParams (pc_hip_universal_params_layout)."""
+    lib = load_library()
+    out = (C.c_size_t * 9)()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    rc = lib.pc_hip_universal_params_layout(CURVES[curve], buf, len(data), 1 if compressed else 0, out)
+    if rc != 0:
+        raise PcHipError(rc, lib.pc_hip_strerror(rc).decode())
+    keys = ("powers_of_g", "n_powers_of_g", "powers_of_gamma_g", "n_powers_of_gamma_g", "h", "beta_h", "neg_powers_of_h", "n_neg_powers_of_h", "total")
+    return dict(zip(keys, list(out)))
 
 
 def points_sum(curve, points):

@@ -279,7 +279,6 @@ int pc_hip_srs_load_serialized(pc_ctx* ctx, pc_curve curve, const void* bytes, s
   if (!ctx || !out || !bytes || (int)curve < 0 || (int)curve > 2) return PC_ERR_INVALID_ARG;
   *out = nullptr;
   if (n_bytes < 8) return PC_ERR_INVALID_ARG;
-  if (compressed && curve == PC_CURVE_PALLAS) return PC_ERR_UNSUPPORTED;      // p = 1 (mod 4): no (p+1)/4 square root
   const size_t fb = (size_t)fq_bytes(curve);
   const size_t bits = curve == PC_CURVE_BLS12_381 ? 381 : curve == PC_CURVE_BN254 ? 254 : 255;
   const size_t yb = (bits + 2 + 7) / 8;
@@ -304,6 +303,59 @@ int pc_hip_srs_load_serialized(pc_ctx* ctx, pc_curve curve, const void* bytes, s
   (void)guarded(ctx, [&]() { ctx->be.free(raw); ctx->be.free(pts); return (int)PC_OK; });
   if (rc == PC_OK) { if (out_points) *out_points = n; if (out_bytes_consumed) *out_bytes_consumed = 8 + (size_t)len * pbytes; }
   return rc;
+}
+
+static size_t g1_point_bytes(pc_curve curve, int compressed) {
+  const size_t fb = (size_t)fq_bytes(curve);
+  const size_t bits = curve == PC_CURVE_BLS12_381 ? 381 : curve == PC_CURVE_BN254 ? 254 : 255;
+  const size_t yb = (bits + 2 + 7) / 8;
+  return curve == PC_CURVE_BLS12_381 ? (compressed ? fb : 2 * fb) : (compressed ? yb : fb + yb);
+}
+
+int pc_hip_srs_serialize(pc_ctx* ctx, const pc_srs* srs, size_t offset, size_t count, int compressed, void* out_bytes_host, size_t capacity,
+                         size_t* out_written) {
+  if (!ctx || !srs || srs->ctx != ctx || offset > srs->n || count > srs->n - offset || !out_written) return PC_ERR_INVALID_ARG;
+  const size_t pbytes = g1_point_bytes(srs->curve, compressed), need = 8 + count * pbytes;
+  *out_written = need;
+  if (!out_bytes_host || capacity < need) return out_bytes_host ? PC_ERR_INVALID_ARG : PC_OK;      // NULL buffer: size query
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    const uint64_t len = count;
+    memcpy(out_bytes_host, &len, 8);                                                                // Vec<T>: u64 little-endian length
+    if (!count) return (int)PC_OK;
+    void* dev = ctx->be.alloc(count * pbytes);
+    try {
+      pc::curve_ops(srs->curve).srs_encode(ctx->be, srs->bases + offset * (size_t)srs->aw, count, compressed, (uint8_t*)dev);
+      ctx->be.copy_d2h((char*)out_bytes_host + 8, dev, count * pbytes);
+    } catch (...) { ctx->be.free(dev); throw; }
+    ctx->be.free(dev);
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_universal_params_layout(pc_curve curve, const void* bytes, size_t n_bytes, int compressed, size_t out[9]) {
+  // kzg10::UniversalParams, CanonicalSerialize order (kzg10/data_structures.rs:57-77):
+  //   powers_of_g: Vec<G1Affine> | powers_of_gamma_g: BTreeMap<usize, G1Affine> | h: G2Affine | beta_h: G2Affine |
+  //   neg_powers_of_h: BTreeMap<usize, G2Affine>        (Vec / BTreeMap: u64 LE length first; map entries: u64 LE key, value)
+  if (!bytes || !out || ((int)curve != PC_CURVE_BLS12_381 && (int)curve != PC_CURVE_BN254)) return PC_ERR_INVALID_ARG;   // pairing curves only
+  const size_t g1 = g1_point_bytes(curve, compressed);
+  // G2 over Fq2: BLS12-381 (zcash): 96 / 192 bytes; BN254 (generic SW over Fq2, flags in the spare bits of the last byte): 64 / 128
+  const size_t g2 = curve == PC_CURVE_BLS12_381 ? (compressed ? 96 : 192) : (compressed ? 64 : 128);
+  const uint8_t* p = (const uint8_t*)bytes;
+  size_t at = 0;
+  auto take_len = [&](uint64_t& v) { if (n_bytes - at < 8) return false; memcpy(&v, p + at, 8); at += 8; return true; };
+  uint64_t n_g = 0, n_gg = 0, n_neg = 0;
+  out[0] = at; if (!take_len(n_g) || n_g > (n_bytes - at) / g1) return PC_ERR_INVALID_ARG;
+  out[1] = (size_t)n_g; at += (size_t)n_g * g1;
+  out[2] = at; if (!take_len(n_gg) || n_gg > (n_bytes - at) / (8 + g1)) return PC_ERR_INVALID_ARG;
+  out[3] = (size_t)n_gg; at += (size_t)n_gg * (8 + g1);
+  if (n_bytes - at < 2 * g2) return PC_ERR_INVALID_ARG;
+  out[4] = at; at += g2;                                   // h
+  out[5] = at; at += g2;                                   // beta_h
+  out[6] = at; if (!take_len(n_neg) || n_neg > (n_bytes - at) / (8 + g2)) return PC_ERR_INVALID_ARG;
+  out[7] = (size_t)n_neg; at += (size_t)n_neg * (8 + g2);
+  out[8] = at;                                             // total size of the structure
+  return PC_OK;
 }
 
 void pc_hip_srs_free(pc_srs* srs) {

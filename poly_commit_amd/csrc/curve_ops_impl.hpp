@@ -194,6 +194,10 @@ struct CurveOpsImpl {
     uint32_t h = 0; be.copy_d2h(&h, bad, 4);
     return h;
   }
+  static void srs_encode(HipBackend& be, const uint32_t* pts_dev, size_t n, int compressed, uint8_t* out_dev) {
+    SrsEncodeBody<C> b{pts_dev, (uint32_t)n, compressed ? 1u : 0u, C::FqP::BITS == 381 ? 1u : 0u, out_dev};
+    be.launch(b, n, 64);
+  }
   static void points_sum(const uint32_t* pts, size_t count, uint32_t* out) {
     XyzzD<C> acc = XyzzD<C>::infinity();
     for (size_t i = 0; i < count; i++) acc.add_affine(AffD<C>::load(pts + i * AW));
@@ -214,7 +218,7 @@ struct CurveOpsImpl {
     acc.store_affine(out);
   }
   static CurveOps table() {
-    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &fixed_base, &srs_decode, &points_sum, &point_mul};
+    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &fixed_base, &srs_decode, &srs_encode, &points_sum, &point_mul};
   }
 };
 

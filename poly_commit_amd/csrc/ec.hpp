@@ -82,6 +82,32 @@ struct XyzzD {
     X = X3;
     ZZ = ZZ.mul(PP); ZZZ = ZZZ.mul(PPP);
   }
+  // The same mixed addition with LAZY coordinates (fp32.hpp, LAZY_OK): X, Y, ZZ, ZZZ stay in [0, 2p) between additions and
+  // none of the nine multiplier calls ends in a conditional subtraction; the affine operand is canonical, its negation
+  // (`negate`: the sign of the signed digit) is p - y without a zero special case.  Infinity stays the exact ZZ == 0: a
+  // product ZZ * PP = 0 (mod p) needs P = 0 (mod p), which takes the branch below.  `canonical()` where the sum leaves the
+  // chain (bucket store, partial list).
+  PC_HD void add_affine_lz(const AffD<C>& a, bool negate) {
+    if (a.is_inf()) return;
+    const Fq ay = negate ? a.y.neg_lz_canonical() : a.y;
+    if (is_inf()) { X = a.x; Y = ay; ZZ = Fq::one(); ZZZ = Fq::one(); return; }
+    Fq U2 = a.x.mul_lz(ZZ), S2 = ay.mul_lz(ZZZ);
+    Fq Pp = U2.sub_lz(X), R = S2.sub_lz(Y);
+    if (Pp.is_zero_lz()) {             // same x: doubling or P + (-P) -- the canonical code (rare)
+      XyzzD t = canonical();
+      AffD<C> b; b.x = a.x; b.y = ay.canon();
+      t.add_affine(b);
+      *this = t;
+      return;
+    }
+    Fq PP = Pp.sqr_lz(), PPP = Pp.mul_lz(PP), Q = X.mul_lz(PP);
+    Fq X3 = R.sqr_lz().sub_lz(PPP).sub_lz(Q.dbl_lz());
+    Y = R.mul_add_mul_lz(Q.sub_lz(X3), Y.neg_lz(), PPP);      // R (Q - X3) + (2p - Y) PPP <= 8 p^2: one reduction, below 2p
+    X = X3;
+    ZZ = ZZ.mul_lz(PP); ZZZ = ZZZ.mul_lz(PPP);
+  }
+  // (every coordinate of a lazy sum is a multiplier output, a sub_lz result or a canonical input: strictly below 2p)
+  PC_HD XyzzD canonical() const { XyzzD r; r.X = X.canon1(); r.Y = Y.canon1(); r.ZZ = ZZ.canon1(); r.ZZZ = ZZZ.canon1(); return r; }
   // this += o (add-2008-s), all special cases handled.
   PC_HD void add(const XyzzD& o) {
     if (o.is_inf()) return;

@@ -194,7 +194,7 @@ struct Fd {
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) column_hi<K + 1, UNIT>(o, m, mod, acc, hi, t);
   }
-  template <bool UNIT>
+  template <bool UNIT, bool REDUCE = true>
   __device__ __forceinline__ Fd mul_impl(const Fd& o) const {
     uint32_t m[N], t[N + 1];
     uint32_t mod[N];
@@ -204,12 +204,16 @@ struct Fd {
     column_hi<N, UNIT>(o, m, mod, acc, hi, t);
     Fd r;
     PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
-    cond_sub(r.l, (uint32_t)acc);
+    if constexpr (REDUCE) cond_sub(r.l, (uint32_t)acc);
     return r;
   }
   __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
   __device__ __forceinline__ Fd sqr() const { return sqr_inl(); }
   __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl(b, c, d); }
+  // Lazy forms (see LAZY_OK below): operands in [0, 2p], no final conditional subtraction, result in [0, 2p)
+  __device__ __forceinline__ Fd mul_lz(const Fd& o) const { return mul_impl<false, false>(o); }
+  __device__ __forceinline__ Fd sqr_lz() const { return sqr_inl<false>(); }
+  __device__ __forceinline__ Fd mul_add_mul_lz(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl<false>(b, c, d); }
   // (the three products as real functions -- operands by value, in registers -- were measured against the ~50 KB of
   // inlined code of a mixed addition: accumulate 36.8 -> 44.0 ms; the instruction cache is not what limits it)
 
@@ -244,6 +248,7 @@ struct Fd {
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) dual_column_hi<K + 1>(b, c, d, m, mod, acc, hi, t);
   }
+  template <bool REDUCE = true>
   __device__ __forceinline__ Fd mul_add_mul_inl(const Fd& b, const Fd& c, const Fd& d) const {
     static_assert(P::BITS < 32 * N, "the fused pair assumes 2 p <= R");
     uint32_t m[N], t[N + 1], mod[N];
@@ -253,7 +258,7 @@ struct Fd {
     dual_column_hi<N>(b, c, d, m, mod, acc, hi, t);
     Fd r;
     PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
-    cond_sub(r.l, (uint32_t)acc);
+    if constexpr (REDUCE) cond_sub(r.l, (uint32_t)acc);
     return r;
   }
 
@@ -293,8 +298,10 @@ struct Fd {
     acc = (acc >> 32) | ((uint64_t)hi << 32);
     if constexpr (K + 1 < 2 * N) sq_column_hi<K + 1>(d, dm, m, mod, acc, hi, t);
   }
+  template <bool REDUCE = true>
   __device__ __forceinline__ Fd sqr_inl() const {
     static_assert(P::BITS < 32 * N, "squaring assumes that 2a fits N limbs");
+    static_assert(REDUCE || P::BITS + 2 <= 32 * N, "the lazy squaring doubles operands up to 2p: 4p must fit N limbs");
     uint32_t d[N], dm[N], m[N], t[N + 1], mod[N];
     PC_UNROLL for (int i = 0; i < N; i++) { mod[i] = P::MOD[i]; d[i] = (l[i] << 1) | (i ? l[i - 1] >> 31 : 0u); dm[i] = l[i] << 1; }
     uint64_t acc = 0; uint32_t hi = 0;
@@ -302,7 +309,7 @@ struct Fd {
     sq_column_hi<N>(d, dm, m, mod, acc, hi, t);
     Fd r;
     PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
-    cond_sub(r.l, (uint32_t)acc);
+    if constexpr (REDUCE) cond_sub(r.l, (uint32_t)acc);
     return r;
   }
 #else
@@ -339,7 +346,71 @@ struct Fd {
 #if !defined(__HIP_DEVICE_COMPILE__)
   PC_HD Fd sqr() const { return mul(*this); }
   PC_HD Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul(b).add(c.mul(d)); }
+  // host: the CIOS multiplier canonicalises inputs below 2p as well (its result before the subtraction is below 2p), and a
+  // canonical value is a valid lazy one
+  PC_HD Fd mul_lz(const Fd& o) const { return mul(o); }
+  PC_HD Fd sqr_lz() const { return mul(*this); }
+  PC_HD Fd mul_add_mul_lz(const Fd& b, const Fd& c, const Fd& d) const { return canon().mul(b.canon()).add(c.canon().mul(d.canon())); }
 #endif
+
+  // ---- lazy reduction (Walter's bound) ---------------------------------------------------------------------------
+  // With R >= 8p a Montgomery product of operands in [0, 2p] is below (4p^2 + pR)/R < 2p WITHOUT the final conditional
+  // subtraction, and so is the fused a*b + c*d ((8p^2 + pR)/R < 2p): inside a long chain of multiplications (the mixed
+  // addition of the bucket accumulation: 9 multiplier calls) values are kept in [0, 2p) and canonicalised only where they
+  // leave the chain.  Additive operations then work modulo 2p.  R >= 8p holds for BLS12-381 Fq (381 + 3 <= 384); BN254 /
+  // Pallas (254 / 255 bits in 256) do not qualify and keep the canonical path.
+  static constexpr bool LAZY_OK = P::BITS + 3 <= 32 * N;
+  static PC_HD uint32_t mod2(int i) { return (P::MOD[i] << 1) | (i ? P::MOD[i - 1] >> 31 : 0u); }      // limbs of 2p
+  // (a - b) mod 2p for a, b in [0, 2p]: in [0, 2p] (in [0, 2p) when a < 2p)
+  PC_HD Fd sub_lz(const Fd& o) const {
+    Fd r; uint32_t br = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = sbb(l[i], o.l[i], br);
+    const uint32_t mask = (uint32_t)0 - br;
+    uint32_t c = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = adc(r.l[i], mod2(i) & mask, c);
+    return r;
+  }
+  // 2 (a) mod 2p-representation: a in [0, 2p) -> [0, 2p)
+  PC_HD Fd dbl_lz() const {
+    Fd r; uint32_t c = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = adc(l[i], l[i], c);
+    uint32_t d[N]; uint32_t br = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) d[i] = sbb(r.l[i], mod2(i), br);
+    const bool ge = br == 0;                     // 4p < 2^(32 N): no carry word
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = ge ? d[i] : r.l[i];
+    return r;
+  }
+  // 2p - a in [0, 2p] (no special case for zero: 2p is a valid representative of it)
+  PC_HD Fd neg_lz() const {
+    Fd r; uint32_t br = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = sbb(mod2(i), l[i], br);
+    return r;
+  }
+  // p - a for a canonical a (table points): in (0, p]
+  PC_HD Fd neg_lz_canonical() const {
+    Fd r; uint32_t br = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) r.l[i] = sbb(P::MOD[i], l[i], br);
+    return r;
+  }
+  // value = 0 (mod p) for a value in [0, 2p]
+  PC_HD bool is_zero_lz() const {
+    uint32_t z = 0, e1 = 0, e2 = 0;
+    PC_UNROLL for (int i = 0; i < N; i++) { z |= l[i]; e1 |= l[i] ^ P::MOD[i]; e2 |= l[i] ^ mod2(i); }
+    return z == 0 || e1 == 0 || e2 == 0;
+  }
+  // [0, 2p) -> [0, p): one conditional subtraction (multiplier outputs and sub_lz results are strictly below 2p)
+  PC_HD Fd canon1() const {
+    Fd r = *this;
+    cond_sub(r.l, 0);
+    return r;
+  }
+  // [0, 2p] -> [0, p)
+  PC_HD Fd canon() const {
+    Fd r = *this;
+    cond_sub(r.l, 0);
+    cond_sub(r.l, 0);          // (only 2p itself needs the second one)
+    return r;
+  }
 
   // Montgomery <-> canonical
   PC_HD Fd from_mont() const {   // multiply by raw 1 => a * R^-1

@@ -220,7 +220,11 @@ struct AccumulateBody {
   uint32_t* pkeys;           // 2 slots per lane
   uint32_t* ppts;            // 2 x Pt::WORDS per lane
   // complete: the whole run [offsets[k], offsets[k+1]) lies inside this lane's chunk
-  PC_HD void flush(const Pt& acc, uint32_t k, bool complete, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
+  // the running sum is kept with lazily reduced coordinates where the field allows it (ec.hpp, add_affine_lz): canonical
+  // again wherever it leaves the lane
+  static constexpr bool LAZY = Pt::Fq::LAZY_OK;
+  PC_HD void flush(const Pt& acc_lz, uint32_t k, bool complete, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
+    const Pt acc = LAZY ? acc_lz.canonical() : acc_lz;
     if (complete) { acc.store(buckets + (size_t)k * Pt::WORDS); return; }
     uint32_t slot = first ? 2 * t : 2 * t + 1;
     acc.store(ppts + (size_t)slot * Pt::WORDS);
@@ -267,11 +271,11 @@ struct AccumulateBody {
         uint32_t nnval = nval; AffD<C> npt = pt;
         if (p + 1 < e) npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride);
         if (p + 2 < e) nnval = entries[p + 2];
-        acc.add_affine(pt.neg_if(val >> 31));
+        if constexpr (LAZY) acc.add_affine_lz(pt, (val >> 31) != 0); else acc.add_affine(pt.neg_if(val >> 31));
         val = nval; nval = nnval; pt = npt;
       }
       flush(acc, k, run_lo >= s && boundary <= e, t, first, k0, k1);
-      last = acc;
+      last = LAZY ? acc.canonical() : acc;
     }
   }
   PC_HD void operator()(uint32_t t) const {

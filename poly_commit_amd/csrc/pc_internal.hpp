@@ -40,6 +40,8 @@ struct CurveOps {
   void (*fixed_base)(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out);
   // ark-serialize bytes of n points (device) -> n resident affine points; returns the number of invalid points
   uint32_t (*srs_decode)(HipBackend& be, const uint8_t* bytes_dev, size_t n, int compressed, uint32_t* out);
+  // n resident affine points -> their ark-serialize bytes (device buffers)
+  void (*srs_encode)(HipBackend& be, const uint32_t* pts_dev, size_t n, int compressed, uint8_t* out_dev);
   // host-side helpers (a handful of points, as the reference does on the host)
   void (*points_sum)(const uint32_t* pts, size_t count, uint32_t* out);
   void (*point_mul)(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out);

@@ -12,7 +12,9 @@
 //   BLS12-381 G1 (zcash / IETF)
 //     uncompressed  x, y: 48 bytes big-endian each; byte 0: 0x80 clear, 0x40 infinity
 //     compressed    x: 48 bytes big-endian; byte 0: 0x80 set, 0x40 infinity, 0x20 y is the lexicographically larger root
-// Compressed points need a square root: y = (x^3 + b)^((p+1)/4), available for p = 3 (mod 4) (BLS12-381, BN254).
+// Compressed points need a square root: y = (x^3 + b)^((p+1)/4) for p = 3 (mod 4) (BLS12-381, BN254); Tonelli-Shanks with
+// the field's 2^s-th root of unity for Pallas (p = 1 mod 2^32): ~255 + up to s^2/2 squarings per point, once per key.
+// SrsEncodeBody is the inverse (resident points -> ark-serialize bytes): what CanonicalSerialize writes for a Vec<G1Affine>.
 #pragma once
 #include "ec.hpp"
 #include "msm.hpp"
@@ -56,6 +58,36 @@ struct SrsDecodeBody {
     for (int i = FN * 32 - 1; i >= 0; i--) { r = r.sqr(); if ((e[i >> 5] >> (i & 31)) & 1) r = r.mul(a); }
     return r;
   }
+  // square root in Fq (Montgomery in, Montgomery out); false: not a quadratic residue
+  PC_HD static bool sqrt(const Fq& a, Fq& out) {
+    constexpr int S = C::FqP::TWO_ADICITY;
+    if constexpr (S == 1) {
+      out = pow_p_plus_1_over_4(a);
+      return out.sqr().eq(a);
+    } else {
+      // Tonelli-Shanks: p - 1 = 2^S t, t odd.  w = a^((t-1)/2), x = a w = a^((t+1)/2), b = x w = a^t; z = a primitive 2^S-th root.
+      if (a.is_zero()) { out = Fq::zero(); return true; }
+      uint32_t e[FN];            // (p - 1) >> (S + 1) = (t - 1) / 2
+      { uint64_t br = 1; for (int i = 0; i < FN; i++) { const uint64_t t = (uint64_t)C::FqP::MOD[i] - br; e[i] = (uint32_t)t; br = t >> 63; } }
+      for (int sh = 0; sh < S + 1; sh++) for (int i = 0; i < FN; i++) e[i] = (e[i] >> 1) | (i + 1 < FN ? e[i + 1] << 31 : 0u);
+      Fq w = Fq::one();
+      for (int i = FN * 32 - 1; i >= 0; i--) { w = w.sqr(); if ((e[i >> 5] >> (i & 31)) & 1) w = w.mul(a); }
+      Fq x = a.mul(w), b = x.mul(w), z;
+      for (int i = 0; i < FN; i++) z.l[i] = C::FqP::ROOT[i];
+      const Fq one = Fq::one();
+      int m = S;
+      while (!b.eq(one)) {
+        int k = 0; Fq t2 = b;
+        while (k < m && !t2.eq(one)) { t2 = t2.sqr(); k++; }       // least k with b^(2^k) = 1
+        if (k >= m) return false;                                  // b has order 2^m: a is not a square
+        Fq wz = z;
+        for (int j = 0; j < m - k - 1; j++) wz = wz.sqr();
+        x = x.mul(wz); z = wz.sqr(); b = b.mul(z); m = k;
+      }
+      out = x;
+      return true;
+    }
+  }
   PC_HD void operator()(uint32_t i) const {
     const uint32_t pbytes = point_bytes(compressed != 0, zcash != 0);
     const uint8_t* p = in + (size_t)i * pbytes;
@@ -78,8 +110,8 @@ struct SrsDecodeBody {
       a.x = xc.to_mont();
       const Fq rhs = curve_rhs(a.x);
       if (compressed) {
-        Fq y = pow_p_plus_1_over_4(rhs);
-        ok = ok && y.sqr().eq(rhs);
+        Fq y;
+        ok = sqrt(rhs, y) && ok;
         const Fq yn = y.neg();
         const bool y_is_larger = less_than(yn.from_mont(), y.from_mont());
         a.y = (y_is_larger == want_larger) ? y : yn;
@@ -90,6 +122,45 @@ struct SrsDecodeBody {
       if (!ok) { atomic_inc_u32(bad); a = AffD<C>::infinity(); }
     }
     a.store(out + (size_t)i * AW);
+  }
+};
+
+// Resident affine points -> ark-serialize bytes (the image of SrsDecodeBody): `CanonicalSerialize` of each G1Affine of a
+// Vec (kzg10/data_structures.rs:57-77 writes `powers_of_g` this way; an IPA key, ipa_pc/data_structures.rs:17-36).
+template <class C>
+struct SrsEncodeBody {
+  typedef Fd<typename C::FqP> Fq;
+  typedef SrsDecodeBody<C> D;
+  static constexpr int FN = Fq::N, AW = 2 * FN, XB = D::XB, YB = D::YB;
+  const uint32_t* pts; uint32_t n; uint32_t compressed; uint32_t zcash; uint8_t* out;
+  PC_HD static void store_bytes(const Fq& c, uint8_t* p, uint32_t nbytes, bool big_endian) {      // canonical limbs -> bytes
+    for (uint32_t i = 0; i < nbytes; i++) {
+      const uint8_t b = i < 4u * FN ? (uint8_t)(c.l[i >> 2] >> (8 * (i & 3))) : 0;
+      p[big_endian ? nbytes - 1 - i : i] = b;
+    }
+  }
+  PC_HD void operator()(uint32_t i) const {
+    const uint32_t pbytes = D::point_bytes(compressed != 0, zcash != 0);
+    uint8_t* p = out + (size_t)i * pbytes;
+    const AffD<C> a = AffD<C>::load(pts + (size_t)i * AW);
+    for (uint32_t k = 0; k < pbytes; k++) p[k] = 0;
+    if (a.is_inf()) {                                     // x = y = 0 with the infinity flag
+      if (zcash) p[0] = compressed ? 0xc0 : 0x40; else p[pbytes - 1] = 0x40;
+      return;
+    }
+    const Fq xc = a.x.from_mont(), yc = a.y.from_mont(), ync = a.y.neg().from_mont();
+    const bool y_is_larger = D::less_than(ync, yc);       // y > -y: SWFlags::YIsNegative / the zcash sort flag
+    if (zcash) {
+      store_bytes(xc, p, XB, true);
+      if (compressed) p[0] |= 0x80 | (y_is_larger ? 0x20 : 0); else store_bytes(yc, p + XB, XB, true);
+    } else if (compressed) {
+      store_bytes(xc, p, YB, false);
+      if (y_is_larger) p[YB - 1] |= 0x80;
+    } else {
+      store_bytes(xc, p, XB, false);
+      store_bytes(yc, p + XB, YB, false);
+      if (y_is_larger) p[XB + YB - 1] |= 0x80;
+    }
   }
 };
 

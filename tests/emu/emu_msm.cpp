@@ -180,6 +180,11 @@ template <class P> static void fop(int op, const uint32_t* a, const uint32_t* b,
   switch (op) {
     case 0: r = x.mul(y); break; case 1: r = x.add(y); break; case 2: r = x.sub(y); break;
     case 3: r = x.inv(); break; case 4: r = x.neg(); break; case 5: r = x.from_mont(); break;
+    // the lazy (mod 2p) helpers of the bucket accumulation: raw outputs, inputs anywhere in [0, 2p]
+    case 10: r = x.sub_lz(y); break; case 11: r = x.dbl_lz(); break; case 12: r = x.neg_lz(); break;
+    case 13: r = x.neg_lz_canonical(); break; case 14: r = x.canon(); break;
+    case 15: r = F::zero(); r.l[0] = x.is_zero_lz() ? 1u : 0u; break;
+    case 16: r = x.mul_lz(y).canon(); break; case 17: r = x.sqr_lz().canon(); break; case 18: r = x.mul_add_mul_lz(y, y, x).canon(); break;
     default: r = x.to_mont(); break;
   }
   r.store(out);
@@ -197,6 +202,9 @@ template <class C> static void ecop(int op, const uint32_t* a, const uint32_t* b
   Pt r = Pt::from_affine(pa);
   switch (op) {
     case 0: r.add_affine(pb); break;
+    case 4: r.add_affine_lz(pb, false); r = r.canonical(); break;                      // the lazy mixed addition, both signs
+    case 5: r.add_affine_lz(pb.neg_if(true), true); r = r.canonical(); break;
+    case 6: { Pt q = Pt::from_affine(pb); q = q.dbl(); r = q; r.add_affine_lz(pa, false); r.add_affine_lz(pb, true); r = r.canonical(); } break;  // 2 Pb + Pa - Pb, lazy chain
     case 1: { Pt q = Pt::from_affine(pb); q = q.dbl(); q.add_affine(pb.neg_if(true)); r.add(q); } break;  // via full add, non-trivial ZZ
     case 2: r = r.dbl(); break;
     case 3: r = Pt::dbl_affine(pa); break;
@@ -353,6 +361,20 @@ extern "C" uint32_t emu_srs_decode(int curve, const uint8_t* in, uint32_t n, int
     case 0: return srs_decode<pc_curve_bls12_381>(in, n, compressed, out);
     case 1: return srs_decode<pc_curve_bn254>(in, n, compressed, out);
     default: return srs_decode<pc_curve_pallas>(in, n, compressed, out);
+  }
+}
+
+// affine points -> ark-serialize bytes (SrsEncodeBody), stepped
+template <class C>
+static void srs_encode(const uint32_t* pts, uint32_t n, int compressed, uint8_t* out) {
+  pc::SrsEncodeBody<C> b{pts, n, compressed ? 1u : 0u, C::FqP::BITS == 381 ? 1u : 0u, out};
+  CpuStepBackend be; be.launch(b, n);
+}
+extern "C" void emu_srs_encode(int curve, const uint32_t* pts, uint32_t n, int compressed, uint8_t* out) {
+  switch (curve) {
+    case 0: srs_encode<pc_curve_bls12_381>(pts, n, compressed, out); break;
+    case 1: srs_encode<pc_curve_bn254>(pts, n, compressed, out); break;
+    default: srs_encode<pc_curve_pallas>(pts, n, compressed, out); break;
   }
 }
 

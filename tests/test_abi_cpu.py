@@ -136,3 +136,26 @@ def test_rust_shim_ffi_declarations_match_the_header(tmp_path):
     bad.write_text(src)
     rf, _ = chk.parse_ffi_rs(str(bad))
     assert rf["pc_hip_msm"][0][2][1] == "u32" != hfuncs["pc_hip_msm"][0][2][1]
+
+
+@pytest.mark.parametrize("curve,compressed", [("bls12_381", False), ("bls12_381", True), ("bn254", False), ("bn254", True)])
+def test_universal_params_layout_host_parser(curve, compressed):
+    """pc_hip_universal_params_layout: field offsets of a serialized kzg10::UniversalParams (kzg10/data_structures.rs:57-77:
+    powers_of_g, powers_of_gamma_g (BTreeMap), h, beta_h, neg_powers_of_h (BTreeMap)); no device needed.  The G2 payloads are
+    opaque to the library, only their sizes matter."""
+    import poly_commit_amd as pc
+    pts = R.gen_bases(curve, 7)
+    g2 = {("bls12_381", True): 96, ("bls12_381", False): 192, ("bn254", True): 64, ("bn254", False): 128}[(curve, compressed)]
+    f = R.ser_point_compressed if compressed else R.ser_point
+    pg = R.ser_g1_vec(curve, pts, compressed)
+    gg = (3).to_bytes(8, "little") + b"".join(k.to_bytes(8, "little") + f(curve, pts[k]) for k in (0, 1, 2))
+    h, bh = bytes([0xA1]) * g2, bytes([0xB2]) * g2
+    neg = (2).to_bytes(8, "little") + b"".join(k.to_bytes(8, "little") + bytes([0xC3]) * g2 for k in (0, 5))
+    data = pg + gg + h + bh + neg
+    lay = pc.universal_params_layout(curve, data + b"trailing", compressed)
+    assert lay == dict(powers_of_g=0, n_powers_of_g=7, powers_of_gamma_g=len(pg), n_powers_of_gamma_g=3, h=len(pg) + len(gg),
+                       beta_h=len(pg) + len(gg) + g2, neg_powers_of_h=len(pg) + len(gg) + 2 * g2, n_neg_powers_of_h=2, total=len(data))
+    with pytest.raises(pc.PcHipError):
+        pc.universal_params_layout(curve, data[:len(pg) + len(gg) + g2], compressed)       # truncated inside beta_h
+    with pytest.raises(pc.PcHipError):
+        pc.universal_params_layout("pallas", data, compressed)                              # not a pairing curve

@@ -64,6 +64,39 @@ def test_field_ops_32bit_vs_bigint(curve):
                 assert got == want, (fname, op, a, b)
 
 
+def test_lazy_reduction_helpers_bls12_381_fq():
+    """The mod-2p helpers behind the lazily reduced bucket accumulation (fp32.hpp LAZY_OK: BLS12-381 Fq only), on inputs
+    anywhere in [0, 2p] including the boundary representatives 0, p, 2p."""
+    fname = "bls12_381_fq"
+    p = R.FIELDS[fname]["p"]
+    n64 = 6
+    Rm = 1 << 384
+    Ri = pow(Rm, -1, p)
+    rnd = random.Random(11)
+    vals = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p] + [rnd.randrange(2 * p + 1) for _ in range(30)]
+
+    def run(op, a, b=0):
+        A, B = O.ints_to_limbs([a], n64)[0], O.ints_to_limbs([b], n64)[0]
+        out = np.zeros(n64, dtype=np.uint64)
+        emu().emu_fop(0, 0, op, p32(A.view(np.uint32)), p32(B.view(np.uint32)), p32(out.view(np.uint32)))
+        return O.limbs_to_ints(out.reshape(1, -1))[0]
+    for a in vals:
+        assert run(14, a) == a % p                                        # canon
+        assert run(15, a) == (1 if a % p == 0 else 0)                     # is_zero_lz
+        assert run(12, a) == 2 * p - a                                    # neg_lz: no zero special case
+        if a < 2 * p:
+            d = run(11, a)
+            assert d < 2 * p and d % p == 2 * a % p                       # dbl_lz
+        if a < p:
+            assert run(13, a) == p - a                                    # neg_lz_canonical
+        assert run(17, a) == a * a * Ri % p                               # sqr_lz
+        for b in vals:
+            s = run(10, a, b)
+            assert 0 <= s <= 2 * p and (s - (a - b)) % p == 0 and (a == 2 * p or s < 2 * p)   # sub_lz stays in range
+            assert run(16, a, b) == a * b * Ri % p                        # mul_lz
+            assert run(18, a, b) == (a * b + b * a) * Ri % p              # fused pair
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_xyzz_group_law_all_special_cases(curve):
     pts = R.gen_bases(curve, 5)
@@ -78,6 +111,11 @@ def test_xyzz_group_law_all_special_cases(curve):
                                p32(out.view(np.uint32)))
                 want = R.ec_add(curve, Pi, Pj) if op < 2 else R.ec_add(curve, Pi, Pi)
                 assert O.array_to_points(curve, out)[0] == want, (op, i, j)
+            if curve == "bls12_381":        # the lazily reduced mixed addition (same special cases; op 5 negates twice; op 6 chains three)
+                for op, want in ((4, R.ec_add(curve, Pi, Pj)), (5, R.ec_add(curve, Pi, Pj)), (6, R.ec_add(curve, Pi, Pj))):
+                    out = np.zeros(arr.shape[1], dtype=np.uint64)
+                    emu().emu_ecop(O.CURVES[curve], op, p32(arr[i].view(np.uint32)), p32(arr[j].view(np.uint32)), p32(out.view(np.uint32)))
+                    assert O.array_to_points(curve, out)[0] == want, ("lazy", op, i, j)
     # P + (-P) through the mixed add
     neg = O.points_to_array(curve, [R.ec_neg(curve, pts[2])])[0]
     out = np.ones(arr.shape[1], dtype=np.uint64)
@@ -412,7 +450,8 @@ def test_check_polynomial_coefficients_from_key_folds_stepped(curve):
         assert O.fr_from_mont_array(curve, s) == R.succinct_check_coeffs(fr, chal)
 
 
-@pytest.mark.parametrize("curve,compressed", [("bls12_381", False), ("bls12_381", True), ("bn254", False), ("bn254", True), ("pallas", False)])
+@pytest.mark.parametrize("curve,compressed", [("bls12_381", False), ("bls12_381", True), ("bn254", False), ("bn254", True), ("pallas", False),
+                                              ("pallas", True)])
 def test_srs_decode_ark_serialize_stepped(curve, compressed):
     """CanonicalDeserialize of Vec<G1Affine> (the head of kzg10::UniversalParams, kzg10/data_structures.rs:80-112): the
     device decoder (SrsDecodeBody, stepped on the CPU) against the Python big-int serialiser -- both roots, infinity,
@@ -426,12 +465,38 @@ def test_srs_decode_ark_serialize_stepped(curve, compressed):
     out = np.zeros((6, 2 * O.fq_limbs(curve)), dtype=np.uint64)
     bad = emu().emu_srs_decode(O.CURVES[curve], body.ctypes.data_as(C.POINTER(C.c_uint8)), 6, 1 if compressed else 0, p32(out.view(np.uint32)))
     assert bad == 0 and O.array_to_points(curve, out) == pts
+    # ... and the encoder (SrsEncodeBody) writes exactly those bytes back (CanonicalSerialize of the points)
+    enc = np.zeros(len(body), dtype=np.uint8)
+    emu().emu_srs_encode(O.CURVES[curve], p32(out.view(np.uint32)), 6, 1 if compressed else 0, enc.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert bytes(enc) == bytes(body)
     # flip a low bit of the first x: (almost surely) no longer a point
     body2 = body.copy()
     body2[47 if curve == "bls12_381" else 0] ^= 1
     bad = emu().emu_srs_decode(O.CURVES[curve], body2.ctypes.data_as(C.POINTER(C.c_uint8)), 6, 1 if compressed else 0, p32(out.view(np.uint32)))
     if not compressed:
         assert bad == 1
+
+
+def test_pallas_square_root_tonelli_shanks_rejects_non_residues():
+    """Compressed Pallas points go through Tonelli-Shanks (2-adicity 32): an x whose x^3 + 5 is not a square must be counted
+    as invalid, both roots of a valid one must come back as flagged."""
+    curve = "pallas"
+    p = R.FIELDS["pallas_fq"]["p"]
+    xs_bad = [x for x in range(2, 60) if pow((x ** 3 + 5) % p, (p - 1) // 2, p) == p - 1][:4]
+    assert len(xs_bad) == 4
+    body = b"".join(x.to_bytes(33, "little") for x in xs_bad)
+    arr = np.frombuffer(body, dtype=np.uint8).copy()
+    out = np.zeros((4, 8), dtype=np.uint64)
+    assert emu().emu_srs_decode(2, arr.ctypes.data_as(C.POINTER(C.c_uint8)), 4, 1, p32(out.view(np.uint32))) == 4
+    # a valid x with both flags
+    x = next(x for x in range(2, 60) if pow((x ** 3 + 5) % p, (p - 1) // 2, p) == 1)
+    for flag in (0, 0x80):
+        b = bytearray(x.to_bytes(33, "little")); b[-1] |= flag
+        arr = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+        out = np.zeros((1, 8), dtype=np.uint64)
+        assert emu().emu_srs_decode(2, arr.ctypes.data_as(C.POINTER(C.c_uint8)), 1, 1, p32(out.view(np.uint32))) == 0
+        (px, py), = O.array_to_points(curve, out)
+        assert px == x and (py * py - x ** 3 - 5) % p == 0 and (py > p - py) == bool(flag)
 
 
 @pytest.mark.parametrize("curve", CURVES)

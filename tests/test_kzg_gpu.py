@@ -233,7 +233,8 @@ def test_golden_ligero_commit_lincomb_msm_many(ctx):
         srs.free()
 
 
-@pytest.mark.parametrize("curve,compressed", [("bls12_381", True), ("bls12_381", False), ("bn254", True), ("bn254", False), ("pallas", False)])
+@pytest.mark.parametrize("curve,compressed", [("bls12_381", True), ("bls12_381", False), ("bn254", True), ("bn254", False), ("pallas", False),
+                                              ("pallas", True)])
 def test_srs_from_ark_serialize_bytes(ctx, curve, compressed):
     """pc_hip_srs_load_serialized: the head of a serialized kzg10::UniversalParams (Vec<G1Affine>: u64 length + points,
     kzg10/data_structures.rs:57-112) decoded on the device into a resident SRS; a commitment over it equals the oracle's."""
@@ -248,6 +249,9 @@ def test_srs_from_ark_serialize_bytes(ctx, curve, compressed):
     assert (srs.read(0, n) == arr).all()
     s = O.gen_scalars(curve, 0x5E71A, n)
     assert (srs.msm(s)[0] == O.msm_pippenger(curve, arr, s, 8, 1)).all()
+    # the writer: the resident points back to exactly the bytes CanonicalSerialize wrote (pc_hip_srs_serialize), whole and in part
+    assert srs.serialize(compressed=compressed) == R.ser_g1_vec(curve, pts, compressed)
+    assert srs.serialize(5, 20, compressed=not compressed) == R.ser_g1_vec(curve, pts[5:25], not compressed)
     srs.free()
     # only the first 100 points (a committer key shorter than the ceremony)
     srs, used2 = ctx.load_serialized_srs(curve, data, compressed, max_points=100)
@@ -262,8 +266,14 @@ def test_srs_from_ark_serialize_bytes(ctx, curve, compressed):
             ctx.load_serialized_srs(curve, bytes(bad), compressed)
 
 
-def test_srs_compressed_pallas_is_unsupported(ctx):
-    import poly_commit_amd as pc
-    with pytest.raises(pc.PcHipError) as e:
-        ctx.load_serialized_srs("pallas", (1).to_bytes(8, "little") + bytes(33), True)
-    assert e.value.status == -6
+def test_srs_with_infinity_round_trips_through_the_writer(ctx):
+    """Infinity in a key (flag 0x40, x = y = 0) survives load -> serialize in every encoding, Pallas compressed included."""
+    for curve in ("bls12_381", "bn254", "pallas"):
+        pts = R.gen_bases(curve, 9)
+        pts[3] = None
+        pts[6] = R.ec_neg(curve, pts[6])
+        for compressed in (False, True):
+            data = R.ser_g1_vec(curve, pts, compressed)
+            srs, used = ctx.load_serialized_srs(curve, data, compressed)
+            assert used == len(data) and srs.serialize(compressed=compressed) == data
+            srs.free()
