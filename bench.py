@@ -52,7 +52,9 @@ os.dup2(2, 1)
 # pipelines keep seven streams busy; once RCCL adds its own, independent streams share a queue and serialise
 # (measured with one rank: 76.2 ms/step at 4 queues, 72.5 at 8 = the figure without RCCL).  Must be set before HIP
 # initialises, i.e. before torch touches the GPU.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PC_BENCH_FORCE_DIST"):
+# (--mode group: the group's contexts and their pipelines are more streams than 4 queues as well -- a kernel trace showed the
+# sort of one MSM queued behind the reductions of another on the same hardware queue: 77.0 ms/step at 4 queues)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PC_BENCH_FORCE_DIST") or "group" in sys.argv:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
@@ -880,6 +882,80 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
                                  "linear_codes/utils.rs:303-331) and one whole row against the oracle's NTT"}}
 
 
+# ------------------------------------------------------------------------------------------------------------
+# --mode group: ONE process drives N devices through pc_hip_group_* (the form a Rust prover holding one CommitterKey binds)
+# ------------------------------------------------------------------------------------------------------------
+def group_case(args, curve, log_degree, steps, warmup):
+    import collections
+    import torch
+    import oracle_lib as O
+    import poly_commit_amd as pc
+    devs = [int(x) for x in os.environ["PC_BENCH_DEVICES"].split(",")] if os.environ.get("PC_BENCH_DEVICES") else list(range(args.gpus))
+    N = len(devs)
+    n = N * (1 << log_degree) + 1
+    p = fr_modulus(curve)
+    g_xy = O.gen_bases(curve, 1)[0]
+    beta, z = seed_fr(curve, 0xBE7A24), seed_fr(curve, 0x2EE7)
+    zm = mont_limbs(curve, z)
+    torch.cuda.set_device(devs[0])
+    ctx0 = pc.Context(devs[0])
+    t0 = time.perf_counter()
+    pts = true_srs_points(ctx0, curve, g_xy, beta, 0, n)
+    powers = host_u64(pts)                       # the CommitterKey's Vec<G1Affine>, packed: what the prover hands to `trim`
+    del pts
+    torch.cuda.empty_cache()
+    srs_gen_ms = (time.perf_counter() - t0) * 1e3
+    grp = pc.Group(devs)
+    t0 = time.perf_counter()
+    srs = grp.upload_srs(curve, powers, precompute=bool(args.precompute))
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    del powers
+    coeffs_dev0 = rand_fr_device(0x5EED0001, n)
+    host = host_u64(coeffs_dev0)
+    per = (n + N - 1) // N
+    shards = []
+    if args.group_coeffs == "device":
+        for d, dev in enumerate(devs):
+            with torch.cuda.device(dev):
+                shards.append(torch.from_numpy(np.ascontiguousarray(host[min(n, d * per):min(n, (d + 1) * per)]).view(np.int64)).cuda(dev))
+        for dev in set(devs):
+            torch.cuda.synchronize(dev)
+    arg = [t.data_ptr() for t in shards] if shards else host
+    depth = max(1, min(2, args.inflight if args.inflight > 0 else 1))
+    pending, results = collections.deque(), []
+
+    def run(k):
+        for _ in range(k):
+            pending.append(srs.commit_open_async(arg, zm, n=n, want_value=args.group_value))
+            while len(pending) > depth - (1 if args.inflight == 0 else 0):
+                results.append(pending.popleft().wait())
+        while pending:
+            results.append(pending.popleft().wait())
+    run(warmup)
+    results.clear()
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    pb = from_mont_limbs(curve, O.poly_eval(curve, host, mont_limbs(curve, beta)))
+    pz = from_mont_limbs(curve, O.poly_eval(curve, host, zm))
+    want_c = oracle_scalar_mul(curve, g_xy, pb)
+    want_w = oracle_scalar_mul(curve, g_xy, (pb - pz) * pow(beta - z, -1, p) % p)
+    ok = len(results) == steps and all((c == want_c).all() and (w == want_w).all() and (not args.group_value or from_mont_limbs(curve, v) == pz)
+                                       for c, w, v in results)
+    srs.free()
+    grp.close()
+    ctx0.close()
+    return {"metric": "MSM G1-scalar-pairs/sec inside KZG commit+open, ONE process driving N devices through pc_hip_group_commit_open_async",
+            "value": (2 * n - 1) * steps / dt, "unit": "pairs/s", "n_gpus": N, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer)",
+            "data": "synthetic", "commit_open_per_s": steps / dt,
+            "config": {"workload": f"MarlinKZG10<{curve}> commit+open of ONE polynomial of {N} x 2^{log_degree} + 1 coefficients, key sharded over {N} device context(s) "
+                                   f"{devs} in one process (pc_hip_group_*), jobs in flight: {depth}", "mode": "group", "coefficients": args.group_coeffs,
+                       "srs_gen_ms": srs_gen_ms, "group_srs_upload_and_table_ms": upload_ms},
+            "parity": {"all_steps_ok": bool(ok), "checked": len(results),
+                       "method": "every commitment, proof and p(z) of the timed region against the closed forms on the true SRS (oracle Horner + scalar multiplication)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -905,10 +981,21 @@ def main():
     ap.add_argument("--small", action="store_true", help="scaled-down sizes for every block (tests on a shared box); says so in the line")
     ap.add_argument("--polys", type=int, default=64)
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="default: nccl (RCCL); gloo when ranks share a GPU")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "group"],
+                    help="ranks (default): one process per GPU over torch.distributed; group: ONE process drives the --gpus devices through "
+                         "pc_hip_group_commit_open_async (persistent worker thread per device)")
+    ap.add_argument("--group-value", type=int, default=0, help="--mode group: also return p(z) with every proof (one more evaluation pass per shard)")
+    ap.add_argument("--group-coeffs", default="host", choices=["host", "device"], help="--mode group: coefficients handed over as one host array, or as resident per-device shards")
     ap.add_argument("--precompute", type=int, default=1,
                     help="1 (default): build the SRS window table in HBM once after the upload "
                          "(pc_hip_srs_precompute; part of SRS residency, outside the timed region); 0: table-free MSM")
     args = ap.parse_args()
+    if args.mode == "group":
+        r = group_case(args, args.curve, min(args.log_degree, 16) if args.small else args.log_degree, args.steps or 10, args.warmup)
+        emit(r)
+        if not r["parity"]["all_steps_ok"]:
+            raise SystemExit("parity check FAILED")
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus, sys.argv[1:])
 

@@ -341,6 +341,19 @@ int pc_hip_group_msm_batch(pc_group* g, const pc_group_srs* srs, const void* con
  * host (N field elements), one division scan, one MSM.  out_value_host (optional): p(z). */
 int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* srs, const void* coeffs_host, size_t n, const void* z_host,
                           void* out_proof_xy, int* out_is_infinity, void* out_value_host);
+/* KZG commit + open of ONE polynomial over the sharded key as one ASYNCHRONOUS job: commit = MSM(powers, coeffs)
+ * (kzg10/mod.rs:175-178), open = witness polynomial + its MSM (:287-310), hiding off.  where = PC_MEM_HOST: `coeffs` is the
+ * polynomial's n coefficients in host memory (Montgomery); every device copies its shard once, for both MSMs, into a
+ * persistent buffer.  where = PC_MEM_DEVICE: `coeffs` is an array of N device pointers, shard d resident on device d.
+ * Returns once the job is queued on the devices' worker threads (one persistent thread per device); up to two jobs stay in
+ * flight, so the copy and sort of one polynomial overlap the bucket accumulation of the previous one.  z_host is copied;
+ * the out_* buffers (commitment, proof: 2 Fq each; value p(z): one Fr, optional) must stay valid until
+ * pc_hip_group_job_wait, which blocks, folds the N partial points and frees the job. */
+typedef struct pc_group_job pc_group_job;
+int pc_hip_group_commit_open_async(pc_group* g, const pc_group_srs* srs, const void* coeffs, pc_mem where, size_t n,
+                                   const void* z_host, void* out_commit_xy, void* out_proof_xy, void* out_value_host,
+                                   pc_group_job** out_job);
+int pc_hip_group_job_wait(pc_group* g, pc_group_job* job);
 /* pc_hip_ntt_batch with the rows split over the devices (rows are independent: linear_codes/mod.rs:131-135). */
 int pc_hip_group_ntt_batch(pc_group* g, pc_curve field_of, const void* in_host, size_t rows, size_t in_cols,
                            unsigned log_n, void* out_host);

@@ -115,6 +115,8 @@ def load_library():
     lib.pc_hip_group_msm_batch.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(sz), sz, ip, vp, C.POINTER(ip)]
     lib.pc_hip_group_kzg_open.argtypes = [vp, vp, vp, sz, vp, vp, C.POINTER(ip), vp]
     lib.pc_hip_group_ntt_batch.argtypes = [vp, ip, vp, sz, sz, C.c_uint, vp]
+    lib.pc_hip_group_commit_open_async.argtypes = [vp, vp, vp, ip, sz, vp, vp, vp, vp, C.POINTER(vp)]
+    lib.pc_hip_group_job_wait.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -556,6 +558,29 @@ class Group:
         return out
 
 
+class GroupJob:
+    def __init__(self, gsrs, coeffs, z_mont, n, want_value=True):
+        self.g = gsrs.g
+        nq = 2 * FQ_BYTES[gsrs.curve] // 8
+        self.comm, self.proof, self.val = np.zeros(nq, dtype=np.uint64), np.zeros(nq, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        self.z = np.ascontiguousarray(z_mont, dtype=np.uint64)
+        if isinstance(coeffs, np.ndarray):
+            self.keep = np.ascontiguousarray(coeffs, dtype=np.uint64)
+            ptr, where, n = C.c_void_p(self.keep.ctypes.data), PC_MEM_HOST, self.keep.shape[0]
+        else:
+            self.keep = (C.c_void_p * len(coeffs))(*coeffs)
+            ptr, where = C.cast(self.keep, C.c_void_p), PC_MEM_DEVICE
+        self.h = C.c_void_p()
+        self.g.check(self.g.lib.pc_hip_group_commit_open_async(self.g.h, gsrs.h, ptr, where, n, self.z.ctypes.data, self.comm.ctypes.data,
+                                                              self.proof.ctypes.data, self.val.ctypes.data if want_value else None, C.byref(self.h)))
+
+    def wait(self):
+        if self.h:
+            self.g.check(self.g.lib.pc_hip_group_job_wait(self.g.h, self.h))
+            self.h = None
+        return self.comm, self.proof, self.val
+
+
 class GroupSrs:
     def __init__(self, group, curve, bases, precompute=False):
         self.g, self.curve = group, curve
@@ -587,6 +612,11 @@ class GroupSrs:
         self.g.check(self.g.lib.pc_hip_group_msm_batch(self.g.h, self.h, ptrs, ns, k, PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
                                                        out.ctypes.data, None))
         return out
+
+    def commit_open_async(self, coeffs, z_mont, n=None, want_value=True):
+        """pc_hip_group_commit_open_async: coeffs = host (n, 4) uint64 array (Montgomery), or a list of N device pointers with `n`.
+        Returns a job; job.wait() -> (commitment xy, proof xy, p(z))."""
+        return GroupJob(self, coeffs, z_mont, n, want_value)
 
     def kzg_open(self, coeffs_mont, z_mont):
         coeffs_mont = np.ascontiguousarray(coeffs_mont, dtype=np.uint64)

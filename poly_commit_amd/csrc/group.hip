@@ -7,6 +7,11 @@
 // The one-process-per-GPU form of the same protocol (torch.distributed / RCCL all_gather of the partial
 // points) is poly_commit_amd/sharded.py, which bench.py --gpus N uses.
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -14,8 +19,55 @@
 #include "../../include/pc_hip.h"
 #include "host_tail.hpp"
 
+// One persistent worker thread per device: every group call hands its per-device work to these (round 2 spawned and joined
+// N std::threads per call).  Tasks of one device run in FIFO order; different devices run concurrently.
+struct DeviceWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;        // work that queues something on the device
+  std::deque<std::function<void()>> reap;     // tasks that only WAIT for queued MSMs: taken when no work is pending, so that a younger
+                                              // job's copy / enqueue never sits behind the wait for an older job's results
+  bool stop = false;
+  void start() {
+    th = std::thread([this]() {
+      for (;;) {
+        std::function<void()> fn;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [this]() { return stop || !q.empty() || !reap.empty(); });
+          if (!q.empty()) { fn = std::move(q.front()); q.pop_front(); }
+          else if (!reap.empty()) { fn = std::move(reap.front()); reap.pop_front(); }
+          else return;
+        }
+        fn();
+      }
+    });
+  }
+  void push(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(fn)); } cv.notify_one(); }
+  // ahead of everything queued: the next phase of an OLDER job goes before a younger job's first phase
+  void push_front(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(mu); q.push_front(std::move(fn)); } cv.notify_one(); }
+  void push_reap(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(mu); reap.push_back(std::move(fn)); } cv.notify_one(); }
+  void shutdown() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_one(); if (th.joinable()) th.join(); }
+};
+
+// Grow-only device buffers of one device for the commit+open jobs: a ring of coefficient shards and quotients, so that a
+// queued MSM can still read its scalars while the next job's shard is being copied in (a per-call hipMalloc / hipFree
+// synchronises the whole device and drains the other pipelines).
+static constexpr int GROUP_RING = 3;
+struct DeviceBufs {
+  void* c[GROUP_RING] = {nullptr, nullptr, nullptr};
+  void* q[GROUP_RING] = {nullptr, nullptr, nullptr};
+  size_t cap[GROUP_RING] = {0, 0, 0};
+};
+
 struct pc_group {
   std::vector<pc_ctx*> ctx;
+  std::vector<std::unique_ptr<DeviceWorker>> worker;
+  std::vector<DeviceBufs> bufs;
+  std::mutex jobs_mu;
+  std::deque<struct pc_group_job*> inflight;       // commit+open jobs not yet waited for, oldest first
+  uint64_t seq = 0;
   std::string last_error;
 };
 
@@ -33,14 +85,19 @@ namespace {
 
 size_t fq_bytes(pc_curve c) { return c == PC_CURVE_BLS12_381 ? 48 : 32; }
 
-// run fn(d) for every device on its own host thread; returns the first non-OK status
+// run fn(d) for every device on that device's worker thread and wait for all of them; returns the first non-OK status
 template <class Fn>
-int fan_out(size_t n_dev, Fn fn) {
+int fan_out(pc_group* g, Fn fn) {
+  const size_t n_dev = g->ctx.size();
   std::vector<int> rc(n_dev, PC_OK);
-  std::vector<std::thread> th;
-  for (size_t d = 1; d < n_dev; d++) th.emplace_back([&, d]() { rc[d] = fn(d); });
-  rc[0] = fn(0);
-  for (auto& t : th) t.join();
+  std::mutex mu; std::condition_variable cv; size_t left = n_dev;
+  for (size_t d = 0; d < n_dev; d++)
+    g->worker[d]->push([&, d]() {
+      rc[d] = fn(d);
+      std::lock_guard<std::mutex> lk(mu);
+      if (--left == 0) cv.notify_one();
+    });
+  { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return left == 0; }); }
   for (int r : rc) if (r != PC_OK) return r;
   return PC_OK;
 }
@@ -98,12 +155,18 @@ int pc_hip_group_create(const int* device_ids, int n_devices, pc_group** out) {
     if (rc != PC_OK) { pc_hip_group_destroy(g); return rc; }
     g->ctx.push_back(c);
   }
+  g->bufs.resize(g->ctx.size());
+  for (size_t d = 0; d < g->ctx.size(); d++) { g->worker.emplace_back(new DeviceWorker()); g->worker.back()->start(); }
   *out = g;
   return PC_OK;
 }
 
 void pc_hip_group_destroy(pc_group* g) {
   if (!g) return;
+  while (!g->inflight.empty()) (void)pc_hip_group_job_wait(g, g->inflight.front());      // nothing may still be queued on the workers
+  for (auto& w : g->worker) w->shutdown();
+  for (size_t d = 0; d < g->ctx.size(); d++)
+    if (d < g->bufs.size()) for (int k = 0; k < GROUP_RING; k++) { pc_hip_free(g->ctx[d], g->bufs[d].c[k]); pc_hip_free(g->ctx[d], g->bufs[d].q[k]); }
   for (pc_ctx* c : g->ctx) pc_hip_shutdown(c);
   delete g;
 }
@@ -123,7 +186,7 @@ int pc_hip_group_srs_upload(pc_group* g, pc_curve curve, const void* bases_host,
   const size_t N = g->ctx.size();
   s->g = g; s->curve = curve; s->n = n; s->pb = pb; s->per = (n + N - 1) / N; if (!s->per) s->per = 1;
   s->chunk.assign(N, nullptr);
-  int rc = fan_out(N, [&](size_t d) {
+  int rc = fan_out(g, [&](size_t d) {
     const size_t lo = s->lo(d) - s->halo(d), hi = s->hi(d);
     int r = pc_hip_srs_upload(g->ctx[d], curve, (const char*)bases_host + lo * stride_bytes, hi - lo, stride_bytes, PC_MEM_HOST, &s->chunk[d]);
     if (r == PC_OK && precompute && hi > lo) r = pc_hip_srs_precompute(g->ctx[d], s->chunk[d], 0, 0);
@@ -149,7 +212,7 @@ int pc_hip_group_msm(pc_group* g, const pc_group_srs* s, size_t base_offset, con
   if (n > s->n - base_offset) n = s->n - base_offset;                 // msm_bigint: min(bases.len(), scalars.len())
   const size_t N = g->ctx.size();
   std::vector<uint8_t> parts(N * s->pb, 0);
-  int rc = fan_out(N, [&](size_t d) {
+  int rc = fan_out(g, [&](size_t d) {
     const size_t a = std::max(base_offset, s->lo(d)), b = std::min(base_offset + n, s->hi(d));
     if (a >= b) return (int)PC_OK;                                     // partial = infinity (zeros)
     return pc_hip_msm(g->ctx[d], s->chunk[d], a - s->lo(d) + s->halo(d), (const char*)scalars_host + (a - base_offset) * 32, form,
@@ -168,7 +231,7 @@ int pc_hip_group_msm_batch(pc_group* g, const pc_group_srs* s, const void* const
   if (!g || !s || s->g != g || !out_xy || (k && (!scalars_host || !n))) return PC_ERR_INVALID_ARG;
   const size_t N = g->ctx.size();
   std::vector<uint8_t> parts(N * k * s->pb, 0);
-  int rc = fan_out(N, [&](size_t d) {
+  int rc = fan_out(g, [&](size_t d) {
     std::vector<const void*> ptr(k); std::vector<size_t> len(k), off(k);
     for (size_t j = 0; j < k; j++) {
       const size_t nj = std::min(n[j], s->n), a = std::min(nj, s->lo(d)), b = std::min(nj, s->hi(d));
@@ -201,7 +264,7 @@ int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* s, const void* coeffs
   for (size_t d = 0; d < N; d++) len[d] = std::min(n, s->hi(d)) - std::min(n, s->lo(d));
   auto cleanup = [&]() { for (size_t d = 0; d < N; d++) { pc_hip_free(g->ctx[d], cdev[d]); pc_hip_free(g->ctx[d], qdev[d]); } };
   // 1. shards to the devices, one evaluation each
-  int rc = fan_out(N, [&](size_t d) {
+  int rc = fan_out(g, [&](size_t d) {
     if (!len[d]) return (int)PC_OK;
     int r = pc_hip_malloc(g->ctx[d], len[d] * 32, &cdev[d]);
     if (r == PC_OK) r = pc_hip_malloc(g->ctx[d], len[d] * 32, &qdev[d]);
@@ -219,7 +282,7 @@ int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* s, const void* coeffs
   }
   // 3. division with the carry, MSM of the quotient chunk: out[j] (coefficient j of this shard) pairs with power j - 1
   std::vector<uint8_t> parts(N * s->pb, 0);
-  if (rc == PC_OK) rc = fan_out(N, [&](size_t d) {
+  if (rc == PC_OK) rc = fan_out(g, [&](size_t d) {
     if (!len[d]) return (int)PC_OK;
     bool nz = false; for (uint64_t w : carry[d]) nz |= w != 0;
     int r = pc_hip_poly_div_scan(g->ctx[d], s->curve, cdev[d], PC_MEM_DEVICE, len[d], z_host, nz ? carry[d].data() : nullptr, qdev[d], PC_MEM_DEVICE);
@@ -237,13 +300,166 @@ int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* s, const void* coeffs
   return rc;
 }
 
+}  // extern "C"
+
+// ---- commit + open of one polynomial as ONE asynchronous job ----------------------------------------------------------
+// Phase A (per device, on its worker): shard -> device (host coefficients: one copy serves commit and open), commit MSM queued on
+// an SRS pipeline, p_shard(z).  The device that finishes phase A last composes the carries on the host and queues phase B on
+// every worker: division scan with the carry, open MSM queued.  Phase C reaps both MSMs.  Tasks of consecutive jobs interleave
+// in the workers' FIFOs (A_k, A_k+1, B_k, C_k, ...), so job k+1's copy and sort overlap job k's accumulation -- the schedule
+// bench.py's `value` runs through the per-pipeline API.
+struct pc_group_job {
+  pc_group* g = nullptr; const pc_group_srs* s = nullptr;
+  size_t n = 0; int slot = 0; pc_mem where = PC_MEM_HOST;
+  const void* coeffs = nullptr;                    // host array (PC_MEM_HOST) or array of N device pointers (PC_MEM_DEVICE)
+  std::vector<const void*> dev_ptrs;
+  uint64_t z[4] = {0, 0, 0, 0};
+  void* out_commit = nullptr; void* out_proof = nullptr; void* out_value = nullptr;
+  std::vector<size_t> len;
+  std::vector<std::vector<uint64_t>> evals, carry;
+  std::vector<uint8_t> part_c, part_w;            // N partial points each
+  std::vector<pc_job*> jc, jw;
+  std::vector<int> rc;
+  std::mutex mu; std::condition_variable cv;
+  size_t left_a = 0, left_c = 0; bool done = false;
+};
+
+namespace {
+
+int ensure_ring(pc_group* g, size_t d, int slot, size_t elems) {
+  DeviceBufs& b = g->bufs[d];
+  if (b.cap[slot] >= elems) return PC_OK;
+  pc_hip_free(g->ctx[d], b.c[slot]); pc_hip_free(g->ctx[d], b.q[slot]); b.c[slot] = b.q[slot] = nullptr; b.cap[slot] = 0;
+  int r = pc_hip_malloc(g->ctx[d], elems * 32, &b.c[slot]);
+  if (r == PC_OK) r = pc_hip_malloc(g->ctx[d], elems * 32, &b.q[slot]);
+  if (r == PC_OK) b.cap[slot] = elems;
+  return r;
+}
+
+void job_phase_c(pc_group_job* j, size_t d) {
+  pc_group* g = j->g;
+  if (j->jc[d]) { int r = pc_hip_job_wait(g->ctx[d], j->jc[d]); if (j->rc[d] == PC_OK) j->rc[d] = r; }
+  if (j->jw[d]) { int r = pc_hip_job_wait(g->ctx[d], j->jw[d]); if (j->rc[d] == PC_OK) j->rc[d] = r; }
+  std::lock_guard<std::mutex> lk(j->mu);
+  if (--j->left_c == 0) { j->done = true; j->cv.notify_all(); }
+}
+
+void job_phase_b(pc_group_job* j, size_t d) {
+  pc_group* g = j->g; const pc_group_srs* s = j->s;
+  if (j->rc[d] == PC_OK && j->len[d]) {
+    const void* cdev = j->where == PC_MEM_DEVICE ? j->dev_ptrs[d] : g->bufs[d].c[j->slot];
+    void* qdev = g->bufs[d].q[j->slot];
+    bool nz = false; for (uint64_t w : j->carry[d]) nz |= w != 0;
+    int r = pc_hip_poly_div_scan(g->ctx[d], s->curve, cdev, PC_MEM_DEVICE, j->len[d], j->z, nz ? j->carry[d].data() : nullptr, qdev, PC_MEM_DEVICE);
+    if (r == PC_OK) {
+      if (d == 0) {                   // q[i - 1] = out[i], i >= 1: skips out[0] = p(z), powers from 0
+        if (j->len[0] >= 2) r = pc_hip_msm_async(g->ctx[0], s->chunk[0], 0, (const char*)qdev + 32, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, j->len[0] - 1,
+                                                 j->part_w.data(), nullptr, &j->jw[0]);
+      } else r = pc_hip_msm_async(g->ctx[d], s->chunk[d], 0, qdev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, j->len[d], j->part_w.data() + d * s->pb, nullptr, &j->jw[d]);   // halo base first
+    }
+    j->rc[d] = r;
+  }
+  g->worker[d]->push_reap([j, d]() { job_phase_c(j, d); });
+}
+
+void job_phase_a(pc_group_job* j, size_t d) {
+  pc_group* g = j->g; const pc_group_srs* s = j->s;
+  int r = PC_OK;
+  if (j->len[d]) {
+    const size_t lo = std::min(j->n, s->lo(d));
+    const void* cdev = nullptr;
+    r = ensure_ring(g, d, j->slot, j->len[d]);
+    if (r == PC_OK) {
+      if (j->where == PC_MEM_DEVICE) cdev = j->dev_ptrs[d];
+      else { cdev = g->bufs[d].c[j->slot]; r = pc_hip_memcpy_h2d(g->ctx[d], g->bufs[d].c[j->slot], (const char*)j->coeffs + lo * 32, j->len[d] * 32); }
+    }
+    // commit: coefficient lo + i pairs with power lo + i = chunk base halo(d) + i
+    if (r == PC_OK) r = pc_hip_msm_async(g->ctx[d], s->chunk[d], s->halo(d), cdev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, j->len[d],
+                                         j->part_c.data() + d * s->pb, nullptr, &j->jc[d]);
+    // p_shard(z): feeds the division carries of the shards below (and p(z)); a single shard with no value requested needs none
+    if (r == PC_OK && (g->ctx.size() > 1 || j->out_value)) r = pc_hip_poly_eval(g->ctx[d], s->curve, cdev, PC_MEM_DEVICE, j->len[d], j->z, j->evals[d].data());
+  }
+  j->rc[d] = r;
+  bool last;
+  { std::lock_guard<std::mutex> lk(j->mu); last = --j->left_a == 0; }
+  if (!last) return;
+  // every shard's p_s(z) is here: the carries (N field elements, host), then phase B everywhere
+  int rc = PC_OK;
+  for (int x : j->rc) if (x != PC_OK) rc = x;
+  if (rc == PC_OK) {
+    switch (s->curve) {
+      case PC_CURVE_BLS12_381: rc = open_carries<pc_bls12_381_fr>(j->evals, j->len, j->z, j->carry, (uint64_t*)j->out_value); break;
+      case PC_CURVE_BN254: rc = open_carries<pc_bn254_fr>(j->evals, j->len, j->z, j->carry, (uint64_t*)j->out_value); break;
+      default: rc = open_carries<pc_pallas_fr>(j->evals, j->len, j->z, j->carry, (uint64_t*)j->out_value); break;
+    }
+  }
+  if (rc != PC_OK) for (int& x : j->rc) if (x == PC_OK) x = rc;
+  // phase B goes to the FRONT of every worker's queue: the open MSM of this job is queued on the device before a younger
+  // job's copy and commit (phase C, which only reaps, goes to the back)
+  for (size_t e = 0; e < g->ctx.size(); e++) g->worker[e]->push_front([j, e]() { job_phase_b(j, e); });
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_hip_group_commit_open_async(pc_group* g, const pc_group_srs* s, const void* coeffs, pc_mem where, size_t n, const void* z_host,
+                                   void* out_commit_xy, void* out_proof_xy, void* out_value_host, pc_group_job** out_job) {
+  if (!g || !s || s->g != g || !out_commit_xy || !out_proof_xy || !z_host || !out_job || (n && !coeffs) || n > s->n) return PC_ERR_INVALID_ARG;
+  *out_job = nullptr;
+  const size_t N = g->ctx.size();
+  // at most GROUP_RING - 1 jobs in flight: a job's ring slot is reused two jobs later
+  for (;;) {
+    pc_group_job* oldest = nullptr;
+    { std::lock_guard<std::mutex> lk(g->jobs_mu); if (g->inflight.size() >= (size_t)GROUP_RING - 1) oldest = g->inflight.front(); }
+    if (!oldest) break;
+    std::unique_lock<std::mutex> lk(oldest->mu);
+    oldest->cv.wait(lk, [&]() { return oldest->done; });
+    lk.unlock();
+    std::lock_guard<std::mutex> lk2(g->jobs_mu);
+    if (!g->inflight.empty() && g->inflight.front() == oldest) g->inflight.pop_front();      // finished; its owner still calls job_wait
+  }
+  pc_group_job* j = new (std::nothrow) pc_group_job();
+  if (!j) return PC_ERR_OOM;
+  j->g = g; j->s = s; j->n = n; j->where = where; j->coeffs = coeffs;
+  if (where == PC_MEM_DEVICE) j->dev_ptrs.assign((const void* const*)coeffs, (const void* const*)coeffs + N);
+  memcpy(j->z, z_host, 32);
+  j->out_commit = out_commit_xy; j->out_proof = out_proof_xy; j->out_value = out_value_host;
+  j->len.assign(N, 0);
+  for (size_t d = 0; d < N; d++) j->len[d] = std::min(n, s->hi(d)) - std::min(n, s->lo(d));
+  j->evals.assign(N, std::vector<uint64_t>(4, 0));
+  j->part_c.assign(N * s->pb, 0); j->part_w.assign(N * s->pb, 0);
+  j->jc.assign(N, nullptr); j->jw.assign(N, nullptr); j->rc.assign(N, PC_OK);
+  j->left_a = N; j->left_c = N;
+  { std::lock_guard<std::mutex> lk(g->jobs_mu); j->slot = (int)(g->seq++ % GROUP_RING); g->inflight.push_back(j); }
+  for (size_t d = 0; d < N; d++) g->worker[d]->push([j, d]() { job_phase_a(j, d); });
+  *out_job = j;
+  return PC_OK;
+}
+
+int pc_hip_group_job_wait(pc_group* g, pc_group_job* j) {
+  if (!g || !j || j->g != g) return PC_ERR_INVALID_ARG;
+  { std::unique_lock<std::mutex> lk(j->mu); j->cv.wait(lk, [&]() { return j->done; }); }
+  { std::lock_guard<std::mutex> lk(g->jobs_mu); for (auto it = g->inflight.begin(); it != g->inflight.end(); ++it) if (*it == j) { g->inflight.erase(it); break; } }
+  int rc = PC_OK;
+  for (int x : j->rc) if (x != PC_OK) rc = x;
+  if (rc == PC_OK) rc = pc_hip_points_sum(j->s->curve, j->part_c.data(), g->ctx.size(), j->out_commit);
+  if (rc == PC_OK) rc = pc_hip_points_sum(j->s->curve, j->part_w.data(), g->ctx.size(), j->out_proof);
+  delete j;
+  return rc;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // LinearEncode::compute_matrices' rows (linear_codes/mod.rs:131-135) are independent: rows split over the devices,
 // no exchange at all.
 int pc_hip_group_ntt_batch(pc_group* g, pc_curve field_of, const void* in_host, size_t rows, size_t in_cols, unsigned log_n, void* out_host) {
   if (!g || (rows && (!in_host || !out_host))) return PC_ERR_INVALID_ARG;
   const size_t N = g->ctx.size(), per = (rows + N - 1) / N;
   const size_t out_cols = (size_t)1 << log_n;
-  return fan_out(N, [&](size_t d) {
+  return fan_out(g, [&](size_t d) {
     const size_t a = std::min(rows, d * per), b = std::min(rows, (d + 1) * per);
     if (a >= b) return (int)PC_OK;
     return pc_hip_ntt_batch(g->ctx[d], field_of, (const char*)in_host + a * in_cols * 32, PC_MEM_HOST, b - a, in_cols, log_n,

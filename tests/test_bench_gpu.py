@@ -65,3 +65,12 @@ def test_two_ranks_batch_and_rows():
     assert d["n_gpus"] == 2 and d["parity"]["all_commitments_closed_form_ok"] and d["parity"]["oracle_horner_ok"]
     d = run_bench(["--gpus", "2", "--workload", "ntt", "--small", "--steps", "2"], {"PC_BENCH_DEVICES": "0,0"})
     assert d["n_gpus"] == 2 and d["parity"]["horner_spot_checks_ok"] and d["parity"]["one_row_vs_oracle_ntt_ok"]
+
+
+def test_group_mode_one_process():
+    """`python bench.py --mode group`: one process, persistent worker thread per device context, commit+open jobs in flight;
+    with 2 contexts on device 0 the results stay bit-identical to the closed forms (host and device-resident coefficients)."""
+    d = run_bench(["--mode", "group", "--gpus", "2", "--log-degree", "14", "--steps", "4"], {"PC_BENCH_DEVICES": "0,0"})
+    assert d["n_gpus"] == 2 and d["parity"]["all_steps_ok"] and d["parity"]["checked"] == 4
+    d = run_bench(["--mode", "group", "--gpus", "1", "--log-degree", "14", "--steps", "3", "--group-coeffs", "device"])
+    assert d["n_gpus"] == 1 and d["parity"]["all_steps_ok"]

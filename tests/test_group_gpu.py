@@ -56,3 +56,37 @@ def test_group_batch_and_ntt_rows():
     mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x710, 7 * 64)).reshape(7, 64, 4)
     assert (g.ntt_batch(curve, mat, 8) == O.ntt_batch(curve, mat, 8)).all()
     g.close()
+
+
+@pytest.mark.parametrize("curve,n,ndev,table", [("bls12_381", 5000, 1, True), ("bls12_381", 6001, 2, True), ("bn254", 4097, 3, False), ("pallas", 1 << 12, 4, False)])
+def test_group_commit_open_async_jobs(curve, n, ndev, table):
+    """pc_hip_group_commit_open_async: commit + open of one polynomial as one asynchronous job (persistent worker thread per
+    device, persistent shard / quotient buffers, two jobs in flight) -- bit-identical to the oracle's commit and open with 1, 2,
+    3, 4 contexts on device 0, from host coefficients and from device-resident shards, and to the blocking group calls."""
+    import torch
+    import poly_commit_amd as pc
+    g = pc.Group([0] * ndev)
+    powers = O.gen_bases(curve, n)
+    srs = g.upload_srs(curve, powers, precompute=table)
+    z = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x6B1, 1))[0]
+    polys = [O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x6D0 + k, n - 3 * k)) for k in range(5)]
+    jobs = [srs.commit_open_async(p, z) for p in polys]            # more jobs than the ring: the call itself throttles
+    for p, job in zip(polys, jobs):
+        comm, proof, val = job.wait()
+        rc1, want_c = O.kzg_commit(curve, powers, p)
+        rc2, want_w = O.kzg_open(curve, powers, p, z)
+        assert rc1 == 0 and rc2 == 0
+        assert (comm == want_c).all() and (proof == want_w).all() and (val == O.poly_eval(curve, p, z)).all()
+    # the blocking calls of the same group agree
+    c2, _ = srs.msm(polys[0], montgomery=True)
+    w2, v2 = srs.kzg_open(polys[0], z)
+    assert (c2 == O.kzg_commit(curve, powers, polys[0])[1]).all() and (w2 == O.kzg_open(curve, powers, polys[0], z)[1]).all()
+    # device-resident shards: shard d on device d (all device 0 here), cut the way the key is cut
+    p = polys[1]
+    per = (n + ndev - 1) // ndev
+    shards = [torch.from_numpy(np.ascontiguousarray(p[min(len(p), d * per):min(len(p), (d + 1) * per)]).view(np.int64)).cuda() for d in range(ndev)]
+    torch.cuda.synchronize()
+    comm, proof, val = srs.commit_open_async([t.data_ptr() if t.numel() else 0 for t in shards], z, n=len(p)).wait()
+    assert (comm == O.kzg_commit(curve, powers, p)[1]).all() and (proof == O.kzg_open(curve, powers, p, z)[1]).all()
+    srs.free()
+    g.close()

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pc_hip.h")
 FFI_RS = os.path.join(ROOT, "rust", "poly-commit-hip", "src", "ffi.rs")
 
-OPAQUE = ("pc_ctx", "pc_srs", "pc_job", "pc_group", "pc_group_srs")
+OPAQUE = ("pc_ctx", "pc_srs", "pc_job", "pc_group", "pc_group_srs", "pc_group_job")
 ENUMS = ("pc_curve", "pc_scalar_form", "pc_mem", "pc_hash", "pc_status")
 
 
