@@ -283,6 +283,17 @@ int pc_hip_fr_powers(pc_ctx* ctx, pc_curve field_of, const void* z_host, size_t 
  * i < n_half -- `k_l += k_r.mul(round_challenge)` followed by normalize_batch (:699-707).  The
  * following round's MSMs address the halves with base_offset 0 and n_half/2. */
 int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host);
+/* The FIRST key fold of an opening, out of place: *out = a new resident key of n_half points,
+ *   out[i] = affine(src[i] + u * src[n_half + i]),  i < n_half,
+ * leaving src (the committer key, resident across openings) untouched -- the round's two MSMs run on src itself (with its
+ * window table, if built) and no working copy of the key is needed.  If pc_hip_srs_precompute_fold was called on src and
+ * n_half is half its length, the multiplication by u costs ~86 mixed additions per element out of the fold table instead of
+ * a 130-doubling ladder. */
+int pc_hip_ec_fold_from(pc_ctx* ctx, const pc_srs* src, size_t n_half, const void* u_host, pc_srs** out);
+/* Once per committer key (like pc_hip_srs_precompute, at `trim`): the fold table T[b][j] = 2^b * key[n/2 + j], b < 131, of the
+ * upper half of the key (131 x n/2 affine points: 17 GB for a 2^22-point Pallas key), used by pc_hip_ec_fold_from: every
+ * opening's first fold multiplies THIS half by its round challenge.  Nothing in the reference corresponds to it.  n even. */
+int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs);
 /* Late halving rounds without folding the key (same l_vec / r_vec / final_comm_key, bit for bit): once n has
  * shrunk to n0 the resident key K0 = key[0..n0) stays as it is and the per-base factors s_j that the remaining
  * folds `k_l += k_r * u` (ipa_pc/mod.rs:699-701) would have applied are kept as a device vector s (n0 Fr,

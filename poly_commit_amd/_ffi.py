@@ -93,6 +93,8 @@ def load_library():
     lib.pc_hip_ipa_fold_dots.argtypes = [vp, ip, vp, vp, sz, vp, vp, vp]
     lib.pc_hip_fr_powers.argtypes = [vp, ip, vp, sz, vp]
     lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
+    lib.pc_hip_ec_fold_from.argtypes = [vp, vp, sz, vp, C.POINTER(vp)]
+    lib.pc_hip_srs_precompute_fold.argtypes = [vp, vp]
     lib.pc_hip_ipa_key_scalars.argtypes = [vp, ip, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
@@ -436,6 +438,20 @@ class Srs:
         """key[i] = affine(key[i] + u * key[n_half + i]) in place on the resident key."""
         u = np.ascontiguousarray(u, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.pc_hip_ec_fold(self.ctx.h, self.h, n_half, C.c_void_p(u.ctypes.data)))
+
+    def precompute_fold(self):
+        """Fold table of the upper half of this (committer) key: pc_hip_srs_precompute_fold."""
+        self.ctx.check(self.ctx.lib.pc_hip_srs_precompute_fold(self.ctx.h, self.h))
+        return self
+
+    def fold_from(self, n_half, u):
+        """A new resident key: affine(self[i] + u * self[n_half + i]), i < n_half; self is left as it is (pc_hip_ec_fold_from)."""
+        u = np.ascontiguousarray(u, dtype=np.uint64)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.pc_hip_ec_fold_from(self.ctx.h, self.h, n_half, C.c_void_p(u.ctypes.data), C.byref(h)))
+        out = Srs.__new__(Srs)
+        out.ctx, out.curve, out.h, out.n = self.ctx, self.curve, h, n_half
+        return out
 
     def device_ptr(self):
         """Address of the resident packed point array (pc_hip_srs_device_ptr)."""

@@ -53,6 +53,13 @@ struct pc_srs {
   size_t n = 0;
   uint32_t* bases = nullptr;     // packed x||y
   uint32_t* table = nullptr;     // precomputed window table (pc_hip_srs_precompute), or null
+  uint32_t* fold_tbl = nullptr;  // fold table of the upper half (pc_hip_srs_precompute_fold), or null
+  size_t fold_half = 0;
+  // pc_hip_ec_fold_from: the half-size working key of an opening keeps its buffers and pipelines across openings -- freeing it
+  // hands it back to the committer key it was folded from (a fresh key cost ~4 ms of pipeline workspace allocation per opening)
+  pc_srs* parent = nullptr;      // the key this one was folded from (while that key is alive)
+  pc_srs* work_cache = nullptr;  // a returned working key, ready for reuse
+  pc_srs* work_out = nullptr;    // the working key currently handed out
   int aw = 0;                    // words per affine point
   pc::MsmConfig cfg;
   MsmLane* lanes[PC_MSM_LANES] = {nullptr, nullptr, nullptr};
@@ -360,6 +367,17 @@ int pc_hip_universal_params_layout(pc_curve curve, const void* bytes, size_t n_b
 
 void pc_hip_srs_free(pc_srs* srs) {
   if (!srs) return;
+  if (srs->parent) {                                   // a working key goes back to its committer key (see pc_srs)
+    pc_srs* par = srs->parent;
+    std::lock_guard<std::recursive_mutex> lk(srs->ctx->mu);
+    for (int i = 0; i < PC_MSM_LANES; i++)             // nothing of it may still be queued
+      if (srs->lanes[i] && srs->lanes[i]->inflight) { try { complete_job(srs->ctx, srs->lanes[i]->inflight); } catch (...) {} }
+    if (par->work_out == srs) par->work_out = nullptr;
+    if (!par->work_cache) { par->work_cache = srs; return; }
+    srs->parent = nullptr;                             // the cache is taken: a real free
+  }
+  if (srs->work_cache) { srs->work_cache->parent = nullptr; pc_hip_srs_free(srs->work_cache); srs->work_cache = nullptr; }
+  if (srs->work_out) { srs->work_out->parent = nullptr; srs->work_out = nullptr; }      // still held by the caller: it frees it
   if (srs->ctx) (void)hipSetDevice(srs->ctx->device);
   for (int i = 0; i < PC_MSM_LANES; i++) {
     if (srs->lanes[i] && srs->lanes[i]->inflight) {   // abandon: let the stream drain, mark the job failed
@@ -370,6 +388,7 @@ void pc_hip_srs_free(pc_srs* srs) {
     delete srs->lanes[i];
   }
   if (srs->bases) (void)hipFree(srs->bases);
+  if (srs->fold_tbl) (void)hipFree(srs->fold_tbl);
   drop_batch_many(srs);
   if (srs->table) (void)hipFree(srs->table);
   drop_many(srs);
@@ -930,10 +949,53 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) 
     if (!n_half) return (int)PC_OK;
     drop_table(srs);                            // the key changes: its window tables are stale
     drop_many(srs);
+    if (srs->fold_tbl) { (void)hipFree(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
     pc::curve_ops(srs->curve).ec_fold(ctx->be, srs->bases, n_half, (const uint32_t*)u_host);
     return (int)PC_OK;
   });
 }
+int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs) {
+  if (!ctx || !srs || srs->ctx != ctx || srs->n < 2 || (srs->n & 1)) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (srs->fold_tbl) { (void)hipFree(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
+    const size_t half = srs->n / 2, pb = (size_t)srs->aw * 4;
+    const pc::CurveOps& ops = pc::curve_ops(srs->curve);
+    uint32_t* t = (uint32_t*)ctx->be.alloc((size_t)ops.fold_rows * half * pb);
+    try { ops.fold_table_build(ctx->be, srs->bases + half * (size_t)srs->aw, half, t); }
+    catch (...) { ctx->be.free(t); throw; }
+    srs->fold_tbl = t; srs->fold_half = half;
+    return (int)PC_OK;
+  });
+}
+
+int pc_hip_ec_fold_from(pc_ctx* ctx, const pc_srs* src, size_t n_half, const void* u_host, pc_srs** out) {
+  if (!ctx || !src || src->ctx != ctx || !u_host || !out || !n_half || 2 * n_half > src->n) return PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  pc_srs* par = const_cast<pc_srs*>(src);
+  pc_srs* dst = nullptr;
+  if (par->work_cache && par->work_cache->n == n_half) { dst = par->work_cache; par->work_cache = nullptr; }      // buffers and pipelines of the last opening
+  const bool fresh = dst == nullptr;
+  if (fresh) {
+    dst = new (std::nothrow) pc_srs();
+    if (!dst) return PC_ERR_OOM;
+    dst->ctx = ctx; dst->curve = src->curve; dst->n = n_half; dst->aw = src->aw;
+  }
+  int rc = guarded(ctx, [&]() {
+    if (fresh) { dst->bases = (uint32_t*)ctx->be.alloc(n_half * (size_t)src->aw * 4); dst->cfg = ctx->msm_cfg; }
+    else { drop_table(dst); drop_many(dst); }
+    const uint32_t* tbl = (src->fold_tbl && src->fold_half == n_half) ? src->fold_tbl : nullptr;
+    pc::curve_ops(src->curve).ec_fold_to(ctx->be, src->bases, dst->bases, n_half, (const uint32_t*)u_host, tbl);
+    if (fresh) for (int i = 0; i < PC_MSM_LANES; i++) srs_lane(dst, i);      // all pipelines now: the next rounds' MSMs find them ready
+    return (int)PC_OK;
+  });
+  if (rc != PC_OK) { dst->parent = nullptr; pc_hip_srs_free(dst); return rc; }
+  if (!par->work_out) { dst->parent = par; par->work_out = dst; } else dst->parent = nullptr;
+  *out = dst;
+  return PC_OK;
+}
+
 int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy) {
   if ((int)curve < 0 || (int)curve > 2 || !point_xy || !scalar_mont || !out_xy) return PC_ERR_INVALID_ARG;
   pc::curve_ops(curve).point_mul((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy);

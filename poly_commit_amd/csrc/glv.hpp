@@ -65,13 +65,15 @@ struct EcFoldGlvBody {
   typedef Fd<typename C::FqP> Fq;
   static constexpr int AW = 2 * Fq::N;
   uint32_t* key; uint32_t half;
+  const uint32_t* key_in = nullptr;   // not null: read the 2 * half points from here (out-of-place fold into `key`)
   NafMasks<5> n1, n2;      // NAF of |k1|, |k2|
   uint32_t neg1, neg2;
   uint32_t beta[Fq::N];
   uint32_t* jac_out = nullptr;   // not null: store (X, Y, Z) of lane i here instead of normalising in the lane
                                  // (JacBatchAffineBody then writes key[i] with one inversion per K points)
   PC_HD void operator()(uint32_t i) const {
-    AffD<C> kl = AffD<C>::load(key + (size_t)i * AW), kr = AffD<C>::load(key + (size_t)(half + i) * AW);
+    const uint32_t* src = key_in ? key_in : key;
+    AffD<C> kl = AffD<C>::load(src + (size_t)i * AW), kr = AffD<C>::load(src + (size_t)(half + i) * AW);
     AffD<C> p1 = kr.neg_if(neg1 != 0);
     AffD<C> p2; p2.x = kr.x.mul(Fq::load(beta)); p2.y = kr.y; if (kr.is_inf()) p2 = kr;
     p2 = p2.neg_if(neg2 != 0);
@@ -90,6 +92,74 @@ struct EcFoldGlvBody {
       if (acc.is_inf()) { Fq::zero().store(o); Fq::zero().store(o + Fq::N); Fq::zero().store(o + 2 * Fq::N); }
       else { acc.X.store(o); acc.Y.store(o + Fq::N); acc.Z.store(o + 2 * Fq::N); }
     } else acc.to_affine().store(key + (size_t)i * AW);
+  }
+};
+
+// ---- the FIRST key fold of an opening from a table of the committer key ---------------------------------------------
+// `k_l += k_r * u` (ipa_pc/mod.rs:699-701) multiplies every element of the upper half of the key by the round challenge.  The
+// committer key is the same for every opening, so the doublings of that multiplication can be done once per key:
+//   T[b][j] = 2^b * K[half + j],  b < FOLD_ROWS,  j < half                    (FOLD_ROWS x the upper half of the key in HBM)
+// and u * K[half + j] = sum over the non-zero NAF digits of the GLV halves of u:  +-T[b][j]  (k1)  /  +-phi(T[b][j])  (k2),
+// phi(x, y) = (beta x, y): ~86 mixed additions and no doubling instead of ~130 doublings + ~86 additions per element (the
+// first fold is half of all fold work of an opening).  The rows are read as coalesced streams (lane i reads T[b][i]).
+static constexpr uint32_t FOLD_ROWS = 131;       // |k1|, |k2| <= 2^128 (glv_constants.h): NAF digits at bits 0 .. 129, one spare
+
+// row b of the table from row b - 1: affine doubling of n points with one inversion per K points (Montgomery's trick along a
+// lane's run; lambda = 3 x^2 / (2 y))
+template <class C>
+struct AffineDoubleRowBody {
+  typedef Fd<typename C::FqP> Fq;
+  static constexpr int FN = Fq::N, AW = 2 * FN;
+  const uint32_t* in; uint32_t* out; uint32_t* scratch;   // scratch: n x Fq (prefix products)
+  uint32_t n, K;
+  PC_HD void operator()(uint32_t t) const {
+    const uint32_t s = t * K, e = (n - s > K) ? s + K : n;
+    Fq run = Fq::one();
+    for (uint32_t j = s; j < e; j++) {
+      run.store(scratch + (size_t)j * FN);
+      const AffD<C> p = AffD<C>::load(in + (size_t)j * AW);
+      if (!p.is_inf() && !p.y.is_zero()) run = run.mul(p.y.dbl());
+    }
+    Fq inv = run.inv();
+    for (uint32_t j = e; j-- > s;) {
+      const AffD<C> p = AffD<C>::load(in + (size_t)j * AW);
+      AffD<C> r = AffD<C>::infinity();
+      if (!p.is_inf() && !p.y.is_zero()) {
+        const Fq d = p.y.dbl();
+        const Fq di = inv.mul(Fq::load(scratch + (size_t)j * FN));       // 1 / (2 y)
+        inv = inv.mul(d);
+        const Fq xx = p.x.sqr(), lam = xx.dbl().add(xx).mul(di);
+        r.x = lam.sqr().sub(p.x.dbl());
+        r.y = lam.mul(p.x.sub(r.x)).sub(p.y);
+      }
+      r.store(out + (size_t)j * AW);
+    }
+  }
+};
+
+// out_xyzz[i] = K[i] + sum of the listed table entries (ops: row | which << 14 | negate << 15; which = 1: phi of the entry)
+template <class C>
+struct EcFoldTableBody {
+  typedef Fd<typename C::FqP> Fq;
+  static constexpr int AW = 2 * Fq::N;
+  static constexpr uint32_t MAX_OPS = 272;
+  const uint32_t* key_lo;    // K[0 .. half)
+  const uint32_t* table;     // FOLD_ROWS x half affine points
+  uint32_t half, n_ops;
+  uint16_t ops[MAX_OPS];
+  uint32_t beta[Fq::N];
+  uint32_t* out_xyzz;        // half x XyzzD::WORDS
+  PC_HD void operator()(uint32_t i) const {
+    XyzzD<C> acc = XyzzD<C>::from_affine(AffD<C>::load(key_lo + (size_t)i * AW));
+    const Fq b = Fq::load(beta);
+    for (uint32_t k = 0; k < n_ops; k++) {
+      const uint32_t op = ops[k], row = op & 0x3fffu;
+      AffD<C> p = AffD<C>::load(table + ((size_t)row * half + i) * AW);
+      if (p.is_inf()) continue;
+      if (op & 0x4000u) p.x = p.x.mul(b);
+      acc.add_affine(p.neg_if((op & 0x8000u) != 0));
+    }
+    acc.store(out_xyzz + (size_t)i * XyzzD<C>::WORDS);
   }
 };
 

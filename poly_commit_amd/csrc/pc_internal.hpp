@@ -37,6 +37,10 @@ struct CurveOps {
   MsmRunner* (*make_runner)(HipBackend& be, size_t n_max, const MsmConfig& cfg, uint32_t subs);
   void (*window_table)(HipBackend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride);
   void (*ec_fold)(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont);
+  // out[i] = affine(in[i] + u * in[half + i]); table: the key's fold table (or null: GLV ladder).  out == in: in place.
+  void (*ec_fold_to)(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table);
+  void (*fold_table_build)(HipBackend& be, const uint32_t* key_hi, size_t half, uint32_t* table);
+  uint32_t fold_rows;
   void (*fixed_base)(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out);
   // ark-serialize bytes of n points (device) -> n resident affine points; returns the number of invalid points
   uint32_t (*srs_decode)(HipBackend& be, const uint8_t* bytes_dev, size_t n, int compressed, uint32_t* out);

@@ -113,8 +113,12 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     p = FR_MODULUS[curve]
     rinv = pow(_R, -1, p)
     with _T("upload_key"):
-        # the folds are destructive: work on a copy of the key -- device-to-device when the caller keeps it resident
-        srs = comm_key.clone() if isinstance(comm_key, _ffi.Srs) else ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
+        # A resident committer key is never modified and never copied: the first round's MSMs run on it (with its window table, if
+        # built), its first fold goes OUT OF PLACE into a new key of half the size (pc_hip_ec_fold_from: from the key's fold table,
+        # if built), the later folds act on that key in place.  A key handed over as a host array is uploaded (a private copy).
+        resident = isinstance(comm_key, _ffi.Srs)
+        srs = comm_key if resident else ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
+        owned = not resident
     h_prime_xy = np.ascontiguousarray(h_prime_xy)
     z = torch.empty((n, 4), dtype=torch.int64, device=coeffs_dev.device)
     ctx.fr_powers(curve, point_mont, n, z.data_ptr())
@@ -172,8 +176,10 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
         with _T("ec_fold"):
             if n0:
                 u_prev = u                                                  # applied to the factors at the top of the next round
-            else:
+            elif owned:
                 srs.ec_fold(h, u)                                           # key_l += u key_r, normalised
+            else:
+                srs, owned = srs.fold_from(h, u), True                      # the same fold, out of place: the committer key stays
         if timings is not None:
             timings.setdefault("per_round_ms", []).append(round((time.perf_counter() - t_round) * 1e3, 3))
         n = h
@@ -184,7 +190,8 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     else:
         final_key = srs.read(0, 1)[0]
     c = coeffs_dev[0].cpu().numpy().view(np.uint64).copy()
-    srs.free()
+    if owned:
+        srs.free()
     return np.stack(l_vec), np.stack(r_vec), final_key, c
 
 

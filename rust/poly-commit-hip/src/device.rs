@@ -78,6 +78,8 @@ pub fn min_pairs() -> usize {
 pub struct ResidentKey {
     pub srs: *mut ffi::pc_srs,
     pub n: usize,
+    /// set by the first IPA opening on this key: the fold table of its upper half (pc_hip_srs_precompute_fold) exists or was tried
+    pub fold_table_built: std::sync::atomic::AtomicBool,
     host_addr: usize,
     host_bytes: usize,
     elem_bytes: usize,
@@ -163,7 +165,7 @@ pub fn resident<G: HipCurve>(bases: &[G]) -> Result<(Arc<ResidentKey>, usize), E
     if bases.len() >= env_usize("PC_HIP_TABLE_MIN_POINTS", 1 << 12) {
         let _ = unsafe { ffi::pc_hip_srs_precompute(ctx.raw, srs, 0, 0) };
     }
-    let key = Arc::new(ResidentKey { srs, n: bases.len(), host_addr: addr, host_bytes: bases.len() * elem, elem_bytes: elem, fingerprint: fingerprint_points(bases) });
+    let key = Arc::new(ResidentKey { srs, n: bases.len(), fold_table_built: std::sync::atomic::AtomicBool::new(false), host_addr: addr, host_bytes: bases.len() * elem, elem_bytes: elem, fingerprint: fingerprint_points(bases) });
     q.push_front(key.clone());
     while q.len() > env_usize("PC_HIP_MAX_KEYS", 8) {
         q.pop_back();

@@ -110,18 +110,30 @@ where
         let log_d = ark_std::log2(d1) as usize;
         let limbs = |x: &G::ScalarField| x.to_mont_limbs();
 
-        // the folds are destructive: work on a device-to-device copy of the resident key
+        // The committer key stays resident and untouched across openings: round 1's MSMs run on it (with its window table), its first
+        // fold goes OUT OF PLACE into a half-size working key (pc_hip_ec_fold_from; from the key's fold table, built once per key),
+        // later folds act on that key in place.  (A key that is a sub-slice of a larger resident allocation is copied instead.)
         let (resident, off) = device::resident(&ck.comm_key[..])?;
-        let mut key = core::ptr::null_mut();
-        let key_src = (unsafe { ffi::pc_hip_srs_device_ptr(resident.srs) } as usize + off * 16 * G::FQ_LIMBS) as *const c_void;
-        check(c, unsafe { ffi::pc_hip_srs_upload(c.raw, G::CURVE, key_src, d1, 0, ffi::PC_MEM_DEVICE, &mut key) })?;
-        struct KeyGuard(*mut ffi::pc_srs);
+        struct KeyGuard(*mut ffi::pc_srs, bool);
         impl Drop for KeyGuard {
             fn drop(&mut self) {
-                unsafe { ffi::pc_hip_srs_free(self.0) }
+                if self.1 {
+                    unsafe { ffi::pc_hip_srs_free(self.0) }      // a working key goes back to its committer key's cache
+                }
             }
         }
-        let _guard = KeyGuard(key);
+        let mut guard = if off == 0 && resident.n == d1 {
+            if d1 >= 2 && !resident.fold_table_built.swap(true, std::sync::atomic::Ordering::SeqCst) {
+                let _ = unsafe { ffi::pc_hip_srs_precompute_fold(c.raw, resident.srs) };      // OOM: the ladder fold stays in use
+            }
+            KeyGuard(resident.srs, false)
+        } else {
+            let mut copy = core::ptr::null_mut();
+            let key_src = (unsafe { ffi::pc_hip_srs_device_ptr(resident.srs) } as usize + off * 16 * G::FQ_LIMBS) as *const c_void;
+            check(c, unsafe { ffi::pc_hip_srs_upload(c.raw, G::CURVE, key_src, d1, 0, ffi::PC_MEM_DEVICE, &mut copy) })?;
+            KeyGuard(copy, true)
+        };
+        let mut key = guard.0;
 
         // powers of z (:641-649)
         let z = DevicePoly::alloc(d1)?;
@@ -195,8 +207,14 @@ where
                                                         limbs(&round_challenge_inv).as_ptr() as *const c_void, dots.as_mut_ptr() as *mut c_void) })?;
             if fixed.is_some() {                                                                                                                           // :699-707
                 u_prev = Some(round_challenge);             // applied to the factors at the top of the next round
-            } else {
+            } else if guard.1 {
                 check(c, unsafe { ffi::pc_hip_ec_fold(c.raw, key, h, limbs(&round_challenge).as_ptr() as *const c_void) })?;
+            } else {
+                // the first fold: out of place, the committer key stays as it is
+                let mut work = core::ptr::null_mut();
+                check(c, unsafe { ffi::pc_hip_ec_fold_from(c.raw, key, h, limbs(&round_challenge).as_ptr() as *const c_void, &mut work) })?;
+                guard = KeyGuard(work, true);
+                key = work;
             }
             n = h;
         }

@@ -143,11 +143,16 @@ def test_ipa_open_rounds_pallas_2p22(ctx):
     cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
     comm, _ = srs.msm(cdev, n=n, montgomery=True)
     assert (comm == O.msm_pippenger(curve, comm_key, O.f_from_mont(curve, 1, coeffs), CORES, 1)).all()
-    srs.free()
+    # the committer key stays resident with its once-per-key tables (window table: round 1's MSMs; fold table: the first key fold),
+    # as in bench.py's workloads.ipa; the commitment over the window table is the same point
+    srs.precompute()
+    srs.precompute_fold()
+    assert (srs.msm(cdev, n=n, montgomery=True)[0] == comm).all()
     # open(): one polynomial, opening challenge from the (caller's) sponge, random-oracle challenges from the
     # transcript (ipa_pc/mod.rs:615-625, 681-688) -- the whole Proof{l_vec, r_vec, final_comm_key, c}
     xi = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A122, 1))
-    (l, r, fk, c), rc0 = ipa.ipa_open(ctx, curve, comm_key, h_prime, [cdev.data_ptr()], [n], [comm], point, xi)
+    (l, r, fk, c), rc0 = ipa.ipa_open(ctx, curve, srs, h_prime, [cdev.data_ptr()], [n], [comm], point, xi)
+    srs.free()
     assert l.shape[0] == lg
     # oracle: same combination (xi * p, xi * C), same first challenge, rounds with its own transcript
     xi_i = O.fr_from_mont_array(curve, xi)[0]

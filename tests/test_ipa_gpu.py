@@ -39,6 +39,37 @@ def test_ipa_open_rounds(ctx, curve, n, fkb):
     assert (fk == want_key).all() and (c == want_c).all()
 
 
+@pytest.mark.parametrize("curve,n,fkb,tables", [("pallas", 1 << 13, 64, True), ("pallas", 1 << 13, 64, False), ("bn254", 1 << 12, 0, True),
+                                                ("bls12_381", 1 << 11, 16, True), ("pallas", 1 << 9, None, True)])
+def test_ipa_open_rounds_on_a_resident_key(ctx, curve, n, fkb, tables):
+    """The committer key stays resident and untouched across openings: round 1's MSMs run on it (window table), its first fold goes
+    out of place into a new key (pc_hip_ec_fold_from) -- from the key's fold table when pc_hip_srs_precompute_fold built one, by the
+    ladder otherwise.  Two openings in a row on the same resident key, each bit for bit the oracle's."""
+    import torch
+    from poly_commit_amd import ipa
+    lg = n.bit_length() - 1
+    key = O.gen_bases(curve, n + 1)
+    key[5] = 0                                                            # an infinity among the generators (both halves)
+    key[n // 2 + 7] = 0
+    comm_key, h_prime = np.ascontiguousarray(key[:n]), key[n]
+    srs = ctx.upload_srs(curve, comm_key)
+    if tables:
+        srs.precompute(min_pairs=1)
+        srs.precompute_fold()
+    before = srs.read(0, n).copy()
+    for rep in range(2):
+        coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE + rep, n))
+        point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B + rep, 1))[0]
+        ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1 + rep, lg))
+        want_l, want_r, want_key, want_c = O.ipa_rounds(curve, comm_key, coeffs, point, np.ascontiguousarray(h_prime), ch)
+        it = iter(range(lg))
+        cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+        l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb)
+        assert (l == want_l).all() and (r == want_r).all() and (fk == want_key).all() and (c == want_c).all()
+    assert (srs.read(0, n) == before).all()                               # the committer key itself is as it was
+    srs.free()
+
+
 def _open_inputs(curve, n, k=2):
     key = O.gen_bases(curve, n + 1)
     comm_key, h = np.ascontiguousarray(key[:n]), np.ascontiguousarray(key[n])
