@@ -234,6 +234,16 @@ def oracle_scalar_mul(curve, g_xy, k):
     return O.msm_naive(curve, np.ascontiguousarray(g_xy).reshape(1, -1), np.ascontiguousarray(sc))
 
 
+def pmc_traffic(key, field="accumulate_hbm_bytes_per_launch"):
+    """HBM bytes per launch from the committed PMC summary (profiles/r03_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of the same workload -- NOT a measurement of this run)."""
+    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    try:
+        return json.load(open(f)).get(field, {}).get(key)
+    except Exception:
+        return None
+
+
 def union_ms(intervals):
     """Total length of the union of [a, b] intervals."""
     tot, end = 0.0, -1e30
@@ -570,9 +580,11 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
             ["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], sp[:6])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                     "traffic": None,
-                     "traffic_note": "PMC FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes (profiles/): not a live figure, so "
-                                     "not in this line",
+                     "traffic": pmc_traffic(f"{curve}:2^{log_degree}:{'table' if args.precompute else 'table-free'}") if world == 1 else None,
+                     "traffic_source": "profiles/r03_pmc_traffic.json: PMC FETCH_SIZE (doubled per the gfx950 note of the guide) + WRITE_SIZE per launch, "
+                                       "separate rocprofv3 --pmc passes of this workload on an earlier box -- the one figure of this block that is NOT "
+                                       "measured in this run (null when that size / table mode was not profiled); undoubled FETCH_SIZE is about half: "
+                                       "for this kernel's 16-byte gathers the raw figure is the plausible one",
                      "kernel": "pc::k_accumulate (bucket accumulation), launched twice per step (commit MSM, open MSM)",
                      "kernel_ms": acc_union_ms,
                      "kernel_ms_definition": "hipEvent marks on the MSM pipelines' own streams INSIDE the timed region "
@@ -881,7 +893,9 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
             "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
             "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS if achieved else None,
+                         "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
+                         "traffic_source": "profiles/r03_pmc_traffic.json (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
                          "kernel": "pc::k_ntt_pass_a + pc::k_ntt_pass_b (one batched NTT = both), hipEvent brackets on the context's stream inside the timed region",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "parity": {"horner_spot_checks_ok": bool(ok), "one_row_vs_oracle_ntt_ok": ok_row,
