@@ -935,6 +935,9 @@ def group_case(args, curve, log_degree, steps, warmup):
     host = host_u64(coeffs_dev0)
     per = (n + N - 1) // N
     shards = []
+    if args.group_coeffs == "pinned":
+        host_pin = torch.from_numpy(host.view(np.int64)).pin_memory()
+        host = host_pin.numpy().view(np.uint64)
     if args.group_coeffs == "device":
         for d, dev in enumerate(devs):
             with torch.cuda.device(dev):
@@ -1006,7 +1009,7 @@ def main():
                     help="ranks (default): one process per GPU over torch.distributed; group: ONE process drives the --gpus devices through "
                          "pc_hip_group_commit_open_async (persistent worker thread per device)")
     ap.add_argument("--group-value", type=int, default=0, help="--mode group: also return p(z) with every proof (one more evaluation pass per shard)")
-    ap.add_argument("--group-coeffs", default="host", choices=["host", "device"], help="--mode group: coefficients handed over as one host array, or as resident per-device shards")
+    ap.add_argument("--group-coeffs", default="host", choices=["host", "pinned", "device"], help="--mode group: coefficients handed over as one host array (pageable, or page-locked), or as resident per-device shards")
     ap.add_argument("--precompute", type=int, default=1,
                     help="1 (default): build the SRS window table in HBM once after the upload "
                          "(pc_hip_srs_precompute; part of SRS residency, outside the timed region); 0: table-free MSM")

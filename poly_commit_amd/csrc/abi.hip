@@ -457,6 +457,16 @@ int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const
 
 int pc_hip_job_wait(pc_ctx* ctx, pc_job* job) {
   if (!ctx || !job) return PC_ERR_INVALID_ARG;
+  // The wait for the device happens WITHOUT the context's lock: other threads (the per-device workers of pc_hip_group_*)
+  // keep queueing work on this context meanwhile -- with the lock held for the whole wait a reaper serialised them behind
+  // every MSM it waited for.  The bookkeeping behind it (host tail, phase times) is under the lock as before; a job that
+  // another call completed in between (enqueue_job reusing its lane) is simply found done.
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!job->done && job->srs) { MsmLane* L = job->srs->lanes[job->lane]; if (L && L->inflight == job) ev = L->be.done; }
+  }
+  if (ev && hipSetDevice(ctx->device) == hipSuccess) (void)hipEventSynchronize(ev);      // an error surfaces in complete_job below
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   int rc = job->status;
   if (!job->done) rc = guarded(ctx, [&]() { complete_job(ctx, job); return job->status; });

@@ -16,18 +16,21 @@
 #include <thread>
 #include <vector>
 #include <string.h>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <hip/hip_runtime.h>
 #include "../../include/pc_hip.h"
 #include "host_tail.hpp"
 
-// One persistent worker thread per device: every group call hands its per-device work to these (round 2 spawned and joined
-// N std::threads per call).  Tasks of one device run in FIFO order; different devices run concurrently.
+// Persistent threads per device, each with a FIFO of tasks (round 2 spawned and joined N std::threads per call): the WORKER queues
+// work on the device (every group call hands its per-device part to it), the COPIER brings a job's host coefficients in, the
+// REAPER waits for queued MSMs.  Tasks of one queue run in order; different queues and devices run concurrently.
 struct DeviceWorker {
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::function<void()>> q;        // work that queues something on the device
-  std::deque<std::function<void()>> reap;     // tasks that only WAIT for queued MSMs: taken when no work is pending, so that a younger
-                                              // job's copy / enqueue never sits behind the wait for an older job's results
+  std::deque<std::function<void()>> q;
   bool stop = false;
   void start() {
     th = std::thread([this]() {
@@ -35,10 +38,9 @@ struct DeviceWorker {
         std::function<void()> fn;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [this]() { return stop || !q.empty() || !reap.empty(); });
-          if (!q.empty()) { fn = std::move(q.front()); q.pop_front(); }
-          else if (!reap.empty()) { fn = std::move(reap.front()); reap.pop_front(); }
-          else return;
+          cv.wait(lk, [this]() { return stop || !q.empty(); });
+          if (q.empty()) return;
+          fn = std::move(q.front()); q.pop_front();
         }
         fn();
       }
@@ -47,7 +49,6 @@ struct DeviceWorker {
   void push(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(fn)); } cv.notify_one(); }
   // ahead of everything queued: the next phase of an OLDER job goes before a younger job's first phase
   void push_front(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(mu); q.push_front(std::move(fn)); } cv.notify_one(); }
-  void push_reap(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(mu); reap.push_back(std::move(fn)); } cv.notify_one(); }
   void shutdown() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_one(); if (th.joinable()) th.join(); }
 };
 
@@ -63,7 +64,15 @@ struct DeviceBufs {
 
 struct pc_group {
   std::vector<pc_ctx*> ctx;
+  std::vector<int> dev;                                    // HIP ordinal of context d
   std::vector<std::unique_ptr<DeviceWorker>> worker;
+  // a second thread per device for the host -> device copy of a job's shard: a 512 MB copy from pageable memory keeps its
+  // thread for ~10 ms, and on the worker it sat between an older job's division scan / open MSM and the device
+  std::vector<std::unique_ptr<DeviceWorker>> copier;
+  // ... and a third that only WAITS for queued MSMs (phase C of a job): on the worker such a wait (tens of ms) sat in front of the
+  // next job's enqueues
+  std::vector<std::unique_ptr<DeviceWorker>> reaper;
+  std::vector<hipStream_t> copy_stream;                    // created by the copier thread at its first copy
   std::vector<DeviceBufs> bufs;
   std::mutex jobs_mu;
   std::deque<struct pc_group_job*> inflight;       // commit+open jobs not yet waited for, oldest first
@@ -153,10 +162,15 @@ int pc_hip_group_create(const int* device_ids, int n_devices, pc_group** out) {
     pc_ctx* c = nullptr;
     int rc = pc_hip_init(device_ids[i], &c);
     if (rc != PC_OK) { pc_hip_group_destroy(g); return rc; }
-    g->ctx.push_back(c);
+    g->ctx.push_back(c); g->dev.push_back(device_ids[i]);
   }
   g->bufs.resize(g->ctx.size());
-  for (size_t d = 0; d < g->ctx.size(); d++) { g->worker.emplace_back(new DeviceWorker()); g->worker.back()->start(); }
+  g->copy_stream.assign(g->ctx.size(), nullptr);
+  for (size_t d = 0; d < g->ctx.size(); d++) {
+    g->worker.emplace_back(new DeviceWorker()); g->worker.back()->start();
+    g->copier.emplace_back(new DeviceWorker()); g->copier.back()->start();
+    g->reaper.emplace_back(new DeviceWorker()); g->reaper.back()->start();
+  }
   *out = g;
   return PC_OK;
 }
@@ -164,7 +178,11 @@ int pc_hip_group_create(const int* device_ids, int n_devices, pc_group** out) {
 void pc_hip_group_destroy(pc_group* g) {
   if (!g) return;
   while (!g->inflight.empty()) (void)pc_hip_group_job_wait(g, g->inflight.front());      // nothing may still be queued on the workers
+  for (auto& w : g->copier) w->shutdown();
   for (auto& w : g->worker) w->shutdown();
+  for (auto& w : g->reaper) w->shutdown();
+  for (size_t d = 0; d < g->copy_stream.size(); d++)
+    if (g->copy_stream[d] && hipSetDevice(g->dev[d]) == hipSuccess) (void)hipStreamDestroy(g->copy_stream[d]);
   for (size_t d = 0; d < g->ctx.size(); d++)
     if (d < g->bufs.size()) for (int k = 0; k < GROUP_RING; k++) { pc_hip_free(g->ctx[d], g->bufs[d].c[k]); pc_hip_free(g->ctx[d], g->bufs[d].q[k]); }
   for (pc_ctx* c : g->ctx) pc_hip_shutdown(c);
@@ -303,8 +321,8 @@ int pc_hip_group_kzg_open(pc_group* g, const pc_group_srs* s, const void* coeffs
 }  // extern "C"
 
 // ---- commit + open of one polynomial as ONE asynchronous job ----------------------------------------------------------
-// Phase A (per device, on its worker): shard -> device (host coefficients: one copy serves commit and open), commit MSM queued on
-// an SRS pipeline, p_shard(z).  The device that finishes phase A last composes the carries on the host and queues phase B on
+// Copy (host coefficients only, on the device's copier thread): shard -> its ring slot; one copy serves commit and open.
+// Phase A (per device, on its worker): commit MSM queued on an SRS pipeline, p_shard(z).  The device that finishes phase A last composes the carries on the host and queues phase B on
 // every worker: division scan with the carry, open MSM queued.  Phase C reaps both MSMs.  Tasks of consecutive jobs interleave
 // in the workers' FIFOs (A_k, A_k+1, B_k, C_k, ...), so job k+1's copy and sort overlap job k's accumulation -- the schedule
 // bench.py's `value` runs through the per-pipeline API.
@@ -322,9 +340,13 @@ struct pc_group_job {
   std::vector<int> rc;
   std::mutex mu; std::condition_variable cv;
   size_t left_a = 0, left_c = 0; bool done = false;
+  double ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // PC_HIP_GROUP_TRACE: submit, copy done, A done, B start, B done, C start, C done (device 0)
 };
 
 namespace {
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool group_trace() { static const bool on = getenv("PC_HIP_GROUP_TRACE") != nullptr; return on; }
 
 int ensure_ring(pc_group* g, size_t d, int slot, size_t elems) {
   DeviceBufs& b = g->bufs[d];
@@ -338,14 +360,17 @@ int ensure_ring(pc_group* g, size_t d, int slot, size_t elems) {
 
 void job_phase_c(pc_group_job* j, size_t d) {
   pc_group* g = j->g;
+  if (d == 0) j->ts[5] = now_ms();
   if (j->jc[d]) { int r = pc_hip_job_wait(g->ctx[d], j->jc[d]); if (j->rc[d] == PC_OK) j->rc[d] = r; }
   if (j->jw[d]) { int r = pc_hip_job_wait(g->ctx[d], j->jw[d]); if (j->rc[d] == PC_OK) j->rc[d] = r; }
+  if (d == 0) j->ts[6] = now_ms();
   std::lock_guard<std::mutex> lk(j->mu);
   if (--j->left_c == 0) { j->done = true; j->cv.notify_all(); }
 }
 
 void job_phase_b(pc_group_job* j, size_t d) {
   pc_group* g = j->g; const pc_group_srs* s = j->s;
+  if (d == 0) j->ts[3] = now_ms();
   if (j->rc[d] == PC_OK && j->len[d]) {
     const void* cdev = j->where == PC_MEM_DEVICE ? j->dev_ptrs[d] : g->bufs[d].c[j->slot];
     void* qdev = g->bufs[d].q[j->slot];
@@ -359,20 +384,31 @@ void job_phase_b(pc_group_job* j, size_t d) {
     }
     j->rc[d] = r;
   }
-  g->worker[d]->push_reap([j, d]() { job_phase_c(j, d); });
+  if (d == 0) j->ts[4] = now_ms();
+  g->reaper[d]->push([j, d]() { job_phase_c(j, d); });
 }
 
-void job_phase_a(pc_group_job* j, size_t d) {
+// the shard of a host polynomial -> its ring slot, on the device's COPIER thread and a stream of its own (the slot's previous user
+// is two jobs back and waited for: pc_hip_group_commit_open_async throttles); nothing of the context is locked while the copy runs
+int job_copy_in(pc_group_job* j, size_t d) {
   pc_group* g = j->g; const pc_group_srs* s = j->s;
-  int r = PC_OK;
+  int r = ensure_ring(g, d, j->slot, j->len[d]);
+  if (r != PC_OK) return r;
+  if (hipSetDevice(g->dev[d]) != hipSuccess) return PC_ERR_HIP;
+  if (!g->copy_stream[d] && hipStreamCreateWithFlags(&g->copy_stream[d], hipStreamNonBlocking) != hipSuccess) return PC_ERR_HIP;
+  const size_t lo = std::min(j->n, s->lo(d));
+  if (hipMemcpyAsync(g->bufs[d].c[j->slot], (const char*)j->coeffs + lo * 32, j->len[d] * 32, hipMemcpyHostToDevice, g->copy_stream[d]) != hipSuccess) return PC_ERR_HIP;
+  const int rc = hipStreamSynchronize(g->copy_stream[d]) == hipSuccess ? PC_OK : PC_ERR_HIP;
+  if (d == 0) j->ts[1] = now_ms();
+  return rc;
+}
+
+void job_phase_a(pc_group_job* j, size_t d, int r) {
+  pc_group* g = j->g; const pc_group_srs* s = j->s;
   if (j->len[d]) {
-    const size_t lo = std::min(j->n, s->lo(d));
     const void* cdev = nullptr;
-    r = ensure_ring(g, d, j->slot, j->len[d]);
-    if (r == PC_OK) {
-      if (j->where == PC_MEM_DEVICE) cdev = j->dev_ptrs[d];
-      else { cdev = g->bufs[d].c[j->slot]; r = pc_hip_memcpy_h2d(g->ctx[d], g->bufs[d].c[j->slot], (const char*)j->coeffs + lo * 32, j->len[d] * 32); }
-    }
+    if (r == PC_OK) r = ensure_ring(g, d, j->slot, j->len[d]);
+    if (r == PC_OK) cdev = j->where == PC_MEM_DEVICE ? j->dev_ptrs[d] : g->bufs[d].c[j->slot];
     // commit: coefficient lo + i pairs with power lo + i = chunk base halo(d) + i
     if (r == PC_OK) r = pc_hip_msm_async(g->ctx[d], s->chunk[d], s->halo(d), cdev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, j->len[d],
                                          j->part_c.data() + d * s->pb, nullptr, &j->jc[d]);
@@ -380,6 +416,7 @@ void job_phase_a(pc_group_job* j, size_t d) {
     if (r == PC_OK && (g->ctx.size() > 1 || j->out_value)) r = pc_hip_poly_eval(g->ctx[d], s->curve, cdev, PC_MEM_DEVICE, j->len[d], j->z, j->evals[d].data());
   }
   j->rc[d] = r;
+  if (d == 0) j->ts[2] = now_ms();
   bool last;
   { std::lock_guard<std::mutex> lk(j->mu); last = --j->left_a == 0; }
   if (!last) return;
@@ -431,8 +468,12 @@ int pc_hip_group_commit_open_async(pc_group* g, const pc_group_srs* s, const voi
   j->part_c.assign(N * s->pb, 0); j->part_w.assign(N * s->pb, 0);
   j->jc.assign(N, nullptr); j->jw.assign(N, nullptr); j->rc.assign(N, PC_OK);
   j->left_a = N; j->left_c = N;
+  j->ts[0] = now_ms();
   { std::lock_guard<std::mutex> lk(g->jobs_mu); j->slot = (int)(g->seq++ % GROUP_RING); g->inflight.push_back(j); }
-  for (size_t d = 0; d < N; d++) g->worker[d]->push([j, d]() { job_phase_a(j, d); });
+  for (size_t d = 0; d < N; d++) {
+    if (where == PC_MEM_HOST && j->len[d]) g->copier[d]->push([j, d]() { const int r = job_copy_in(j, d); j->g->worker[d]->push([j, d, r]() { job_phase_a(j, d, r); }); });
+    else g->worker[d]->push([j, d]() { job_phase_a(j, d, PC_OK); });
+  }
   *out_job = j;
   return PC_OK;
 }
@@ -441,6 +482,9 @@ int pc_hip_group_job_wait(pc_group* g, pc_group_job* j) {
   if (!g || !j || j->g != g) return PC_ERR_INVALID_ARG;
   { std::unique_lock<std::mutex> lk(j->mu); j->cv.wait(lk, [&]() { return j->done; }); }
   { std::lock_guard<std::mutex> lk(g->jobs_mu); for (auto it = g->inflight.begin(); it != g->inflight.end(); ++it) if (*it == j) { g->inflight.erase(it); break; } }
+  if (group_trace())
+    fprintf(stderr, "[group job] submit %.2f  copy +%.2f  A +%.2f  B %.2f..%.2f  C %.2f..%.2f  wait-returns +%.2f\n", j->ts[0], j->ts[1] ? j->ts[1] - j->ts[0] : 0.0,
+            j->ts[2] - j->ts[0], j->ts[3] - j->ts[0], j->ts[4] - j->ts[0], j->ts[5] - j->ts[0], j->ts[6] - j->ts[0], now_ms() - j->ts[0]);
   int rc = PC_OK;
   for (int x : j->rc) if (x != PC_OK) rc = x;
   if (rc == PC_OK) rc = pc_hip_points_sum(j->s->curve, j->part_c.data(), g->ctx.size(), j->out_commit);

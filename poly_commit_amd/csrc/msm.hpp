@@ -539,7 +539,11 @@ void build_window_table_batched(Backend& be, const uint32_t* bases, uint32_t n, 
 inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255) {
   uint32_t best = 8; double best_cost = 1e300;
   for (uint32_t c = 8; c <= 23; c++) {
-    double cost = (double)n * (scalar_bits / c + 1) + 3.0 * (double)((size_t)1 << (c - 1));
+    // a top digit of fewer than 5 bits lands in <= 2^4 buckets with n / 2^4 .. n / 2 entries each: chains of hundreds of chunks
+    // (c = 11, 12, 14 at 255 bits; 2^14 pairs with c = 14: 8 buckets of 2048 entries, 7 scan steps in k_accumulate)
+    const uint32_t Wd = scalar_bits / c + 1;
+    if (scalar_bits - (Wd - 1) * c < 5) continue;
+    double cost = (double)n * Wd + 3.0 * (double)((size_t)1 << (c - 1));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;

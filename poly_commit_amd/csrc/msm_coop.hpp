@@ -67,13 +67,18 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t 
   }
 }
 
-// Bucket accumulation with an in-workgroup merge of the runs that chunk edges cut in two.
-// AccumulateBody::chunk leaves, per lane, a partial for its first run (bucket began in an earlier
-// chunk) and one for its last run (bucket continues in the next chunk).  With ~32 entries per
-// bucket and 64 per chunk nearly every bucket is cut exactly once, i.e. its two halves sit in
-// neighbouring lanes: lane t hands its last-run sum to lane t+1 through LDS, lane t+1 adds it to
-// its first-run partial and, if the bucket ends inside its chunk, writes the finished bucket.
-// Only buckets spanning >= 3 chunks or a workgroup edge still go through the partial list.
+// Bucket accumulation with an in-workgroup merge of the runs that chunk edges cut.
+// AccumulateBody::chunk leaves, per lane, a partial for its first run when that run is not complete inside the chunk (slot 2t,
+// key k0) and one for its last run when that is a different run and continues in the next chunk (slot 2t + 1, key k1).  A bucket
+// cut by chunk edges is a chain of consecutive lanes: a START lane (its piece begins inside the chunk and runs off its end: the
+// tail, or a head that begins at the chunk's first entry), any number of TRANSPARENT lanes (the whole chunk is one run of that
+// bucket) and a CLOSING lane (its head ends inside the chunk).  With ~96 entries per bucket and chunks of 1500 (n = 2^24)
+// every chain is start + close: lane t hands its last-run sum to lane t + 1 through LDS.  With chunks of 16 and ~20-32 entries
+// per bucket (n <= 2^18) most chains have one or two transparent lanes, and before round 3 all of those went through the
+// level-by-level segmented reduction (0.4-0.7 ms of a 1.1-2.0 ms MSM): now the pieces that flow right are combined by a
+// segmented Hillis-Steele scan over the workgroup's lanes (one step per doubling of the longest chain, none when no lane is
+// transparent), and the closing lane adds the scanned sum of its left neighbour.  Chains that leave the workgroup keep ONE
+// partial per side (k_accumulate_edges joins those); only chains longer than that still reach the partial list.
 #ifndef PC_ACC_WAVES_PER_EU
 #define PC_ACC_WAVES_PER_EU 0
 #endif
@@ -86,38 +91,66 @@ template <class C>
 __global__ void PC_ACC_BOUNDS k_accumulate(AccumulateBody<C> b, uint32_t lanes) {
   typedef XyzzD<C> Pt;
   __shared__ uint32_t xch[Pt::WORDS * 256];
-  __shared__ uint32_t key_offer[256], key_first[256];
+  __shared__ uint32_t key_out[256], key_first[256], flags[256];
   const uint32_t tid = threadIdx.x, t = blockIdx.x * 256 + tid;
   const bool valid = t < lanes;
   uint32_t k0 = KEY_INVALID, k1 = KEY_INVALID;
-  Pt last = Pt::infinity();
-  if (valid) b.chunk(t, k0, k1, last);
+  Pt V = Pt::infinity();                       // the lane's last run (AccumulateBody::chunk), then the scanned sum of its chain
+  if (valid) b.chunk(t, k0, k1, V);
+  const uint32_t M = b.offsets[b.g.NB];
+  const uint64_t s64 = (uint64_t)t * b.g.T;
+  const uint32_t cs = s64 < M ? (uint32_t)s64 : M;
+  const uint32_t ce = (M - cs > b.g.T) ? cs + b.g.T : M;
+  // the piece that flows to the right: the tail, or a head that runs off the chunk's end
+  const bool head_left = k0 != KEY_INVALID && b.offsets[k0] < cs;                       // begins in an earlier chunk
+  const bool head_right = k0 != KEY_INVALID && k1 == KEY_INVALID && b.offsets[k0 + 1] > ce;   // continues in the next chunk
+  const bool transparent = head_left && head_right;
+  const uint32_t okey = k1 != KEY_INVALID ? k1 : head_right ? k0 : KEY_INVALID;
   LdsPoints<C> lds{xch, 256};
-  key_offer[tid] = k1; key_first[tid] = k0;
-  if (k1 != KEY_INVALID) lds.put(tid, last);
-  __syncthreads();
-  const bool give = k1 != KEY_INVALID && tid < 255 && key_first[tid + 1] == k1;
-  const bool take = k0 != KEY_INVALID && tid > 0 && key_offer[tid - 1] == k0;
-  if (take) {
-    uint32_t* slot = b.ppts + (size_t)(2 * t) * Pt::WORDS;
-    Pt f = Pt::load(slot);
-    f.add(lds.get(tid - 1));
-    // the merged sum covers the bucket from its start (inside lane t-1's chunk) to where lane t's
-    // first run stopped: complete iff the bucket ends inside this chunk
-    const uint32_t M = b.offsets[b.g.NB];
-    const uint64_t s64 = (uint64_t)t * b.g.T;
-    const uint32_t e = (M - (uint32_t)s64 > b.g.T) ? (uint32_t)s64 + b.g.T : M;
-    if (b.offsets[k0 + 1] <= e) { f.store(b.buckets + (size_t)k0 * Pt::WORDS); k0 = KEY_INVALID; }
-    else f.store(slot);
+  // flags: bit 0 = the sum reaches back to the chain's start (or to lane 0), bit 1 = it stopped at lane 0 without one
+  uint32_t fl = (okey == KEY_INVALID || !transparent) ? 1u : 0u;
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const bool need = !(fl & 1u);
+    if (!__syncthreads_or(need)) break;
+    if (okey != KEY_INVALID) lds.put(tid, V);
+    flags[tid] = fl;
+    __syncthreads();
+    if (need) {
+      if (tid < d) fl = 3u;                      // lanes [0, tid] are all transparent: the chain began in an earlier workgroup
+      else { V.add(lds.get(tid - d)); fl = flags[tid - d]; }
+    }
+    __syncthreads();
   }
-  if (give) k1 = KEY_INVALID;
+  key_out[tid] = okey; key_first[tid] = head_left ? k0 : KEY_INVALID; flags[tid] = fl;
+  if (okey != KEY_INVALID) lds.put(tid, V);
+  __syncthreads();
+  const bool take = head_left && tid > 0 && key_out[tid - 1] == k0;
+  const bool give = okey != KEY_INVALID && tid < 255 && key_first[tid + 1] == okey;
+  if (transparent) {
+    // V already holds everything of this bucket from the chain's start (or lane 0) to here
+    if (give) k0 = KEY_INVALID;
+    else V.store(b.ppts + (size_t)(2 * t) * Pt::WORDS);      // last lane of the workgroup: one partial for the chain so far
+  } else {
+    if (take) {
+      uint32_t* slot = b.ppts + (size_t)(2 * t) * Pt::WORDS;
+      Pt f = Pt::load(slot);
+      f.add(lds.get(tid - 1));
+      // complete iff the chain began inside this workgroup (the head ends inside this chunk: it is not `head_right`)
+      if (!(flags[tid - 1] & 2u) && !head_right) { f.store(b.buckets + (size_t)k0 * Pt::WORDS); k0 = KEY_INVALID; }
+      else f.store(slot);
+    }
+    if (give) { if (k1 != KEY_INVALID) k1 = KEY_INVALID; else k0 = KEY_INVALID; }
+  }
   if (valid) { b.pkeys[2 * t] = k0; b.pkeys[2 * t + 1] = k1; }
 }
 
-// The runs that a WORKGROUP edge cut (lane 255 of workgroup k / lane 0 of workgroup k+1) are the only cut runs the
-// in-workgroup merge above cannot see: one lane per edge does the same merge right after the accumulation.  With
-// uniformly distributed scalars this leaves the partial list empty, so the level-by-level segmented reduction behind
-// it has launches but no additions left (it still handles buckets spanning three or more chunks: skewed scalars).
+// The chains that a WORKGROUP edge cuts (last lane of workgroup k / first lanes of workgroup k + 1): one lane per edge joins the
+// piece the left workgroup kept for its last lane (its tail, or the scanned sum of a chain that ran off the workgroup) with the
+// closing partial on the right -- lane 0 of workgroup k + 1, or, when that lane and its neighbours were transparent and handed
+// their pieces on, the first lane behind them that still holds the bucket (looked for among the first EDGE_REACH lanes).
+// With uniformly distributed scalars this leaves the partial list empty, so the level-by-level segmented reduction behind
+// it has launches but no additions left (it still handles longer chains: skewed scalars).
+static constexpr uint32_t EDGE_REACH = 8;
 template <class C>
 __global__ void __launch_bounds__(64) k_accumulate_edges(AccumulateBody<C> b, uint32_t lanes) {
   PC_LATENCY_KERNEL();
@@ -126,16 +159,31 @@ __global__ void __launch_bounds__(64) k_accumulate_edges(AccumulateBody<C> b, ui
   const uint64_t t64 = (uint64_t)(k + 1) * 256;           // first lane of workgroup k + 1
   if (t64 >= lanes) return;
   const uint32_t t = (uint32_t)t64, a = t - 1;
-  const uint32_t k1 = b.pkeys[2 * a + 1], k0 = b.pkeys[2 * t];
-  if (k1 == KEY_INVALID || k1 != k0) return;
-  uint32_t* slot = b.ppts + (size_t)(2 * t) * Pt::WORDS;
-  Pt f = Pt::load(slot);
-  f.add(Pt::load(b.ppts + (size_t)(2 * a + 1) * Pt::WORDS));
   const uint32_t M = b.offsets[b.g.NB];
-  const uint64_t s64 = (uint64_t)t * b.g.T;
-  const uint32_t e = (M - (uint32_t)s64 > b.g.T) ? (uint32_t)s64 + b.g.T : M;
-  b.pkeys[2 * a + 1] = KEY_INVALID;
-  if (b.offsets[k0 + 1] <= e) { f.store(b.buckets + (size_t)k0 * Pt::WORDS); b.pkeys[2 * t] = KEY_INVALID; }
+  // the left piece: the tail of lane a, or its head when that runs off the chunk (then slot 2a + 1 is unused)
+  uint32_t aslot = 2 * a + 1, key = b.pkeys[aslot];
+  if (key == KEY_INVALID) {
+    aslot = 2 * a; key = b.pkeys[aslot];
+    if (key == KEY_INVALID || (uint64_t)b.offsets[key + 1] <= t64 * b.g.T) return;   // ends inside lane a's chunk: not cut by this edge
+  }
+  // the right piece
+  uint32_t u = t;
+  for (;; u++) {
+    if (u >= lanes || u - t >= EDGE_REACH) return;
+    const uint32_t ku = b.pkeys[2 * u];
+    if (ku == key) break;
+    if (ku != KEY_INVALID) return;
+  }
+  const uint64_t us = (uint64_t)u * b.g.T;
+  const uint32_t ue = (M - (uint32_t)us > b.g.T) ? (uint32_t)us + b.g.T : M;
+  uint32_t* slot = b.ppts + (size_t)(2 * u) * Pt::WORDS;
+  Pt f = Pt::load(slot);
+  f.add(Pt::load(b.ppts + (size_t)aslot * Pt::WORDS));
+  b.pkeys[aslot] = KEY_INVALID;
+  // complete iff the bucket begins inside the left workgroup (whose scan collected all of it into lane a's piece) and ends
+  // inside lane u's chunk
+  const uint64_t ws = (uint64_t)(a - 255u) * b.g.T;
+  if (b.offsets[key] >= ws && b.offsets[key + 1] <= ue) { f.store(b.buckets + (size_t)key * Pt::WORDS); b.pkeys[2 * u] = KEY_INVALID; }
   else f.store(slot);
 }
 
