@@ -379,6 +379,8 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
     eng, job, coeffs = S.eng, S.job, S.coeffs
 
     depth = max(0, args.inflight)
+    eng_blocking = depth == 0 and dist is None      # --inflight 0: the blocking ABI calls themselves (pc_hip_msm)
+    eng.blocking = eng_blocking
     pending = collections.deque()
     results = []                            # (kind, point) of everything that left the pipeline, in order
 
@@ -538,6 +540,7 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
         del qdev
 
     # The kernels without a second pipeline competing for the CUs: strictly serial MSMs after the timed region.
+    eng.blocking = False
     eng.phases, eng.marks = [], []
     for _ in range(3):
         job.commit_async(coeffs, n).result()
@@ -546,10 +549,13 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
     for _ in range(3):
         job.commit_async(coeffs, n).result()
     blocking_msm_ms = (time.perf_counter() - t0) / 3 * 1e3
+    in_region = bool(acc_iv)
+    if not in_region:           # --inflight 0 (blocking calls leave no per-launch marks): the serial figure stands in
+        acc_union_ms = float(sp[3])
 
     pairs_per_step = (2 * n - 1) if world == 1 else world * (2 * n) - 1
     acc_serial_ms = float(sp[3])
-    launch_pairs = (2 * n - 1) / 2.0 if world == 1 else n - 0.5 / world
+    launch_pairs = ((2 * n - 1) / 2.0 if world == 1 else n - 0.5 / world) if in_region else float(n)
     bytes_per_launch = launch_pairs * PAIR_BYTES[curve]
     achieved = bytes_per_launch / (acc_union_ms * 1e-3) / 1e9 if acc_union_ms > 0 else None
     ach_serial = n * PAIR_BYTES[curve] / (acc_serial_ms * 1e-3) / 1e9 if acc_serial_ms > 0 else None
@@ -587,10 +593,11 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
                                        "for this kernel's 16-byte gathers the raw figure is the plausible one",
                      "kernel": "pc::k_accumulate (bucket accumulation), launched twice per step (commit MSM, open MSM)",
                      "kernel_ms": acc_union_ms,
-                     "kernel_ms_definition": "hipEvent marks on the MSM pipelines' own streams INSIDE the timed region "
-                                             "(pc_hip_last_msm_marks_ms): union of the [start, end] intervals of all accumulate launches / "
-                                             "launches -- consecutive launches of different pipelines overlap, the union is what the region "
-                                             "spent per launch (2 x kernel_ms <= ms_per_step by construction)",
+                     "kernel_ms_definition": ("hipEvent marks on the MSM pipelines' own streams INSIDE the timed region "
+                                              "(pc_hip_last_msm_marks_ms): union of the [start, end] intervals of all accumulate launches / "
+                                              "launches -- consecutive launches of different pipelines overlap, the union is what the region "
+                                              "spent per launch (2 x kernel_ms <= ms_per_step by construction)") if in_region else
+                                             "the `serial` figure (this run's steps are blocking calls, which leave no per-launch marks)",
                      "launches": len(acc_iv),
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "arithmetic": arith,

@@ -78,6 +78,7 @@ class HipEngine:
         self._scratch = None
         self.phases = []
         self.marks = []      # absolute phase boundaries of the same MSMs (Context.last_msm_marks_ms)
+        self.blocking = False   # True: every MSM is the BLOCKING pc_hip_msm call (bench.py --inflight 0)
 
     def load_srs(self, bases, precompute=False, n=None):
         """bases: host array of affine points, or a device pointer with `n` (a chunk generated on the device)."""
@@ -105,6 +106,13 @@ class HipEngine:
 
     def msm_async(self, scalars, n, base_offset, elem_off=0):
         """Queue the MSM on one of the SRS's pipelines; .wait() returns the affine point."""
+        if self.blocking:
+            out, _ = self.srs.msm(self._ptr(scalars, elem_off), n=n, base_offset=base_offset, montgomery=True)
+
+            class _Done:
+                def wait(self_inner):
+                    return out
+            return _Done()
         job = self.srs.msm_async(self._ptr(scalars, elem_off), n=n, base_offset=base_offset, montgomery=True)
         eng = self
 

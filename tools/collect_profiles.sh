@@ -9,6 +9,7 @@ cp $G/d_bench_batch.json profiles/r03_bench_batch_bn254.json
 cp $G/d_ipa_2p22.json profiles/r03_ipa_pallas_2p22.json
 cp $G/d_lincomb.json profiles/r03_lincomb_bn254.json
 [ -f $G/d_hyrax.jsonl ] && cp $G/d_hyrax.jsonl profiles/r03_hyrax_bn254.jsonl
+[ -f $G/d_msm_size_sweep.json ] && cp $G/d_msm_size_sweep.json profiles/r03_msm_size_sweep.json
 cp $G/d_prof24/bench_kernel_stats.csv profiles/r03_bench_2p24_kernel_stats.csv
 cp $G/d_prof20/bench_kernel_stats.csv profiles/r03_bench_2p20_kernel_stats.csv
 cp $G/d_profntt/bench_kernel_stats.csv profiles/r03_ntt_kernel_stats.csv

@@ -21,6 +21,7 @@ timeout -k 10 600 python bench.py --workload batch > gpurun_out/d_bench_batch.js
 timeout -k 10 300 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_out/d_ipa_2p22.json
 timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/d_lincomb.json
 timeout -k 10 300 python tools/hyrax_timing.py 2>/dev/null | grep workload > gpurun_out/d_hyrax.jsonl
+PC_SWEEP_LOGS=8,10,12,14,16,18,20,22 timeout -k 10 300 python tools/msm_size_sweep.py 2>/dev/null | tail -1 > gpurun_out/d_msm_size_sweep.json
 
 
 cd /tmp && export TMPDIR=/tmp
