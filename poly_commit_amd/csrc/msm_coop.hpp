@@ -67,6 +67,120 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t 
   }
 }
 
+// ---- the same level with TWO lanes per point ---------------------------------------------------------------------------
+// A cooperative level is a chain of log2(K) dependent additions on a lone wave per SIMD: its time is the latency of one XYZZ
+// addition (12M + 2S, ~17 us) times the number of bits.  Here an even lane holds (X, ZZ) and its odd neighbour (Y, ZZZ) of the
+// same point, and the addition is laid out so that both run the SAME instruction stream on their halves:
+//   slot 1  A1*B2          U1            | S1              4  B1*B2     ZZ1*ZZ2      | ZZZ1*ZZZ2
+//        2  A2*B1          U2            | S2              5  D*DD      PPP          | (unused)
+//           D = T2 - T1    P             | R                  exchange: even <- RR, odd <- PPP
+//        3  D^2            PP            | RR              6  U1*PP = Q              | ZZZ12*PPP = ZZZ3
+//                                                             X3 = RR - PPP - 2Q, exchange: odd <- Q - X3
+//                                                          7  ZZ12*PP = ZZ3          | R*(Q - X3) - S1*PPP = Y3   (fused pair)
+// 7.3 multiplication times instead of 13, three neighbour exchanges (DPP quad_perm [1,0,3,2]).  Same formulas, same
+// intermediate values as XyzzD::add: the results are bit-identical.  Equal x (doubling / P + (-P)) gathers the whole point into
+// both lanes and runs XyzzD::dbl (rare).  Used for the levels that are latency-bound (few points); wide levels keep one lane
+// per point (twice the lanes would only add work there).
+template <class C>
+struct HalfPt {
+  typedef Fd<typename C::FqP> Fq;
+  Fq a, b;        // even lane: X, ZZ   odd lane: Y, ZZZ
+};
+
+template <class Fq>
+__device__ __forceinline__ Fq lane_xchg(const Fq& v) {       // the value of the neighbour lane (lane ^ 1)
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < Fq::N; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xB1, 0xF, 0xF, true);
+  return r;
+}
+template <class Fq>
+__device__ __forceinline__ Fq lane_sel(bool c, const Fq& x, const Fq& y) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < Fq::N; i++) r.l[i] = c ? x.l[i] : y.l[i];
+  return r;
+}
+
+template <class C>
+__device__ __forceinline__ void half_add(HalfPt<C>& p, const HalfPt<C>& o, bool odd) {
+  typedef Fd<typename C::FqP> Fq;
+  if (o.b.is_zero()) return;                      // infinity has ZZ = ZZZ = 0: both lanes of a pair agree
+  if (p.b.is_zero()) { p = o; return; }
+  const Fq T1 = p.a.mul(o.b), T2 = o.a.mul(p.b);
+  const Fq D = T2.sub(T1);
+  const int dz = D.is_zero() ? 1 : 0, dz_nb = __builtin_amdgcn_mov_dpp(dz, 0xB1, 0xF, 0xF, true);
+  const bool pz = odd ? dz_nb != 0 : dz != 0, rz = odd ? dz != 0 : dz_nb != 0;
+  if (pz) {                                       // same x
+    const Fq na = lane_xchg(p.a), nb = lane_xchg(p.b);
+    XyzzD<C> f;
+    f.X = lane_sel(odd, na, p.a); f.Y = lane_sel(odd, p.a, na); f.ZZ = lane_sel(odd, nb, p.b); f.ZZZ = lane_sel(odd, p.b, nb);
+    const XyzzD<C> r = rz ? f.dbl() : XyzzD<C>::infinity();
+    p.a = lane_sel(odd, r.Y, r.X); p.b = lane_sel(odd, r.ZZZ, r.ZZ);
+    return;
+  }
+  const Fq DD = D.sqr();
+  const Fq BB = p.b.mul(o.b);
+  const Fq T5 = D.mul(DD);                                                    // even: PPP
+  const Fq rc1 = lane_xchg(lane_sel(odd, DD, T5));                            // even <- RR, odd <- PPP
+  const Fq R6 = lane_sel(odd, BB, T1).mul(lane_sel(odd, rc1, DD));            // even: Q, odd: ZZZ3
+  const Fq X3 = rc1.sub(T5).sub(R6.dbl());                                    // even: RR - PPP - 2Q
+  const Fq rc2 = lane_xchg(R6.sub(X3));                                       // odd <- Q - X3
+  const Fq R7 = lane_sel(odd, D, BB).mul_add_mul(lane_sel(odd, rc2, DD), lane_sel(odd, T1.neg(), Fq::zero()), lane_sel(odd, rc1, Fq::zero()));
+  p.a = lane_sel(odd, R7, X3);                                                // even: X3, odd: Y3
+  p.b = lane_sel(odd, R6, R7);                                                // even: ZZ3, odd: ZZZ3
+}
+
+// grid = cnt * (1 + n_old) workgroups of 2 K lanes; contract of k_bucket_level_coop
+template <class C>
+__global__ void __launch_bounds__(512) k_bucket_level_coop2(uint32_t K, uint32_t lgK, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
+                                                           const uint32_t* x, const uint32_t* old_in, uint32_t* out) {
+  PC_LATENCY_KERNEL();
+  typedef XyzzD<C> Pt;
+  typedef Fd<typename C::FqP> Fq;
+  constexpr int FN = Fq::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t a = blockIdx.x / cnt, gidx = blockIdx.x % cnt, tid = threadIdx.x, l = tid >> 1, L = 2 * K;
+  const bool odd = (tid & 1u) != 0;
+  const uint32_t oa = odd ? FN : 0, ob = odd ? 3 * FN : 2 * FN;               // where this lane's halves sit in a stored point
+  const size_t stride = (size_t)cnt * Pt::WORDS;
+  const uint32_t nw = lgK + weight_off;
+  const uint32_t* src = (a == 0) ? x + ((size_t)gidx * K + l) * Pt::WORDS
+                                 : old_in + ((size_t)(a - 1) * cnt * K + (size_t)gidx * K + l) * Pt::WORDS;
+  HalfPt<C> v; v.a = Fq::load(src + oa); v.b = Fq::load(src + ob);
+  auto put = [&]() {
+#pragma unroll
+    for (int k = 0; k < FN; k++) { smem[k * L + tid] = v.a.l[k]; smem[(FN + k) * L + tid] = v.b.l[k]; }
+  };
+  auto get = [&](uint32_t t2) {
+    HalfPt<C> r;
+#pragma unroll
+    for (int k = 0; k < FN; k++) { r.a.l[k] = smem[k * L + t2]; r.b.l[k] = smem[(FN + k) * L + t2]; }
+    return r;
+  };
+  auto store = [&](uint32_t* dst) { v.a.store(dst + oa); v.b.store(dst + ob); };
+  if (a == 0) {
+    for (uint32_t d = 0; d < lgK; d++) {
+      put();
+      __syncthreads();
+      const uint32_t low = l & ((2u << d) - 1u);
+      if ((low & (low - 1u)) == 0 && low < (1u << d)) half_add<C>(v, get(tid + (2u << d)), odd);
+      __syncthreads();
+    }
+    uint32_t* o = out + (size_t)gidx * Pt::WORDS;
+    if (l == 0) { store(o); if (weight_off) store(o + (size_t)(1 + lgK) * stride); }
+    else if ((l & (l - 1u)) == 0) { uint32_t b = 31 - __builtin_clz(l); store(o + (size_t)(1 + b) * stride); }
+  } else {
+    for (uint32_t d = K >> 1; d >= 1; d >>= 1) {
+      put();
+      __syncthreads();
+      if (l < d) half_add<C>(v, get(tid + 2 * d), odd);
+      __syncthreads();
+    }
+    if (l == 0) store(out + (size_t)(nw + a) * stride + (size_t)gidx * Pt::WORDS);
+  }
+}
+
 // Bucket accumulation with an in-workgroup merge of the runs that chunk edges cut.
 // AccumulateBody::chunk leaves, per lane, a partial for its first run when that run is not complete inside the chunk (slot 2t,
 // key k0) and one for its last run when that is a different run and continues in the next chunk (slot 2t + 1, key k1).  A bucket
