@@ -221,7 +221,7 @@ struct HipBackend {
 
   // one level of the bucket reduction (see BucketLevelBody / k_bucket_level_coop)
   template <class C>
-  void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, bool bits, const uint32_t* x,
+  void bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, int mode, const uint32_t* x,
                     const uint32_t* old_in, uint32_t* out);
 
   template <class Body>

@@ -72,19 +72,17 @@ void HipBackend::seg_reduce_tail(const MsmGeom& g, uint32_t level, uint32_t slot
 }
 
 template <class C>
-void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, bool bits, const uint32_t* x,
+void HipBackend::bucket_level(uint32_t K, uint32_t weight_off, uint32_t cnt, uint32_t n_old, int mode, const uint32_t* x,
                               const uint32_t* old_in, uint32_t* out) {
-  if (bits) {   // 16 <= K <= 256: one workgroup of K lanes per group
+  if (mode) {   // 16 <= K <= 256: one workgroup per group; mode 2: two lanes per point (K <= 128, latency-bound levels)
     uint32_t lgK = 0; while ((1u << lgK) < K) lgK++;
     size_t lds = (size_t)K * XyzzD<C>::WORDS * 4;
-    // few points: the level is a chain of dependent additions on lone waves -- two lanes per point (msm_coop.hpp)
-    static const uint32_t coop2_max = []() { const char* e = getenv("PC_HIP_COOP2_MAX_LOG2"); int v = e ? atoi(e) : 15; return v < 0 ? 0u : 1u << (v > 30 ? 30 : v); }();
-    if ((uint64_t)cnt * (1 + n_old) * K <= coop2_max)
+    if (mode == 2 && K <= 128)
       hipLaunchKernelGGL(k_bucket_level_coop2<C>, dim3(cnt * (1 + n_old)), dim3(2 * K), lds, stream, K, lgK, weight_off, cnt, n_old, x,
                          old_in, out);
     else
-    hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, lgK, weight_off, cnt, n_old, x,
-                       old_in, out);
+      hipLaunchKernelGGL(k_bucket_level_coop<C>, dim3(cnt * (1 + n_old)), dim3(K), lds, stream, K, lgK, weight_off, cnt, n_old, x,
+                         old_in, out);
     PC_HIP_CHECK(hipGetLastError());
   } else {
     BucketLevelBody<C> b{K, weight_off, cnt, n_old, x, old_in, out};

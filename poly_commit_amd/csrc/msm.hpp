@@ -588,6 +588,13 @@ struct MsmConfig {
   uint32_t K1 = 256;         // group size of the later, latency-bound levels (workgroup-cooperative on HIP)
   uint32_t target_lanes = 1u << 18;
   uint32_t seg_tail_lanes = 256;         // seg-reduce levels with at most this many lanes run inside one launch
+  uint32_t coop2_max_points = 1u << 15;  // cooperative levels of at most this many points (all arrays) run with two lanes per point
+                                         // (msm_coop.hpp): latency-bound chains; their groups are then at most 128 points, i.e.
+                                         // workgroups of 256 lanes that fit beside a resident accumulation workgroup (512-lane
+                                         // groups made the pipelined 2^20 step 9 % slower: they need a whole CU to themselves)
+  size_t coop2_max_entries = (size_t)1 << 22;   // ... and only in MSMs of at most this many entries (n x digits): at 2^20 pairs the
+                                         // blocking MSM gains 3.7 % (3.83 -> 3.69 ms) but the pipelined step loses 1.5 % (5.61 -> 5.70 ms:
+                                         // twice the lanes and one more launch compete with the next MSM's accumulation)
   uint32_t coop_max_points = 1u << 17;   // levels with more points than this use the serial fan-in K0 (cooperative levels from the
                                          // first level on -- 7 + 6 + 6 instead of 16 + 8 + 8 dependent additions at 2^19 buckets --
                                          // measured slower: bucket reduction 1.82 vs 1.55 ms on the same box; PC_HIP_COOP_MAX_LOG2)
@@ -802,7 +809,7 @@ class MsmPlan {
       const size_t stride = cnt * Pt::WORDS;
       const uint32_t n_old = l ? lvl_narr_[l - 1] : 0;  // previous level's arrays after its S array, contiguous
       const uint32_t* old_in = l ? prev_base + (size_t)g.W * lvl_m_[l - 1] * Pt::WORDS : nullptr;
-      be_.template bucket_level<C>(K, l == 0 ? 1u : 0u, (uint32_t)cnt, n_old, lvl_bits_[l] != 0, x, old_in, lvl_base);
+      be_.template bucket_level<C>(K, l == 0 ? 1u : 0u, (uint32_t)cnt, n_old, (int)lvl_bits_[l], x, old_in, lvl_base);
       x = lvl_base; prev_base = lvl_base; lvl_base += (size_t)(1 + lvl_narr_[l]) * stride;
     }
     be_.mark();   // 6: bucket reduction
@@ -857,12 +864,16 @@ class MsmPlan {
       // wide levels are throughput-bound: short serial chains (K0).  Once a level holds few enough
       // points the chain length is all that matters: workgroup-cooperative "bits" levels (K1).
       uint32_t K;
+      // points this level reads: groups x K x arrays (its weighted array and the older plain ones)
+      const size_t level_pts = (size_t)n * g_.Wd <= cfg_.coop2_max_entries ? (size_t)g_.W * m * (1 + (n_levels_ ? lvl_narr_[n_levels_ - 1] : 0))
+                                                                           : (size_t)-1;      // (no two-lane levels in large MSMs)
       if ((size_t)g_.W * m > cfg_.coop_max_points) K = tbl ? cfg_.tbl_K0 : cfg_.K0;
       else {
         // the remaining log2(m) bits are split evenly over the fewest cooperative levels of at most log2(K1) bits each:
         // the chain is one addition per bit, so 19 bits cost 7 + 6 + 6 dependent additions, not 8 + 8 + a serial tail
         uint32_t rem = 0; while ((1u << rem) < m) rem++;
         uint32_t lg1 = 0; while ((1u << lg1) < cfg_.K1) lg1++;
+        if (level_pts <= cfg_.coop2_max_points && lg1 > 7) lg1 = 7;      // two lanes per point: groups of at most 128
         const uint32_t nl = (rem + lg1 - 1) / lg1;
         K = 1u << ((rem + nl - 1) / nl);
       }
@@ -872,7 +883,7 @@ class MsmPlan {
       const uint32_t woff = n_levels_ == 0 ? 1u : 0u;
       const uint32_t nw = bits ? lgK + woff : 1u;
       lvl_K_[n_levels_] = K; m /= K; lvl_m_[n_levels_] = m;   // m = elements per window AFTER this level
-      lvl_bits_[n_levels_] = bits;
+      lvl_bits_[n_levels_] = !bits ? 0u : (K <= 128 && level_pts <= cfg_.coop2_max_points) ? 2u : 1u;
       lvl_narr_[n_levels_] = nw + (n_levels_ ? lvl_narr_[n_levels_ - 1] : 0);
       // weights of the new arrays (as powers of two), then the older arrays keep theirs
       std::vector<uint32_t> e;

@@ -131,9 +131,9 @@ __device__ __forceinline__ void half_add(HalfPt<C>& p, const HalfPt<C>& o, bool 
   p.b = lane_sel(odd, R6, R7);                                                // even: ZZ3, odd: ZZZ3
 }
 
-// grid = cnt * (1 + n_old) workgroups of 2 K lanes; contract of k_bucket_level_coop
+// grid = cnt * (1 + n_old) workgroups of 2 K <= 256 lanes; contract of k_bucket_level_coop
 template <class C>
-__global__ void __launch_bounds__(512) k_bucket_level_coop2(uint32_t K, uint32_t lgK, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
+__global__ void __launch_bounds__(256) k_bucket_level_coop2(uint32_t K, uint32_t lgK, uint32_t weight_off, uint32_t cnt, uint32_t n_old,
                                                            const uint32_t* x, const uint32_t* old_in, uint32_t* out) {
   PC_LATENCY_KERNEL();
   typedef XyzzD<C> Pt;
