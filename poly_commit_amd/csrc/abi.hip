@@ -583,7 +583,7 @@ int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* sc
     if (!n_msms) return (int)PC_OK;
     if (!m) { memset(out_xy, 0, n_msms * pb); if (out_is_infinity) for (size_t k = 0; k < n_msms; k++) out_is_infinity[k] = 1; return (int)PC_OK; }
     const uint32_t bits = srs->curve == PC_CURVE_BN254 ? 254u : 255u;
-    const uint32_t c = pc::msm_choose_table_c(m, bits), Wd = pc::msm_num_windows(bits, c);
+    const uint32_t c = pc::msm_choose_table_c(m, bits, 0), Wd = pc::msm_num_windows(bits, c);
     if ((uint64_t)n_msms * m * Wd >= (1ull << 31) || ((uint64_t)n_msms << (c - 1)) >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;
     pc_srs::Many& M = srs->many;
     if (!M.lane || M.base_offset != base_offset || M.m != m || M.B != n_msms) {

@@ -536,13 +536,15 @@ void build_window_table_batched(Backend& be, const uint32_t* bases, uint32_t n, 
 }
 
 // window width for the table mode: n * (bits/c + 1) mixed adds against ~3 * 2^(c-1) reduction adds
-inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255) {
+inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255, uint32_t min_top_bits = 5) {
   uint32_t best = 8; double best_cost = 1e300;
   for (uint32_t c = 8; c <= 23; c++) {
     // a top digit of fewer than 5 bits lands in <= 2^4 buckets with n / 2^4 .. n / 2 entries each: chains of hundreds of chunks
-    // (c = 11, 12, 14 at 255 bits; 2^14 pairs with c = 14: 8 buckets of 2048 entries, 7 scan steps in k_accumulate)
+    // (c = 11, 12, 14 at 255 bits; 2^14 pairs with c = 14: 8 buckets of 2048 entries, 7 scan steps in k_accumulate).  The many-MSM
+    // pass asks for no minimum: with a bucket set per sub-MSM the bucket count is what costs (Hyrax, 1024 x 1025 pairs: c = 13
+    // instead of 11 is 4 x the buckets, commit 4.2 -> 5.2 ms)
     const uint32_t Wd = scalar_bits / c + 1;
-    if (scalar_bits - (Wd - 1) * c < 5) continue;
+    if (scalar_bits - (Wd - 1) * c < min_top_bits) continue;
     double cost = (double)n * Wd + 3.0 * (double)((size_t)1 << (c - 1));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
