@@ -101,6 +101,36 @@ def test_msm_tunings(ctx, c, T):
         ctx.set_msm_tuning(0, 0)
 
 
+@pytest.mark.parametrize("T", [1, 2, 5, 8])
+@pytest.mark.parametrize("n,table", [(700, False), (5000, True), (40000, False), (70001, True)])
+def test_msm_chains_of_cut_buckets(ctx, T, n, table):
+    """The joins of buckets that chunk edges cut (k_accumulate's in-workgroup scan, k_accumulate_edges, the segmented reduction
+    behind them): small chunks against distributions whose buckets span a few lanes, a whole workgroup, several workgroups --
+    uniform, a handful of values, all equal, mostly zero -- with and without the window table; bit-identical to the oracle."""
+    curve = "bls12_381"
+    bases = O.gen_bases(curve, n)
+    rnd = O.gen_scalars(curve, 0xC4A1 + n, n)
+    idx = np.arange(n)
+    dists = {
+        "uniform": rnd,
+        "five_values": np.ascontiguousarray(rnd[idx % 5]),
+        "all_equal": np.ascontiguousarray(np.repeat(rnd[:1], n, axis=0)),
+        "runs": np.ascontiguousarray(rnd[idx // 300]),
+        "sparse": np.ascontiguousarray(np.where((idx % 13 == 0)[:, None], rnd, 0).astype(np.uint64)),
+    }
+    ctx.set_msm_tuning(0, T)
+    try:
+        srs = ctx.upload_srs(curve, bases)
+        if table:
+            srs.precompute()
+        for name, sc in dists.items():
+            got, _ = srs.msm(sc)
+            assert (got == O.msm_pippenger(curve, bases, sc, 8, 1)).all(), (name, T, n, table)
+        srs.free()
+    finally:
+        ctx.set_msm_tuning(0, 0)
+
+
 def test_msm_linearity(ctx):
     """commit(f*p) == f*commit(p): add_commitments_test, kzg10/mod.rs:520-544."""
     curve = "bls12_381"
