@@ -876,6 +876,36 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
             ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=N)
         torch.cuda.synchronize()
         merkle_ms = (time.perf_counter() - t0) / 3 * 1e3
+    # N > 1: a column's digest needs the rows of every rank -- the digests' chaining states travel from rank to rank
+    # (ShardedRows.commit / pc_hip_column_hash_part: 48 bytes per column and hop instead of a transpose of the matrix), the last
+    # rank builds the tree and broadcasts the root
+    chain = None
+    if world > 1:
+        root, _ = shard.commit(y, n_rows, N, D.dist, "blake2s", "sha256", blocks=8)
+        torch.cuda.synchronize()
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            root2, _ = shard.commit(y, n_rows, N, D.dist, "blake2s", "sha256", blocks=8)
+        torch.cuda.synchronize()
+        D.barrier()
+        chain_ms = (time.perf_counter() - t0) / 3 * 1e3
+        roots = D.gather_u64(np.frombuffer(bytes(root) , dtype=np.uint64))
+        same = bool((roots == roots[0]).all()) and bytes(root2) == bytes(root)
+        ok_root = None
+        if n_rows % (2 * world) == 0 and n_rows * N * 32 <= (64 << 20):      # small enough to re-hash the whole matrix on the host
+            import hashlib
+            import pyref as R
+            full = D.gather_u64(host_u64(y).reshape(-1))
+            if rank == 0:
+                can = np.ascontiguousarray(O.f_from_mont(curve, 1, full.reshape(-1, 4))).view(np.uint8).reshape(n_rows, N, 32)
+                pre = int(n_rows).to_bytes(8, "little")
+                leaves = [hashlib.blake2s(pre + can[:, j, :].tobytes()).digest() for j in range(N)]
+                ok_root = R.merkle_tree(leaves, "sha256", True)[0] == bytes(root)
+        chain = {"column_digests_and_tree_ms": chain_ms, "root_equal_on_all_ranks": same, "root_vs_host_rehash_ok": ok_root,
+                 "bytes_per_hop": N * 48,
+                 "note": "chained column digests: rank r absorbs its rows into the states rank r - 1 left, 8 column ranges in flight; "
+                         "root re-hashed on the host (hashlib) when the whole matrix is at most 64 MB"}
     # parity (test_reed_solomon's property, linear_codes/utils.rs:303-331): out[r][j] == row_r(omega^j), a few rows and
     # columns by the oracle's Horner; one whole row against the oracle's NTT
     w = from_mont_limbs(curve, O.root_of_unity(curve, log_n))
@@ -898,7 +928,7 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
             "value": world * rows * n_cols * steps / dt, "unit": "coeffs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "per_rank_ms_per_step": [float(v) / steps * 1e3 for v in per_rank],
             "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
-            "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms,
+            "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms, "sharded_commit": chain,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS if achieved else None,
                          "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
@@ -1050,9 +1080,11 @@ def main():
                   "value": r["value"], "unit": "coeffs/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
                   "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                   "dtype": "u32 limbs (255-bit Fr modular integer)", "data": "synthetic", "dist": D.info(),
-                  "config": {"workload": r["workload"], "parallelism": "1 GPU" if world == 1 else f"rows sharded over {world} GPUs, no collective"},
-                  **{k: r[k] for k in ("per_rank_ms_per_step", "ntt_phase_ms", "column_hash_blake2s_ms", "merkle_tree_sha256_ms", "roofline", "parity")}})
+                  "config": {"workload": r["workload"], "parallelism": "1 GPU" if world == 1 else f"rows sharded over {world} GPUs: no collective for the NTTs, 48 bytes per column and hop for the column digests"},
+                  **{k: r[k] for k in ("per_rank_ms_per_step", "ntt_phase_ms", "column_hash_blake2s_ms", "merkle_tree_sha256_ms", "sharded_commit", "roofline", "parity")}})
         ok = r["parity"]["horner_spot_checks_ok"] and r["parity"]["one_row_vs_oracle_ntt_ok"]
+        if r["sharded_commit"] is not None:
+            ok = ok and r["sharded_commit"]["root_equal_on_all_ranks"] and r["sharded_commit"]["root_vs_host_rehash_ok"] is not False
         D.close()
         if not ok:
             raise SystemExit("parity check FAILED")

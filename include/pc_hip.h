@@ -192,6 +192,20 @@ int pc_hip_last_ntt_phases_ms(const pc_ctx* ctx, float out[2]);
 int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_mem where_in, size_t rows,
                        size_t n_cols, pc_hash hash, void* out_digests, pc_mem where_out);
 
+/* The same digests when the rows of the encoded matrix are spread over several devices (the rows of
+ * LinearEncode::compute_matrices are independent, linear_codes/mod.rs:131-135, but the column hash of :256-263 needs a whole
+ * column): every device absorbs ITS slab of `rows` consecutive rows (ext_slab_dev: rows x n_cols, device memory) into the
+ * digests' chaining states of the columns [col0, col0 + cols) and the states travel from device to device -- 48 bytes per
+ * column instead of a transpose of the matrix.  state_dev: n_cols x 48 bytes, indexed by column (12 words: the digest's h,
+ * its byte counter, and the 8 message bytes that straddle the slab edge: the u64 length prefix shifts the 32-byte elements by
+ * 8 against the 64-byte blocks); read unless `first`, written unless `last`.  first != 0: this slab starts the columns (IV,
+ * length prefix of rows_total elements); last != 0: this slab ends them, out_digests_dev (n_cols x 32 bytes, device) receives
+ * the digests of the columns of the range -- bit-identical to pc_hip_column_hash of the whole matrix.  Slabs other than the
+ * last hold an even number of rows (PC_ERR_UNSUPPORTED otherwise). */
+int pc_hip_column_hash_part(pc_ctx* ctx, pc_curve field_of, pc_hash hash, const void* ext_slab_dev, size_t rows,
+                            size_t n_cols, size_t rows_total, size_t col0, size_t cols, int first, int last,
+                            void* state_dev, void* out_digests_dev);
+
 /* Merkle tree over the column digests: create_merkle_tree, poly-commit/src/linear_codes/
  * mod.rs:506-521 (called at :270-274) -> ark_crypto_primitives MerkleTree::new, for the Config
  * the reference's tests and benches instantiate (linear_codes/univariate_ligero/tests.rs:21-37):

@@ -84,6 +84,7 @@ def load_library():
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
     lib.pc_hip_column_hash.argtypes = [vp, ip, vp, ip, sz, sz, ip, vp, ip]
+    lib.pc_hip_column_hash_part.argtypes = [vp, ip, ip, vp, sz, sz, sz, sz, sz, ip, ip, vp, vp]
     lib.pc_hip_merkle_tree.argtypes = [vp, ip, vp, ip, sz, ip, vp, ip]
     lib.pc_hip_ligero_commit.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, ip, ip, ip, vp, ip, vp, vp]
     lib.pc_hip_last_ligero_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -208,6 +209,15 @@ class Context:
         hid = {"sha256": 0, "blake2s": 1}[hash_name]
         self.check(self.lib.pc_hip_column_hash(self.h, CURVES[curve], pin, win, rows, n_cols, hid, pout, wout))
         return out
+
+    def column_hash_part(self, curve, slab_dev, rows, n_cols, rows_total, state_dev, first, last, out_dev=0, hash_name="blake2s",
+                         col0=0, cols=None):
+        """One slab of rows absorbed into the per-column chaining states (pc_hip_column_hash_part): device pointers only.
+        state_dev: n_cols x 48 bytes; out_dev: n_cols x 32 bytes, written when `last`."""
+        hid = {"sha256": 0, "blake2s": 1}[hash_name]
+        self.check(self.lib.pc_hip_column_hash_part(self.h, CURVES[curve], hid, C.c_void_p(slab_dev), rows, n_cols, rows_total, col0,
+                                                    n_cols - col0 if cols is None else cols, 1 if first else 0, 1 if last else 0,
+                                                    C.c_void_p(state_dev), C.c_void_p(out_dev)))
 
     def matrix_columns(self, mat_dev, rows, n_cols, indices):
         """Columns `indices` of a resident rows x n_cols matrix of 32-byte elements -> (t, rows, 4) uint64 host array."""

@@ -753,6 +753,23 @@ int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_m
   });
 }
 
+int pc_hip_column_hash_part(pc_ctx* ctx, pc_curve field_of, pc_hash hash, const void* ext_slab_dev, size_t rows, size_t n_cols, size_t rows_total,
+                            size_t col0, size_t cols, int first, int last, void* state_dev, void* out_digests_dev) {
+  if (!ctx || (int)field_of < 0 || (int)field_of > 2 || ((int)hash != PC_HASH_SHA256 && (int)hash != PC_HASH_BLAKE2S)) return PC_ERR_INVALID_ARG;
+  if (rows >= (1ull << 32) || n_cols >= (1ull << 32) || rows_total >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  if (col0 > n_cols || cols > n_cols - col0 || rows > rows_total || (rows && cols && !ext_slab_dev)) return PC_ERR_INVALID_ARG;
+  if (cols && ((!(first && last) && !state_dev) || (last && !out_digests_dev))) return PC_ERR_INVALID_ARG;
+  if (!last && (rows & 1)) return PC_ERR_UNSUPPORTED;             // two rows fill one block: only the last slab may be odd
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (!cols) return (int)PC_OK;
+    pc::field_ops(field_of).column_hash_part(ctx->be, (int)hash, (const uint32_t*)ext_slab_dev, (uint32_t)rows, (uint32_t)n_cols, (uint32_t)rows_total,
+                                             (uint32_t)col0, (uint32_t)cols, first, last, (uint32_t*)state_dev, (uint32_t*)out_digests_dev);
+    ctx->be.sync();
+    return (int)PC_OK;
+  });
+}
+
 int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n, const void* z_host,
                         void* out, pc_mem where_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || !z_host || (n && !coeffs) || (n > 1 && !out)) return PC_ERR_INVALID_ARG;

@@ -92,8 +92,14 @@ struct FieldOpsImpl {
     if (hash == PC_HASH_SHA256) { ColumnHashBody<FrP, Sha256> b{e, rows, n_cols, o}; be.launch(b, n_cols, 64); }
     else { ColumnHashBody<FrP, Blake2s256> b{e, rows, n_cols, o}; be.launch(b, n_cols, 64); }
   }
+  static void column_hash_part(HipBackend& be, int hash, const uint32_t* e, uint32_t rows, uint32_t n_cols, uint32_t rows_total, uint32_t col0,
+                               uint32_t cols, int first, int last, uint32_t* state, uint32_t* o) {
+    if (hash == PC_HASH_SHA256) { ColumnHashPartBody<FrP, Sha256> b{e, rows, n_cols, rows_total, col0, (uint32_t)first, (uint32_t)last, state, o}; be.launch(b, cols, 64); }
+    else { ColumnHashPartBody<FrP, Blake2s256> b{e, rows, n_cols, rows_total, col0, (uint32_t)first, (uint32_t)last, state, o}; be.launch(b, cols, 64); }
+  }
   static FieldOps table() {
-    return FieldOps{&make_ntt, &poly_eval_f, &div_scan_f, &witness_f, &fr_fold, &fr_dot, &ipa_fold_dots, &fr_powers, &ipa_key_scalars, &fr_lincomb, &column_hash};
+    return FieldOps{&make_ntt, &poly_eval_f, &div_scan_f, &witness_f, &fr_fold, &fr_dot, &ipa_fold_dots, &fr_powers, &ipa_key_scalars, &fr_lincomb, &column_hash,
+                    &column_hash_part};
   }
 };
 

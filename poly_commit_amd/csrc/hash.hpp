@@ -23,6 +23,9 @@ PC_HD uint32_t bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | (
 struct Sha256 {
   uint32_t h[8], buf[16], nbuf; uint64_t bytes;
   PC_HD void init() { PC_UNROLL for (int i = 0; i < 8; i++) h[i] = pc_hash_constants::IV[i]; nbuf = 0; bytes = 0; }
+  // chaining state between whole blocks (nbuf == 0): h and the byte counter, 10 words
+  PC_HD void export_state(uint32_t* o) const { PC_UNROLL for (int i = 0; i < 8; i++) o[i] = h[i]; o[8] = (uint32_t)bytes; o[9] = (uint32_t)(bytes >> 32); }
+  PC_HD void import_state(const uint32_t* o) { PC_UNROLL for (int i = 0; i < 8; i++) h[i] = o[i]; bytes = (uint64_t)o[8] | ((uint64_t)o[9] << 32); nbuf = 0; }
   PC_HD void compress() {
     uint32_t w[16], s[8];
     PC_UNROLL for (int i = 0; i < 16; i++) w[i] = buf[i];
@@ -81,6 +84,8 @@ struct Blake2s256 {
     h[0] ^= 0x01010020u;   // digest length 32, no key, fanout 1, depth 1
     nbuf = 0; t = 0;
   }
+  PC_HD void export_state(uint32_t* o) const { PC_UNROLL for (int i = 0; i < 8; i++) o[i] = h[i]; o[8] = (uint32_t)t; o[9] = (uint32_t)(t >> 32); }
+  PC_HD void import_state(const uint32_t* o) { PC_UNROLL for (int i = 0; i < 8; i++) h[i] = o[i]; t = (uint64_t)o[8] | ((uint64_t)o[9] << 32); nbuf = 0; }
   PC_HD void compress(bool last) {
     uint32_t v[16], m[16];
     PC_UNROLL for (int i = 0; i < 16; i++) m[i] = buf[i];
@@ -170,6 +175,57 @@ struct ColumnHashBody {
       d.template finish_tail<10>(tail, dig);
     } else d.template finish_tail<2>(carry, dig);
     PC_UNROLL for (int k = 0; k < 8; k++) out[(size_t)j * 8 + k] = dig[k];
+  }
+};
+
+// The same digests when the ROWS of the encoded matrix are spread over several devices (rows are independent for
+// the NTT, but a column's digest needs all of its rows).  Instead of transposing 2 GiB between the devices, the digest's CHAINING
+// STATE travels: device d absorbs its slab of rows [r0, r0 + rows) into the state device d - 1 left for every column, and hands
+// on 48 bytes per column (h, byte counter, the 8 message bytes that straddle the slab edge -- the u64 length prefix shifts every
+// 32-byte element by 8 against the 64-byte blocks).  state[j] = 12 words: export_state (10) | carry (2).  `first`: start from
+// the IV and the length prefix of the WHOLE column (rows_total); `last`: finish and write the digest.  Slabs of devices that are
+// not the last hold an even number of rows (two rows fill one block).
+template <class FrP, class D>
+struct ColumnHashPartBody {
+  typedef Fd<FrP> F;
+  const uint32_t* ext;   // rows x n_cols elements of this slab, row-major, Montgomery
+  uint32_t rows, n_cols, rows_total, col0, first, last;
+  uint32_t* state;       // n_cols x 12 words, read unless `first`, written unless `last`
+  uint32_t* out;         // n_cols x 8 words, written when `last`
+  PC_HD F row(uint32_t r, uint32_t j) const { return F::load(ext + ((size_t)r * n_cols + j) * FrP::N); }
+  PC_HD void operator()(uint32_t lane) const {
+    static_assert(FrP::N == 8, "32-byte scalar-field elements");
+    const uint32_t j = col0 + lane;
+    D d; uint32_t carry[2];
+    if (first) { d.init(); carry[0] = rows_total; carry[1] = 0u; }
+    else { uint32_t st[12]; PC_UNROLL for (int k = 0; k < 12; k++) st[k] = state[(size_t)j * 12 + k]; d.import_state(st); carry[0] = st[10]; carry[1] = st[11]; }
+    F a = rows > 0 ? row(0, j) : F::zero(), b = rows > 1 ? row(1, j) : F::zero();
+    uint32_t r = 0;
+    for (; r + 2 <= rows; r += 2) {
+      const F ca = a.from_mont(), cb = b.from_mont();
+      if (r + 2 < rows) a = row(r + 2, j);
+      if (r + 3 < rows) b = row(r + 3, j);
+      uint32_t m[16];
+      m[0] = carry[0]; m[1] = carry[1];
+      PC_UNROLL for (int k = 0; k < 8; k++) m[2 + k] = ca.l[k];
+      PC_UNROLL for (int k = 0; k < 6; k++) m[10 + k] = cb.l[k];
+      carry[0] = cb.l[6]; carry[1] = cb.l[7];
+      d.absorb_block(m);
+    }
+    if (last) {
+      uint32_t dig[8];
+      if (r < rows) {
+        const F ca = a.from_mont();
+        uint32_t tail[10];
+        tail[0] = carry[0]; tail[1] = carry[1];
+        PC_UNROLL for (int k = 0; k < 8; k++) tail[2 + k] = ca.l[k];
+        d.template finish_tail<10>(tail, dig);
+      } else d.template finish_tail<2>(carry, dig);
+      PC_UNROLL for (int k = 0; k < 8; k++) out[(size_t)j * 8 + k] = dig[k];
+    } else {                                                    // (rows is even here: checked by the caller)
+      uint32_t st[12]; d.export_state(st); st[10] = carry[0]; st[11] = carry[1];
+      PC_UNROLL for (int k = 0; k < 12; k++) state[(size_t)j * 12 + k] = st[k];
+    }
   }
 };
 

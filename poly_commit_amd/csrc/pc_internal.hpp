@@ -65,6 +65,9 @@ struct FieldOps {
                           uint32_t* out_l, uint32_t* out_r);
   void (*fr_lincomb)(HipBackend& be, const void* addr, const void* lens, const void* xi, size_t k, void* out, size_t n_out);
   void (*column_hash)(HipBackend& be, int hash, const uint32_t* ext, uint32_t rows, uint32_t n_cols, uint32_t* out);
+  // one slab of rows absorbed into the per-column chaining states (hash.hpp, ColumnHashPartBody); columns [col0, col0 + cols)
+  void (*column_hash_part)(HipBackend& be, int hash, const uint32_t* ext, uint32_t rows, uint32_t n_cols, uint32_t rows_total, uint32_t col0,
+                           uint32_t cols, int first, int last, uint32_t* state, uint32_t* out);
 };
 
 // (accessor functions rather than global tables: a namespace-scope constant would also be emitted into the

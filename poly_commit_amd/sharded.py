@@ -155,6 +155,26 @@ class HipEngine:
         self.ctx.ntt_batch(self.curve, self._ptr(rows_buf), log_n, out=self._ptr(out_buf), rows=n_rows, in_cols=in_cols)
         return out_buf
 
+    # ---- column digests of a matrix whose rows are spread over the ranks (ShardedRows.commit) ----
+    def state_buffer(self, n_cols):
+        import torch
+        return torch.zeros((n_cols, 12), dtype=torch.int32, device="cuda")      # pc_hip_column_hash_part: 48 bytes per column
+
+    def digest_buffer(self, n_cols):
+        import torch
+        return torch.zeros((n_cols, 8), dtype=torch.int32, device="cuda")
+
+    def column_hash_part(self, slab, rows, n_cols, rows_total, state, first, last, out, hash_name, col0, cols):
+        self.ctx.column_hash_part(self.curve, self._ptr(slab) if rows else 0, rows, n_cols, rows_total, state.data_ptr(), first, last,
+                                  out.data_ptr() if out is not None else 0, hash_name, col0, cols)
+
+    def merkle_nodes(self, digests, n_leaves, tree_hash):
+        """(2^h - 1, 32) uint8 node array (root at row 0) over the resident leaf digests."""
+        h = max(1, (n_leaves - 1).bit_length())
+        nodes = np.zeros(((1 << h) - 1, 32), dtype=np.uint8)
+        self.ctx.merkle_tree(digests.data_ptr(), tree_hash, True, out=nodes, n_leaves=n_leaves)
+        return nodes
+
 
 class ShardedKzg:
     def __init__(self, engine, curve, rank=0, world=1, dist=None):
@@ -307,12 +327,55 @@ class ShardedRows:
     def __init__(self, engine, rank=0, world=1):
         self.e, self.rank, self.world = engine, rank, world
 
-    def row_range(self, n_rows):
+    def row_range(self, n_rows, rank=None):
+        # an even number of rows per rank (two 32-byte rows fill one 64-byte block of the column digests: commit() below)
         per = (n_rows + self.world - 1) // self.world
-        return min(n_rows, self.rank * per), min(n_rows, (self.rank + 1) * per)
+        per += per & 1 if self.world > 1 else 0
+        r = self.rank if rank is None else rank
+        return min(n_rows, r * per), min(n_rows, (r + 1) * per)
 
     def encode(self, rows_buf, n_rows_local, in_cols, log_n, out_buf=None):
         return self.e.ntt_rows(rows_buf, n_rows_local, in_cols, log_n, out_buf)
+
+    def commit(self, ext_slab, n_rows, n_ext_cols, dist, col_hash="blake2s", tree_hash="sha256", blocks=4):
+        """Steps 2-3 of LinearCodePCS::commit (linear_codes/mod.rs:256-277) over an encoded matrix whose ROWS live on different
+        ranks (`ext_slab`: this rank's rows of row_range(n_rows), the output of encode()).  A column's digest needs all of its
+        rows; instead of transposing the matrix between the devices (2 GiB at BASELINE configs[4]) the digests' chaining states
+        travel: rank r absorbs its slab into the states rank r - 1 left (pc_hip_column_hash_part) and hands on 48 bytes per
+        column, in `blocks` column ranges so that rank r + 1 works on range b while rank r is on range b + 1.  The last rank
+        that holds rows finishes the digests, builds the Merkle tree and broadcasts the root.
+        Returns (root: 32 bytes, nodes: the whole node array on the rank that built it, else None)."""
+        import torch
+        e = self.e
+        wire = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+        ranges = [self.row_range(n_rows, r) for r in range(self.world)]
+        active = [r for r in range(self.world) if ranges[r][1] > ranges[r][0]]
+        lo, hi = ranges[self.rank]
+        root = torch.zeros(32, dtype=torch.uint8, device=wire)
+        nodes = None
+        if self.rank in active:
+            k = active.index(self.rank)
+            first, last = k == 0, k == len(active) - 1
+            state = e.state_buffer(n_ext_cols)
+            digests = e.digest_buffer(n_ext_cols) if last else None
+            nb = max(1, min(blocks, n_ext_cols))
+            for b in range(nb):
+                c0, c1 = n_ext_cols * b // nb, n_ext_cols * (b + 1) // nb
+                if c1 == c0:
+                    continue
+                if not first:
+                    buf = torch.empty((c1 - c0, 12), dtype=torch.int32, device=wire)
+                    dist.recv(buf, src=active[k - 1])
+                    state[c0:c1].copy_(buf)
+                e.column_hash_part(ext_slab, hi - lo, n_ext_cols, n_rows, state, first, last, digests, col_hash, c0, c1 - c0)
+                if not last:
+                    dist.send(state[c0:c1].to(wire).contiguous(), dst=active[k + 1])
+            if last:
+                nodes = e.merkle_nodes(digests, n_ext_cols, tree_hash)
+                root = torch.from_numpy(nodes[0].copy()).to(wire)
+        if dist is not None and self.world > 1:
+            dist.broadcast(root, src=active[-1])
+        return root.cpu().numpy(), nodes
 
 
 class _Future:

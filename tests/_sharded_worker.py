@@ -58,6 +58,40 @@ class OracleEngine:
     def ntt_rows(self, rows_buf, n_rows, in_cols, log_n, out_buf):
         return O.ntt_batch(self.curve, np.ascontiguousarray(rows_buf[:n_rows]), log_n, threads=1)
 
+    # chained column digests (ShardedRows.commit): BLAKE2s with an explicit state (tests/_blake2s_state.py)
+    def state_buffer(self, n_cols):
+        import torch
+        return torch.zeros((n_cols, 12), dtype=torch.int32)
+
+    def digest_buffer(self, n_cols):
+        import torch
+        return torch.zeros((n_cols, 8), dtype=torch.int32)
+
+    def column_hash_part(self, slab, rows, n_cols, rows_total, state, first, last, out, hash_name, col0, cols):
+        import _blake2s_state as B
+        assert hash_name == "blake2s"
+        st = state.numpy().view(np.uint32)
+        can = O.fr_from_mont_array(self.curve, np.ascontiguousarray(slab).reshape(-1, 4)) if rows else []
+        for j in range(col0, col0 + cols):
+            if first:
+                (h, t), pending = B.init(), int(rows_total).to_bytes(8, "little")
+            else:
+                h, t = [int(x) for x in st[j, :8]], int(st[j, 8]) | (int(st[j, 9]) << 32)
+                pending = int(st[j, 10]).to_bytes(4, "little") + int(st[j, 11]).to_bytes(4, "little")
+            data = b"".join(int(can[r * n_cols + j]).to_bytes(32, "little") for r in range(rows))
+            if last:
+                out.numpy().view(np.uint8).reshape(-1, 32)[j] = np.frombuffer(B.absorb(h, t, pending, data, True), dtype=np.uint8)
+            else:
+                h, t, pending = B.absorb(h, t, pending, data, False)
+                assert len(pending) == 8
+                st[j, :8] = h
+                st[j, 8], st[j, 9] = t & 0xFFFFFFFF, t >> 32
+                st[j, 10], st[j, 11] = int.from_bytes(pending[:4], "little"), int.from_bytes(pending[4:], "little")
+
+    def merkle_nodes(self, digests, n_leaves, tree_hash):
+        leaves = [bytes(x) for x in digests.numpy().view(np.uint8).reshape(-1, 32)[:n_leaves]]
+        return np.frombuffer(b"".join(R.merkle_tree(leaves, tree_hash, True)), dtype=np.uint8).reshape(-1, 32)
+
 
 def main():
     dist.init_process_group("gloo")
@@ -138,6 +172,19 @@ def main():
             else:
                 out = rows.encode(local, r_hi - r_lo, n_cols, log_n)
             ok &= bool((out == want[r_lo:r_hi]).all())
+        # the commitment's root with the rows spread over the ranks: chained column digests, tree on the last rank with rows
+        fr = R.CURVES[curve]["fr"]
+        cols_can = O.fr_from_mont_array(curve, np.ascontiguousarray(want).reshape(-1, 4))
+        n_ext = 1 << log_n
+        leaves = [R.column_digest(fr, [cols_can[r * n_ext + j] for r in range(n_rows)], "blake2s") for j in range(n_ext)]
+        want_root = R.merkle_tree(leaves, "sha256", True)[0]
+        if use_hip:
+            slab = y if r_hi > r_lo else None
+        else:
+            slab = out if r_hi > r_lo else None
+        for nb in (1, 3):
+            root, nodes = rows.commit(slab, n_rows, n_ext, dist, "blake2s", "sha256", blocks=nb)
+            ok &= bytes(root) == want_root
         # every row is owned exactly once
         owned = np.zeros(n_rows, dtype=np.int64)
         owned[r_lo:r_hi] = 1

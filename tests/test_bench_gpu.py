@@ -65,6 +65,8 @@ def test_two_ranks_batch_and_rows():
     assert d["n_gpus"] == 2 and d["parity"]["all_commitments_closed_form_ok"] and d["parity"]["oracle_horner_ok"]
     d = run_bench(["--gpus", "2", "--workload", "ntt", "--small", "--steps", "2"], {"PC_BENCH_DEVICES": "0,0"})
     assert d["n_gpus"] == 2 and d["parity"]["horner_spot_checks_ok"] and d["parity"]["one_row_vs_oracle_ntt_ok"]
+    # the commitment's root over rows that live on two ranks (chained column digests), re-hashed on the host
+    assert d["sharded_commit"]["root_equal_on_all_ranks"] and d["sharded_commit"]["root_vs_host_rehash_ok"] is True
 
 
 def test_group_mode_one_process():

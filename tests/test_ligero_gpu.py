@@ -74,3 +74,36 @@ def test_multilinear_ligero_device(ctx):
     value = R.mle_evaluate(fr, evals, point)
     assert ligero.check(ctx, curve, com, None, m([value])[0], pr, idx, m(r), rho_inv=2, tensors=ab) is True
     assert ligero.check(ctx, curve, com, None, m([value + 1])[0], pr, idx, m(r), rho_inv=2, tensors=ab) is False
+
+
+@pytest.mark.parametrize("curve,hash_name", [("bls12_381", "blake2s"), ("bn254", "sha256"), ("pallas", "blake2s")])
+def test_column_digests_chained_over_row_slabs(ctx, curve, hash_name):
+    """pc_hip_column_hash_part: the digests of the columns of a matrix whose rows arrive slab by slab (the rows of the encoded
+    matrix on different devices, ShardedRows.commit) -- the chaining state of every column handed from slab to slab -- are the
+    digests of pc_hip_column_hash over the whole matrix and of the oracle (FieldToBytesColHasher, bench-templates/src/lib.rs:
+    327-337), for even slabs, an odd last slab, column ranges, one slab that is first and last; an odd slab that is not the last
+    is refused."""
+    import torch
+    import poly_commit_amd as pc
+    rows, n_cols = 23, 96
+    mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x51AB, rows * n_cols)).reshape(rows, n_cols, 4)
+    fr = R.CURVES[curve]["fr"]
+    can = O.fr_from_mont_array(curve, np.ascontiguousarray(mat).reshape(-1, 4))
+    want = np.stack([np.frombuffer(R.column_digest(fr, [can[r * n_cols + j] for r in range(rows)], hash_name), dtype=np.uint8) for j in range(n_cols)])
+    assert (ctx.column_hash(curve, mat, hash_name) == want).all()
+    dev = torch.from_numpy(np.ascontiguousarray(mat).view(np.int64)).cuda()
+    for cuts in ([0, 23], [0, 8, 23], [0, 2, 4, 22, 23], [0, 10, 20, 23]):
+        state = torch.zeros((n_cols, 12), dtype=torch.int32, device="cuda")
+        out = torch.zeros((n_cols, 8), dtype=torch.int32, device="cuda")
+        for k in range(len(cuts) - 1):
+            lo, hi = cuts[k], cuts[k + 1]
+            first, last = k == 0, k == len(cuts) - 2
+            # two column ranges per slab, as the pipelined exchange of ShardedRows.commit issues them
+            for c0, c1 in ((0, 40), (40, n_cols)):
+                ctx.column_hash_part(curve, dev.data_ptr() + lo * n_cols * 32, hi - lo, n_cols, rows, state.data_ptr(), first, last,
+                                     out.data_ptr(), hash_name, c0, c1 - c0)
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy().view(np.uint8).reshape(n_cols, 32) == want).all(), cuts
+    state = torch.zeros((n_cols, 12), dtype=torch.int32, device="cuda")
+    with pytest.raises(pc.PcHipError):
+        ctx.column_hash_part(curve, dev.data_ptr(), 3, n_cols, rows, state.data_ptr(), True, False, 0, hash_name)
