@@ -379,6 +379,15 @@ int pc_hip_group_commit_open_async(pc_group* g, const pc_group_srs* srs, const v
                                    const void* z_host, void* out_commit_xy, void* out_proof_xy, void* out_value_host,
                                    pc_group_job** out_job);
 int pc_hip_group_job_wait(pc_group* g, pc_group_job* job);
+/* pc_hip_ligero_commit with the rows of the coefficient matrix split over the devices of the group (even slabs of consecutive
+ * rows): every device encodes its rows, the column digests are chained through the devices (pc_hip_column_hash_part: 48 bytes
+ * per column travel, the matrix does not), the last device with rows builds the tree.  mat_host: rows x in_cols Fr (Montgomery).
+ * nodes_out_host / leaves_out_host as in pc_hip_ligero_commit.  out_ext_slabs: NULL, or one pointer per device that receives
+ * the device's resident slab of the encoded matrix (rows [d * per, (d + 1) * per), per = ceil(rows / N) rounded up to even; NULL
+ * for a device without rows) -- what LinCodePCCommitmentState keeps for `open`; the caller frees them with pc_hip_free. */
+int pc_hip_group_ligero_commit(pc_group* g, pc_curve field_of, const void* mat_host, size_t rows, size_t in_cols, unsigned log_n,
+                               pc_hash col_hash, pc_hash tree_hash, int len_prefix, void** out_ext_slabs, void* leaves_out_host,
+                               void* nodes_out_host);
 /* pc_hip_ntt_batch with the rows split over the devices (rows are independent: linear_codes/mod.rs:131-135). */
 int pc_hip_group_ntt_batch(pc_group* g, pc_curve field_of, const void* in_host, size_t rows, size_t in_cols,
                            unsigned log_n, void* out_host);

@@ -118,6 +118,7 @@ def load_library():
     lib.pc_hip_group_msm_batch.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(sz), sz, ip, vp, C.POINTER(ip)]
     lib.pc_hip_group_kzg_open.argtypes = [vp, vp, vp, sz, vp, vp, C.POINTER(ip), vp]
     lib.pc_hip_group_ntt_batch.argtypes = [vp, ip, vp, sz, sz, C.c_uint, vp]
+    lib.pc_hip_group_ligero_commit.argtypes = [vp, ip, vp, sz, sz, C.c_uint, ip, ip, ip, vp, vp, vp]
     lib.pc_hip_group_commit_open_async.argtypes = [vp, vp, vp, ip, sz, vp, vp, vp, vp, C.POINTER(vp)]
     lib.pc_hip_group_job_wait.argtypes = [vp, vp]
     _lib = lib
@@ -582,6 +583,17 @@ class Group:
         out = np.zeros((mat.shape[0], 1 << log_n, 4), dtype=np.uint64)
         self.check(self.lib.pc_hip_group_ntt_batch(self.h, CURVES[curve], mat.ctypes.data, mat.shape[0], mat.shape[1], log_n, out.ctypes.data))
         return out
+
+    def ligero_commit(self, curve, mat, log_n, col_hash="blake2s", tree_hash="sha256", len_prefix=True):
+        """LinearCodePCS::commit steps 1-3 with the rows split over the group's devices (pc_hip_group_ligero_commit): chained
+        column digests, tree on the last device.  Returns (nodes (2^h - 1, 32) uint8 with the root at row 0, leaves (2^log_n, 32))."""
+        mat = np.ascontiguousarray(mat, dtype=np.uint64)
+        hid = {"sha256": 0, "blake2s": 1}
+        nodes = np.zeros(((1 << max(1, log_n)) - 1, 32), dtype=np.uint8)
+        leaves = np.zeros((1 << log_n, 32), dtype=np.uint8)
+        self.check(self.lib.pc_hip_group_ligero_commit(self.h, CURVES[curve], mat.ctypes.data, mat.shape[0], mat.shape[1], log_n, hid[col_hash],
+                                                       hid[tree_hash], 1 if len_prefix else 0, None, leaves.ctypes.data, nodes.ctypes.data))
+        return nodes, leaves
 
 
 class GroupJob:

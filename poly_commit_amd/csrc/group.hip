@@ -497,6 +497,72 @@ int pc_hip_group_job_wait(pc_group* g, pc_group_job* j) {
 
 extern "C" {
 
+// LinearCodePCS::commit steps 1-3 (linear_codes/mod.rs:248-277) with the rows of the coefficient matrix split over the devices:
+// every device encodes its slab (the rows are independent), the column digests are chained through the devices -- device d
+// absorbs its slab into the per-column states device d - 1 left (pc_hip_column_hash_part; 48 bytes per column and hop through a
+// host buffer, in column ranges so that the devices overlap) -- and the last device with rows builds the tree.  The encoded
+// slabs stay resident when out_ext_slabs is given (one device pointer per device; freed by the caller with pc_hip_free).
+int pc_hip_group_ligero_commit(pc_group* g, pc_curve field_of, const void* mat_host, size_t rows, size_t in_cols, unsigned log_n,
+                               pc_hash col_hash, pc_hash tree_hash, int len_prefix, void** out_ext_slabs, void* leaves_out_host,
+                               void* nodes_out_host) {
+  if (!g || !rows || !in_cols || !mat_host || !nodes_out_host || log_n > 32 || in_cols > ((size_t)1 << log_n)) return PC_ERR_INVALID_ARG;
+  const size_t N = g->ctx.size(), NC = (size_t)1 << log_n;
+  size_t per = (rows + N - 1) / N; per += per & 1;                     // even slabs: two rows fill one block of the digests
+  std::vector<size_t> lo(N), hi(N);
+  size_t last_dev = 0;
+  for (size_t d = 0; d < N; d++) { lo[d] = std::min(rows, d * per); hi[d] = std::min(rows, (d + 1) * per); if (hi[d] > lo[d]) last_dev = d; }
+  std::vector<void*> ext(N, nullptr), state(N, nullptr);
+  void* leaves = nullptr; void* nodes = nullptr;
+  // 1. encode: all devices at once
+  int rc = fan_out(g, [&](size_t d) {
+    if (hi[d] == lo[d]) return (int)PC_OK;
+    int r = pc_hip_malloc(g->ctx[d], (hi[d] - lo[d]) * NC * 32, &ext[d]);
+    if (r == PC_OK) r = pc_hip_malloc(g->ctx[d], NC * 48, &state[d]);
+    if (r == PC_OK) r = pc_hip_ntt_batch(g->ctx[d], field_of, (const char*)mat_host + lo[d] * in_cols * 32, PC_MEM_HOST, hi[d] - lo[d], in_cols, log_n,
+                                         ext[d], PC_MEM_DEVICE);
+    return r;
+  });
+  // 2. digests: range b of device d waits for range b of device d - 1 (a counter per device, advanced under one mutex)
+  if (rc == PC_OK) rc = pc_hip_malloc(g->ctx[last_dev], NC * 32, &leaves);
+  const size_t NB = std::min<size_t>(8, NC);
+  std::vector<uint8_t> wire(NC * 48);                                  // the states between two devices (host)
+  std::vector<size_t> done(N, 0);
+  std::mutex mu; std::condition_variable cv; int chain_rc = PC_OK;
+  if (rc == PC_OK) rc = fan_out(g, [&](size_t d) {
+    if (hi[d] == lo[d]) return (int)PC_OK;
+    const bool first = d == 0, last = d == last_dev;
+    for (size_t b = 0; b < NB; b++) {
+      const size_t c0 = NC * b / NB, c1 = NC * (b + 1) / NB;
+      int r = PC_OK;
+      if (!first) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return done[d - 1] > b || chain_rc != PC_OK; });
+        if (chain_rc != PC_OK) return chain_rc;
+        lk.unlock();
+        r = pc_hip_memcpy_h2d(g->ctx[d], (char*)state[d] + c0 * 48, wire.data() + c0 * 48, (c1 - c0) * 48);
+      }
+      if (r == PC_OK) r = pc_hip_column_hash_part(g->ctx[d], field_of, col_hash, ext[d], hi[d] - lo[d], NC, rows, c0, c1 - c0, first, last, state[d], leaves);
+      if (r == PC_OK && !last) r = pc_hip_memcpy_d2h(g->ctx[d], wire.data() + c0 * 48, (char*)state[d] + c0 * 48, (c1 - c0) * 48);
+      { std::lock_guard<std::mutex> lk(mu); if (r != PC_OK) chain_rc = r; else done[d] = b + 1; }
+      cv.notify_all();
+      if (r != PC_OK) return r;
+    }
+    return (int)PC_OK;
+  });
+  // 3. tree on the last device
+  unsigned h = 1; while (((size_t)1 << h) < NC) h++;
+  if (rc == PC_OK) rc = pc_hip_malloc(g->ctx[last_dev], ((size_t)1 << h) * 32, &nodes);
+  if (rc == PC_OK) rc = pc_hip_merkle_tree(g->ctx[last_dev], tree_hash, leaves, PC_MEM_DEVICE, NC, len_prefix, nodes, PC_MEM_DEVICE);
+  if (rc == PC_OK) rc = pc_hip_memcpy_d2h(g->ctx[last_dev], nodes_out_host, nodes, (((size_t)1 << h) - 1) * 32);
+  if (rc == PC_OK && leaves_out_host) rc = pc_hip_memcpy_d2h(g->ctx[last_dev], leaves_out_host, leaves, NC * 32);
+  pc_hip_free(g->ctx[last_dev], leaves); pc_hip_free(g->ctx[last_dev], nodes);
+  for (size_t d = 0; d < N; d++) {
+    pc_hip_free(g->ctx[d], state[d]);
+    if (rc == PC_OK && out_ext_slabs) out_ext_slabs[d] = ext[d]; else pc_hip_free(g->ctx[d], ext[d]);
+  }
+  return rc;
+}
+
 // LinearEncode::compute_matrices' rows (linear_codes/mod.rs:131-135) are independent: rows split over the devices,
 // no exchange at all.
 int pc_hip_group_ntt_batch(pc_group* g, pc_curve field_of, const void* in_host, size_t rows, size_t in_cols, unsigned log_n, void* out_host) {

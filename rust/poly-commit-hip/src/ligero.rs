@@ -78,6 +78,31 @@ pub fn commit_root<F: HipField>(mat: &[F], rows: usize, in_cols: usize, rho_inv:
     Ok((nodes[0], leaves))
 }
 
+/// `commit_root` with the rows of the coefficient matrix spread over several devices (`pc_hip_group_ligero_commit`): every device
+/// encodes its rows, the column digests are chained through the devices (48 bytes per column travel from device to device instead
+/// of a transpose of the encoded matrix), the last device builds the tree.  Same `(root, leaves)`, bit for bit.
+pub fn commit_root_group<F: HipField>(devices: &[i32], mat: &[F], rows: usize, in_cols: usize, rho_inv: usize, col_hash: c_int, tree_hash: c_int)
+    -> Result<([u8; 32], Vec<[u8; 32]>), Error> {
+    assert_eq!(mat.len(), rows * in_cols);
+    let log_n = next_log2(in_cols * rho_inv);
+    let n = 1usize << log_n;
+    let mut leaves = vec![[0u8; 32]; n];
+    let mut nodes = vec![[0u8; 32]; (1usize << log_n.max(1)) - 1];
+    let packed;
+    let src = if F::layout_is_abi() { mat.as_ptr() as *const c_void } else { packed = pack_scalars(mat); packed.as_ptr() as *const c_void };
+    let mut g = core::ptr::null_mut();
+    let fail = |rc: c_int| Error::InvalidParameters(format!("pc_hip_group: {}", crate::device::strerror(rc)));
+    let rc = unsafe { ffi::pc_hip_group_create(devices.as_ptr(), devices.len() as c_int, &mut g) };
+    if rc != ffi::PC_OK { return Err(fail(rc)); }
+    let rc = unsafe {
+        ffi::pc_hip_group_ligero_commit(g, F::FIELD_OF, src, rows, in_cols, log_n as c_uint, col_hash, tree_hash, 1, core::ptr::null_mut(),
+                                        leaves.as_mut_ptr() as *mut c_void, nodes.as_mut_ptr() as *mut c_void)
+    };
+    unsafe { ffi::pc_hip_group_destroy(g) };
+    if rc != ffi::PC_OK { return Err(fail(rc)); }
+    Ok((nodes[0], leaves))
+}
+
 impl<F, C, P, H> LinearEncode<F, C, P, H> for HipUnivariateLigero<F, C, P, H>
 where
     F: HipField,

@@ -90,3 +90,22 @@ def test_group_commit_open_async_jobs(curve, n, ndev, table):
     assert (comm == O.kzg_commit(curve, powers, p)[1]).all() and (proof == O.kzg_open(curve, powers, p, z)[1]).all()
     srs.free()
     g.close()
+
+
+@pytest.mark.parametrize("ndev,rows", [(1, 7), (2, 8), (3, 7), (4, 16), (4, 3)])
+def test_group_ligero_commit_chained_digests(ndev, rows):
+    """pc_hip_group_ligero_commit: rows encoded on different device contexts, column digests chained through them
+    (pc_hip_column_hash_part), tree on the last -- node array and leaves identical to the single-context pc_hip_ligero_commit."""
+    import poly_commit_amd as pc
+    curve, in_cols, log_n = "bls12_381", 40, 8
+    mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x11CE + rows, rows * in_cols)).reshape(rows, in_cols, 4)
+    ctx = pc.Context(0)
+    want_nodes, want_leaves = ctx.ligero_commit(curve, mat, log_n)
+    g = pc.Group([0] * ndev)
+    for col_hash, tree_hash in (("blake2s", "sha256"), ("sha256", "blake2s")):
+        if col_hash != "blake2s":
+            want_nodes, want_leaves = ctx.ligero_commit(curve, mat, log_n, col_hash=col_hash, tree_hash=tree_hash)
+        nodes, leaves = g.ligero_commit(curve, mat, log_n, col_hash, tree_hash)
+        assert (leaves == want_leaves).all() and (nodes == want_nodes).all(), (ndev, rows, col_hash)
+    g.close()
+    ctx.close()
