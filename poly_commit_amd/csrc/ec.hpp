@@ -88,7 +88,7 @@ struct XyzzD {
   // product ZZ * PP = 0 (mod p) needs P = 0 (mod p), which takes the branch below.  `canonical()` where the sum leaves the
   // chain (bucket store, partial list).
   PC_HD void add_affine_lz(const AffD<C>& a, bool negate) {
-    if (a.is_inf()) return;
+    if (a.y.is_zero()) { if (a.x.is_zero()) return; }        // infinity = (0, 0); y alone decides for every point of the curve (no 2-torsion)
     const Fq ay = negate ? a.y.neg_lz_canonical() : a.y;
     if (is_inf()) { X = a.x; Y = ay; ZZ = Fq::one(); ZZZ = Fq::one(); return; }
     Fq U2 = a.x.mul_lz(ZZ), S2 = ay.mul_lz(ZZZ);

@@ -224,7 +224,10 @@ struct AccumulateBody {
   // again wherever it leaves the lane
   static constexpr bool LAZY = Pt::Fq::LAZY_OK;
   PC_HD void flush(const Pt& acc_lz, uint32_t k, bool complete, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
-    const Pt acc = LAZY ? acc_lz.canonical() : acc_lz;
+    // (the sum leaves the lane lazily reduced, coordinates in [0, 2p): every consumer -- the joins of k_accumulate, the segmented and
+    // the bucket reduction, the host tail -- feeds loaded coordinates into multiplications first (XyzzD::add / dbl), which accept
+    // them; infinity is the exact ZZ == 0 either way.  Saves four conditional subtractions per flush: 1.3 % of the kernel)
+    const Pt& acc = acc_lz;
     if (complete) { acc.store(buckets + (size_t)k * Pt::WORDS); return; }
     uint32_t slot = first ? 2 * t : 2 * t + 1;
     acc.store(ppts + (size_t)slot * Pt::WORDS);
@@ -275,7 +278,7 @@ struct AccumulateBody {
         val = nval; nval = nnval; pt = npt;
       }
       flush(acc, k, run_lo >= s && boundary <= e, t, first, k0, k1);
-      last = LAZY ? acc.canonical() : acc;
+      last = acc;
     }
   }
   PC_HD void operator()(uint32_t t) const {
