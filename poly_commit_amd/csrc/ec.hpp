@@ -133,6 +133,46 @@ struct XyzzD {
 };
 
 
+// ---- one XYZZ addition spread over TWO lanes (msm_coop.hpp, k_bucket_level_coop2) ------------------------------------------
+// The even lane holds (X, ZZ) of a point, the odd lane (Y, ZZZ).  XyzzD::add is laid out so that both lanes run the same
+// instruction stream on their halves, in four phases with a neighbour exchange after the first three:
+//   p1  A1*B2, A2*B1, D = difference          U1, U2, P                 | S1, S2, R            -> exchange "D == 0"
+//   p2  D^2, B1*B2, D*DD                      PP, ZZ1*ZZ2, PPP          | RR, ZZZ1*ZZZ2, -     -> even sends PPP, odd sends RR
+//   p3  one product, X3                       Q = U1*PP, X3             | ZZZ3 = ZZZ12*PPP     -> even sends Q - X3
+//   p4  one fused pair                        ZZ3 = ZZ12*PP (+ 0*0)     | Y3 = R*(Q - X3) - S1*PPP
+// 7.3 multiplication times instead of 13; the values are those of XyzzD::add, bit for bit.  The phases are plain PC_HD code
+// (the device exchanges by DPP, tests/emu steps the two lanes on the host).
+template <class C>
+struct HalfPt {
+  typedef Fd<typename C::FqP> Fq;
+  Fq a, b;        // even lane: X, ZZ   odd lane: Y, ZZZ
+  static PC_HD HalfPt of(const XyzzD<C>& p, bool odd) { HalfPt h; h.a = odd ? p.Y : p.X; h.b = odd ? p.ZZZ : p.ZZ; return h; }
+};
+template <class Fq>
+PC_HD Fq fq_sel(bool c, const Fq& x, const Fq& y) {
+  Fq r;
+  PC_UNROLL for (int i = 0; i < Fq::N; i++) r.l[i] = c ? x.l[i] : y.l[i];
+  return r;
+}
+template <class C>
+struct HalfAdd {
+  typedef Fd<typename C::FqP> Fq;
+  Fq T1, D, DD, BB, T5, rc1, R6, X3;
+  PC_HD bool p1(const HalfPt<C>& p, const HalfPt<C>& o) { T1 = p.a.mul(o.b); const Fq T2 = o.a.mul(p.b); D = T2.sub(T1); return D.is_zero(); }
+  PC_HD Fq p2(const HalfPt<C>& p, const HalfPt<C>& o, bool odd) { DD = D.sqr(); BB = p.b.mul(o.b); T5 = D.mul(DD); return fq_sel(odd, DD, T5); }
+  PC_HD Fq p3(bool odd, const Fq& recv) {
+    rc1 = recv;                                                       // even: RR, odd: PPP
+    R6 = fq_sel(odd, BB, T1).mul(fq_sel(odd, rc1, DD));               // even: Q, odd: ZZZ3
+    X3 = rc1.sub(T5).sub(R6.dbl());                                   // even: RR - PPP - 2Q
+    return R6.sub(X3);                                                // even: Q - X3
+  }
+  PC_HD void p4(HalfPt<C>& p, bool odd, const Fq& rc2) {
+    const Fq R7 = fq_sel(odd, D, BB).mul_add_mul(fq_sel(odd, rc2, DD), fq_sel(odd, T1.neg(), Fq::zero()), fq_sel(odd, rc1, Fq::zero()));
+    p.a = fq_sel(odd, R7, X3);                                        // even: X3, odd: Y3
+    p.b = fq_sel(odd, R6, R7);                                        // even: ZZ3, odd: ZZZ3
+  }
+};
+
 // Jacobian coordinates (x = X/Z^2, y = Y/Z^3), a = 0: cheaper doubling (2M + 5S, dbl-2009-l) than
 // XYZZ (6M + 3S).  Used by the per-element scalar multiplications (IPA key fold, fixed-base SRS
 // generation), where doublings outnumber additions 3:1 after NAF recoding.

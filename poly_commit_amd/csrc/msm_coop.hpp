@@ -81,12 +81,6 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop(uint32_t K, uint32_t 
 // intermediate values as XyzzD::add: the results are bit-identical.  Equal x (doubling / P + (-P)) gathers the whole point into
 // both lanes and runs XyzzD::dbl (rare).  Used for the levels that are latency-bound (few points); wide levels keep one lane
 // per point (twice the lanes would only add work there).
-template <class C>
-struct HalfPt {
-  typedef Fd<typename C::FqP> Fq;
-  Fq a, b;        // even lane: X, ZZ   odd lane: Y, ZZZ
-};
-
 template <class Fq>
 __device__ __forceinline__ Fq lane_xchg(const Fq& v) {       // the value of the neighbour lane (lane ^ 1)
   Fq r;
@@ -94,41 +88,26 @@ __device__ __forceinline__ Fq lane_xchg(const Fq& v) {       // the value of the
   for (int i = 0; i < Fq::N; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xB1, 0xF, 0xF, true);
   return r;
 }
-template <class Fq>
-__device__ __forceinline__ Fq lane_sel(bool c, const Fq& x, const Fq& y) {
-  Fq r;
-#pragma unroll
-  for (int i = 0; i < Fq::N; i++) r.l[i] = c ? x.l[i] : y.l[i];
-  return r;
-}
 
+// p += o on a lane pair (ec.hpp: HalfPt, HalfAdd -- the phases between the exchanges)
 template <class C>
 __device__ __forceinline__ void half_add(HalfPt<C>& p, const HalfPt<C>& o, bool odd) {
   typedef Fd<typename C::FqP> Fq;
   if (o.b.is_zero()) return;                      // infinity has ZZ = ZZZ = 0: both lanes of a pair agree
   if (p.b.is_zero()) { p = o; return; }
-  const Fq T1 = p.a.mul(o.b), T2 = o.a.mul(p.b);
-  const Fq D = T2.sub(T1);
-  const int dz = D.is_zero() ? 1 : 0, dz_nb = __builtin_amdgcn_mov_dpp(dz, 0xB1, 0xF, 0xF, true);
+  HalfAdd<C> h;
+  const int dz = h.p1(p, o) ? 1 : 0, dz_nb = __builtin_amdgcn_mov_dpp(dz, 0xB1, 0xF, 0xF, true);
   const bool pz = odd ? dz_nb != 0 : dz != 0, rz = odd ? dz != 0 : dz_nb != 0;
-  if (pz) {                                       // same x
+  if (pz) {                                       // same x: doubling or P + (-P) -- the whole point into both lanes, XyzzD::dbl
     const Fq na = lane_xchg(p.a), nb = lane_xchg(p.b);
     XyzzD<C> f;
-    f.X = lane_sel(odd, na, p.a); f.Y = lane_sel(odd, p.a, na); f.ZZ = lane_sel(odd, nb, p.b); f.ZZZ = lane_sel(odd, p.b, nb);
-    const XyzzD<C> r = rz ? f.dbl() : XyzzD<C>::infinity();
-    p.a = lane_sel(odd, r.Y, r.X); p.b = lane_sel(odd, r.ZZZ, r.ZZ);
+    f.X = fq_sel(odd, na, p.a); f.Y = fq_sel(odd, p.a, na); f.ZZ = fq_sel(odd, nb, p.b); f.ZZZ = fq_sel(odd, p.b, nb);
+    p = HalfPt<C>::of(rz ? f.dbl() : XyzzD<C>::infinity(), odd);
     return;
   }
-  const Fq DD = D.sqr();
-  const Fq BB = p.b.mul(o.b);
-  const Fq T5 = D.mul(DD);                                                    // even: PPP
-  const Fq rc1 = lane_xchg(lane_sel(odd, DD, T5));                            // even <- RR, odd <- PPP
-  const Fq R6 = lane_sel(odd, BB, T1).mul(lane_sel(odd, rc1, DD));            // even: Q, odd: ZZZ3
-  const Fq X3 = rc1.sub(T5).sub(R6.dbl());                                    // even: RR - PPP - 2Q
-  const Fq rc2 = lane_xchg(R6.sub(X3));                                       // odd <- Q - X3
-  const Fq R7 = lane_sel(odd, D, BB).mul_add_mul(lane_sel(odd, rc2, DD), lane_sel(odd, T1.neg(), Fq::zero()), lane_sel(odd, rc1, Fq::zero()));
-  p.a = lane_sel(odd, R7, X3);                                                // even: X3, odd: Y3
-  p.b = lane_sel(odd, R6, R7);                                                // even: ZZ3, odd: ZZZ3
+  const Fq rc1 = lane_xchg(h.p2(p, o, odd));
+  const Fq rc2 = lane_xchg(h.p3(odd, rc1));
+  h.p4(p, odd, rc2);
 }
 
 // grid = cnt * (1 + n_old) workgroups of 2 K <= 256 lanes; contract of k_bucket_level_coop

@@ -211,6 +211,44 @@ template <class C> static void ecop(int op, const uint32_t* a, const uint32_t* b
   }
   r.to_affine().store(out);
 }
+// The two-lane addition of k_bucket_level_coop2 (ec.hpp: HalfPt / HalfAdd), both lanes of the pair stepped on the host: the phases are
+// the device's own code, the exchanges between them (DPP on the device) are plain assignments here.  mode bit 0 / 1: give the first /
+// second operand a non-trivial ZZ (2P - P instead of P).
+template <class C> static void half_add_pair(int mode, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  typedef pc::XyzzD<C> Pt; typedef pc::AffD<C> A; typedef pc::HalfPt<C> H; typedef pc::Fd<typename C::FqP> Fq;
+  auto lift = [](const A& q, bool twist) { Pt r = Pt::from_affine(q); if (twist && !q.is_inf()) { r = r.dbl(); r.add_affine(q.neg_if(true)); } return r; };
+  const Pt P = lift(A::load(a), mode & 1), Q = lift(A::load(b), mode & 2);
+  H p[2] = {H::of(P, false), H::of(P, true)}, o[2] = {H::of(Q, false), H::of(Q, true)};
+  if (o[0].b.is_zero()) { /* + infinity */ }
+  else if (p[0].b.is_zero()) { p[0] = o[0]; p[1] = o[1]; }
+  else {
+    pc::HalfAdd<C> h[2];
+    const bool dz[2] = {h[0].p1(p[0], o[0]), h[1].p1(p[1], o[1])};
+    const bool pz = dz[0], rz = dz[1];                                   // even lane: P == 0, odd lane: R == 0
+    if (pz) {
+      Pt f; f.X = p[0].a; f.ZZ = p[0].b; f.Y = p[1].a; f.ZZZ = p[1].b;
+      const Pt r = rz ? f.dbl() : Pt::infinity();
+      p[0] = H::of(r, false); p[1] = H::of(r, true);
+    } else {
+      const Fq s0 = h[0].p2(p[0], o[0], false), s1 = h[1].p2(p[1], o[1], true);
+      const Fq t0 = h[0].p3(false, s1), t1 = h[1].p3(true, s0);
+      h[0].p4(p[0], false, t1); h[1].p4(p[1], true, t0);
+    }
+  }
+  Pt r; r.X = p[0].a; r.ZZ = p[0].b; r.Y = p[1].a; r.ZZZ = p[1].b;
+  // bit-identical to the one-lane addition, coordinate by coordinate
+  Pt w = P; w.add(Q);
+  uint32_t x[Pt::WORDS], y[Pt::WORDS]; r.store(x); w.store(y);
+  out[2 * Fq::N] = memcmp(x, y, sizeof x) == 0 ? 1u : 0u;
+  r.to_affine().store(out);
+}
+extern "C" void emu_half_add(int curve, int mode, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  switch (curve) {
+    case 0: half_add_pair<pc_curve_bls12_381>(mode, a, b, out); break;
+    case 1: half_add_pair<pc_curve_bn254>(mode, a, b, out); break;
+    case 2: half_add_pair<pc_curve_pallas>(mode, a, b, out); break;
+  }
+}
 extern "C" void emu_ecop(int curve, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   switch (curve) {
     case 0: ecop<pc_curve_bls12_381>(op, a, b, out); break;

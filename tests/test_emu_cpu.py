@@ -124,6 +124,26 @@ def test_xyzz_group_law_all_special_cases(curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_two_lane_addition_stepped(curve):
+    """The XYZZ addition spread over a lane pair (k_bucket_level_coop2; ec.hpp HalfAdd): both lanes stepped on the host through the
+    device's own phases -- every pair of {5 points, infinity}, with trivial and non-trivial ZZ on either side (so P + P, P + (-P)
+    and both infinities are in it): equal to the group law AND coordinate-for-coordinate to the one-lane XyzzD::add."""
+    pts = R.gen_bases(curve, 5)
+    pts.append(R.ec_neg(curve, pts[1]))
+    arr = O.points_to_array(curve, pts + [None])
+    nq = arr.shape[1]
+    for i in range(7):
+        for j in range(7):
+            Pi = pts[i] if i < 6 else None
+            Pj = pts[j] if j < 6 else None
+            for mode in range(4):
+                out = np.zeros(nq + 1, dtype=np.uint64)
+                emu().emu_half_add(O.CURVES[curve], mode, p32(arr[i].view(np.uint32)), p32(arr[j].view(np.uint32)), p32(out.view(np.uint32)))
+                assert O.array_to_points(curve, out[:nq].reshape(1, -1))[0] == R.ec_add(curve, Pi, Pj), (mode, i, j)
+                assert out.view(np.uint32)[2 * nq] == 1, ("coordinates differ from XyzzD::add", mode, i, j)
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_msm_pipeline_stepped(curve):
     for n in (1, 2, 33, 300):
         b = O.gen_bases(curve, n)
