@@ -358,6 +358,9 @@ class ShardedRows:
             first, last = k == 0, k == len(active) - 1
             state = e.state_buffer(n_ext_cols)
             digests = e.digest_buffer(n_ext_cols) if last else None
+            on_device = hasattr(state, "is_cuda") and state.is_cuda
+            if on_device:            # torch filled the buffers on ITS stream; the library's kernels run on the context's
+                torch.cuda.synchronize()
             nb = max(1, min(blocks, n_ext_cols))
             for b in range(nb):
                 c0, c1 = n_ext_cols * b // nb, n_ext_cols * (b + 1) // nb
@@ -367,6 +370,8 @@ class ShardedRows:
                     buf = torch.empty((c1 - c0, 12), dtype=torch.int32, device=wire)
                     dist.recv(buf, src=active[k - 1])
                     state[c0:c1].copy_(buf)
+                    if on_device:    # (RCCL's receive and the copy are stream-ordered on torch's side only)
+                        torch.cuda.synchronize()
                 e.column_hash_part(ext_slab, hi - lo, n_ext_cols, n_rows, state, first, last, digests, col_hash, c0, c1 - c0)
                 if not last:
                     dist.send(state[c0:c1].to(wire).contiguous(), dst=active[k + 1])
