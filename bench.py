@@ -531,7 +531,24 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
         for _ in range(reps):                 # the commit alone
             eng.srs.msm(hostc, n=n, base_offset=1, montgomery=True)
         dt_c = (time.perf_counter() - t0) / reps
+        # ... and with the device copy of the polynomial that the shim keeps between commit and open
+        # (rust/poly-commit-hip/src/device.rs, device_poly): commit = upload + MSM on the copy, open = witness + MSM on it
+        pbuf = ctx.malloc(n * 32)
+
+        def cached_step():
+            ctx.memcpy_h2d(pbuf, hostc[:n])
+            c, _ = eng.srs.msm(pbuf, n=n, base_offset=1, montgomery=True)
+            ctx.witness_poly(curve, pbuf, zm, out=qdev.data_ptr(), n=n)
+            w, _ = eng.srs.msm(qdev, n=n - 1, base_offset=1, montgomery=True)
+            return c, w
+        c2, w2 = cached_step()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cached_step()
+        dt_s = (time.perf_counter() - t0) / reps
+        ctx.free_dev(pbuf)
         trait = {"ms_per_commit_open": dt_t * 1e3, "commit_ms": dt_c * 1e3, "open_ms": (dt_t - dt_c) * 1e3,
+                 "with_shim_polynomial_cache_ms": dt_s * 1e3, "with_shim_polynomial_cache_parity_ok": bool((c2 == want_c).all() and (w2 == want_w).all()),
                  "commit_open_per_s": 1.0 / dt_t, "value": (2 * n - 1) / dt_t, "unit": "pairs/s",
                  "parity_ok": bool((c == want_c).all() and (w == want_w).all()),
                  "note": "blocking pc_hip_msm with PC_MEM_HOST coefficients (pageable numpy memory, one H2D inside the call), "

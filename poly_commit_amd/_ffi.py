@@ -291,6 +291,19 @@ class Context:
         self.check(self.lib.pc_hip_last_ntt_phases_ms(self.h, out))
         return list(out)
 
+    # raw device buffers of the library (pc_hip_malloc / pc_hip_free / pc_hip_memcpy_*): what a shim caches a polynomial in
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.pc_hip_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free_dev(self, ptr):
+        self.check(self.lib.pc_hip_free(self.h, C.c_void_p(ptr)))
+
+    def memcpy_h2d(self, dst_dev, src_host):
+        src = np.ascontiguousarray(src_host)
+        self.check(self.lib.pc_hip_memcpy_h2d(self.h, C.c_void_p(dst_dev), C.c_void_p(src.ctypes.data), src.nbytes))
+
     def witness_poly(self, curve, coeffs, z, out=None, n=None):
         """q = p / (x - z); coeffs n x 4 uint64 (Montgomery), z 4 x uint64 host array."""
         pin, win = _ptr(coeffs)
