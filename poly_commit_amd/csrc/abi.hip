@@ -652,9 +652,11 @@ int pc_hip_last_msm_shape(const pc_ctx* ctx, uint32_t out[4]) {
 // Stage a host buffer on the device (or pass a device pointer through).
 struct Staged {
   pc::HipBackend& be; void* dev = nullptr; bool owned = false;
-  Staged(pc::HipBackend& b, const void* p, pc_mem where, size_t bytes, bool copy_in) : be(b) {
+  // slot 0 / 1: the context's grow-only staging buffers (input / output of the call); -1 or a large request: transient
+  Staged(pc::HipBackend& b, const void* p, pc_mem where, size_t bytes, bool copy_in, int slot = -1) : be(b) {
     if (where == PC_MEM_DEVICE) { dev = const_cast<void*>(p); return; }
-    dev = be.alloc(bytes); owned = true;
+    if (slot >= 0 && bytes <= pc::HipBackend::STAGE_KEEP) dev = be.stage(slot, bytes);
+    else { dev = be.alloc(bytes); owned = true; }
     if (copy_in && bytes) be.copy_h2d(dev, p, bytes);
   }
   ~Staged() { if (owned) be.free(dev); }
@@ -677,8 +679,8 @@ int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem wher
       it = ctx->ntt_plans.emplace(key, std::move(r)).first;
     }
     const size_t N = (size_t)1 << log_n;
-    Staged sin(ctx->be, in, where_in, rows * in_cols * 32, true);
-    Staged sout(ctx->be, out, where_out, rows * N * 32, false);
+    Staged sin(ctx->be, in, where_in, rows * in_cols * 32, true, 0);
+    Staged sout(ctx->be, out, where_out, rows * N * 32, false, 1);
     ctx->be.n_ev = 0;
     it->second->run((const uint32_t*)sin.dev, rows, in_cols, (uint32_t*)sout.dev);
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, rows * N * 32); else ctx->be.sync();
@@ -703,7 +705,7 @@ int pc_hip_poly_eval(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem 
   if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    Staged sin(ctx->be, coeffs, where_in, n * 32, true);
+    Staged sin(ctx->be, coeffs, where_in, n * 32, true, 0);
     const uint32_t* z = (const uint32_t*)z_host;
     pc::field_ops(field_of).poly_eval(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)out_host, scan_fan());
     return (int)PC_OK;
@@ -717,8 +719,8 @@ int pc_hip_poly_div_scan(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (n == 0) return (int)PC_OK;
-    Staged sin(ctx->be, coeffs, where_in, n * 32, true);
-    Staged sout(ctx->be, out, where_out, n * 32, false);
+    Staged sin(ctx->be, coeffs, where_in, n * 32, true, 0);
+    Staged sout(ctx->be, out, where_out, n * 32, false, 1);
     const uint32_t* z = (const uint32_t*)z_host; const uint32_t* cin = (const uint32_t*)carry_in_host;
     pc::field_ops(field_of).div_scan(ctx->be, (const uint32_t*)sin.dev, n, z, cin, (uint32_t*)sout.dev, scan_fan());
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n * 32);
@@ -740,8 +742,8 @@ int pc_hip_column_hash(pc_ctx* ctx, pc_curve field_of, const void* ext_mat, pc_m
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (!n_cols) return (int)PC_OK;
-    Staged sin(ctx->be, ext_mat, where_in, rows * n_cols * 32, true);
-    Staged sout(ctx->be, out_digests, where_out, n_cols * 32, false);
+    Staged sin(ctx->be, ext_mat, where_in, rows * n_cols * 32, true, 0);
+    Staged sout(ctx->be, out_digests, where_out, n_cols * 32, false, 1);
     const uint32_t* e = (const uint32_t*)sin.dev; uint32_t* o = (uint32_t*)sout.dev;
     ctx->be.n_ev = 0; ctx->be.mark();
     pc::field_ops(field_of).column_hash(ctx->be, (int)hash, e, (uint32_t)rows, (uint32_t)n_cols, o);
@@ -777,8 +779,8 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     if (n <= 1) return (int)PC_OK;
-    Staged sin(ctx->be, coeffs, where_in, n * 32, true);
-    Staged sout(ctx->be, out, where_out, (n - 1) * 32, false);
+    Staged sin(ctx->be, coeffs, where_in, n * 32, true, 0);
+    Staged sout(ctx->be, out, where_out, (n - 1) * 32, false, 1);
     const uint32_t* z = (const uint32_t*)z_host;
     pc::field_ops(field_of).witness(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan());
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, (n - 1) * 32);
@@ -895,8 +897,8 @@ int pc_hip_merkle_tree(pc_ctx* ctx, pc_hash hash, const void* leaf_digests, pc_m
   return guarded(ctx, [&]() {
     unsigned h = 1; while (((size_t)1 << h) < n_leaves) h++;      // padded leaf count 2^h >= 2
     const size_t n_nodes = ((size_t)1 << h) - 1;
-    Staged sin(ctx->be, leaf_digests, where_in, n_leaves * 32, true);
-    Staged sout(ctx->be, out_nodes, where_out, n_nodes * 32, false);
+    Staged sin(ctx->be, leaf_digests, where_in, n_leaves * 32, true, 0);
+    Staged sout(ctx->be, out_nodes, where_out, n_nodes * 32, false, 1);
     uint32_t* nodes = (uint32_t*)sout.dev;
     ctx->be.n_ev = 0; ctx->be.mark();
     for (int d = (int)h - 1; d >= 0; d--) {
@@ -922,8 +924,8 @@ int pc_hip_matrix_columns(pc_ctx* ctx, const void* mat_dev, size_t rows, size_t 
   if (!t) return PC_OK;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    Staged sidx(ctx->be, indices_host, PC_MEM_HOST, t * 4, true);
-    Staged sout(ctx->be, out, where_out, rows * t * 32, false);
+    Staged sidx(ctx->be, indices_host, PC_MEM_HOST, t * 4, true, 0);
+    Staged sout(ctx->be, out, where_out, rows * t * 32, false, 1);
     pc::gather_columns(ctx->be, (const uint32_t*)mat_dev, rows, n_cols, (const uint32_t*)sidx.dev, t, (uint32_t*)sout.dev);
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, rows * t * 32); else ctx->be.sync();
     return (int)PC_OK;
@@ -945,7 +947,7 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
   return guarded(ctx, [&]() {
     if (!n_out) return (int)PC_OK;
     // host polynomials are staged back to back in one device buffer
-    Staged stage(ctx->be, nullptr, PC_MEM_HOST, where_in == PC_MEM_HOST ? total * 32 : 0, false);
+    Staged stage(ctx->be, nullptr, PC_MEM_HOST, where_in == PC_MEM_HOST ? total * 32 : 0, false, 0);
     std::vector<uint64_t> addr(k ? k : 1, 0); std::vector<uint32_t> len32(k ? k : 1, 0);
     size_t off = 0;
     for (size_t j = 0; j < k; j++) {
@@ -955,12 +957,15 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
         addr[j] = (uint64_t)(uintptr_t)((char*)stage.dev + off * 32); off += lens[j];
       } else addr[j] = (uint64_t)(uintptr_t)polys[j];
     }
-    Staged daddr(ctx->be, addr.data(), PC_MEM_HOST, addr.size() * 8, true);
-    Staged dlen(ctx->be, len32.data(), PC_MEM_HOST, len32.size() * 4, true);
-    Staged dxi(ctx->be, xi_host, PC_MEM_HOST, (k ? k : 1) * 32, k != 0);
-    Staged sout(ctx->be, out, where_out, n_out * 32, false);
+    // the three small argument arrays side by side in the context's grow-only scratch (three hipMalloc / hipFree pairs per call before)
+    const size_t kk = k ? k : 1, o_len = kk * 8, o_xi = (o_len + kk * 4 + 31) & ~(size_t)31;
+    char* args = (char*)ctx->be.workspace(o_xi + kk * 32);
+    ctx->be.copy_h2d(args, addr.data(), kk * 8);
+    ctx->be.copy_h2d(args + o_len, len32.data(), kk * 4);
+    if (k) ctx->be.copy_h2d(args + o_xi, xi_host, k * 32);
+    Staged sout(ctx->be, out, where_out, n_out * 32, false, 1);
     ctx->be.n_ev = 0; ctx->be.mark();
-    pc::field_ops(field_of).fr_lincomb(ctx->be, daddr.dev, dlen.dev, dxi.dev, k, sout.dev, n_out);
+    pc::field_ops(field_of).fr_lincomb(ctx->be, args, args + o_len, args + o_xi, k, sout.dev, n_out);
     ctx->be.mark();
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, n_out * 32); else ctx->be.sync();
     ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;

@@ -143,6 +143,7 @@ struct HipBackend {
     if (scan_tmp) (void)hipFree(scan_tmp);
     if (sort_ws) (void)hipFree(sort_ws);
     if (work_ws) (void)hipFree(work_ws);
+    for (int i = 0; i < 2; i++) if (stage_ws[i]) (void)hipFree(stage_ws[i]);
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
     if (done) (void)hipEventDestroy(done);
     if (main_stream) stream = main_stream;
@@ -162,6 +163,17 @@ struct HipBackend {
       PC_HIP_CHECK(hipMalloc(&work_ws, bytes)); work_ws_bytes = bytes;
     }
     return work_ws;
+  }
+  // Grow-only device copies of the host arguments / results of one call (slot 0: input, 1: output): the entry points that take
+  // host memory (the trait-shaped open hands its polynomial over on the host) paid a hipMalloc + a device-synchronising hipFree
+  // per call.  Kept up to STAGE_KEEP bytes per slot; larger requests stay transient (caller allocates).
+  static constexpr size_t STAGE_KEEP = (size_t)1 << 30;
+  void* stage(int slot, size_t bytes) {
+    if (bytes > stage_bytes[slot]) {
+      if (stage_ws[slot]) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(stage_ws[slot]); stage_ws[slot] = nullptr; stage_bytes[slot] = 0; }
+      PC_HIP_CHECK(hipMalloc(&stage_ws[slot], bytes ? bytes : 4)); stage_bytes[slot] = bytes ? bytes : 4;
+    }
+    return stage_ws[slot];
   }
   void memset(void* p, int v, size_t bytes) { PC_HIP_CHECK(hipMemsetAsync(p, v, bytes, stream)); }
   void copy_d2d(void* d, const void* s, size_t bytes) { PC_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
@@ -207,6 +219,7 @@ struct HipBackend {
                     uint32_t* entries);
   void* sort_ws = nullptr; size_t sort_ws_bytes = 0;
   void* work_ws = nullptr; size_t work_ws_bytes = 0;
+  void* stage_ws[2] = {nullptr, nullptr}; size_t stage_bytes[2] = {0, 0};
   int sort_mode = -1;   // -1 = read PC_HIP_SORT on first use; 0 = atomic; 1 = LDS radix
   bool tail_split = false; hipStream_t main_stream = nullptr, tail_stream = nullptr; hipEvent_t tail_ev = nullptr;
 
