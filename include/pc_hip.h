@@ -118,7 +118,9 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs, const size_t* base_offsets,
  * (own HIP stream + workspace) and returns; pc_hip_job_wait blocks until the result has been
  * written to out_xy / out_is_infinity (which must stay valid until then) and frees the job.
  * Lets a prover keep several commitments in flight so that the latency-bound tail of one MSM
- * overlaps the bucket accumulation of the next (pc_hip_msm_batch does this internally). */
+ * overlaps the bucket accumulation of the next (pc_hip_msm_batch does this internally).
+ * Threads: every entry point takes the context's lock, but pc_hip_job_wait waits for the device OUTSIDE it, so other threads
+ * keep queueing work on the same context while one waits.  An SRS must not be freed while a job on it is being waited for. */
 int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars,
                      pc_scalar_form form, pc_mem where, size_t n, void* out_xy, int* out_is_infinity,
                      pc_job** out_job);
