@@ -334,29 +334,6 @@ struct SegReduceBody {
 // 6. bucket reduction level:  X (wb x m) -> S (wb x m/K), Tw (wb x m/K);  plain fan-in-K sums
 //    of the older Tw arrays ride along (which = 1 + j).
 // ---------------------------------------------------------------------------------------
-template <class C>
-struct BucketReduceBody {
-  static constexpr bool LATENCY_BOUND = true;   // raised wave priority beside an accumulation (hip_backend.hpp)
-  typedef XyzzD<C> Pt;
-  uint32_t m_in;             // elements per window at this level
-  uint32_t K;                // group size (power of two, <= m_in)
-  uint32_t weight_off;       // 1 at level 0 (weights j+1), 0 afterwards (weights j)
-  uint32_t n_groups_total;   // windows * m_in / K
-  const uint32_t* x;         // input array (windows * m_in points)
-  uint32_t* s_out;           // windows * m_in/K
-  uint32_t* tw_out;          // windows * m_in/K
-  PC_HD void operator()(uint32_t gidx) const {
-    const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;   // windows are contiguous, m_in % K == 0
-    Pt run = Pt::infinity(), acc = Pt::infinity();
-    for (uint32_t j = K; j-- > 0;) {
-      run.add(Pt::load(base + (size_t)j * Pt::WORDS));
-      if (j + weight_off > 0) acc.add(run);
-    }
-    run.store(s_out + (size_t)gidx * Pt::WORDS);
-    acc.store(tw_out + (size_t)gidx * Pt::WORDS);
-  }
-};
-
 // One launch per level: lanes [0, cnt) do the weighted running sums of this level; lanes
 // [cnt*(1+a), cnt*(2+a)) fold older plain array a (fan-in K).  Serial depth per level =
 // one launch instead of (1 + l).
