@@ -76,3 +76,22 @@ def test_group_mode_one_process():
     assert d["n_gpus"] == 2 and d["parity"]["all_steps_ok"] and d["parity"]["checked"] == 4
     d = run_bench(["--mode", "group", "--gpus", "1", "--log-degree", "14", "--steps", "3", "--group-coeffs", "device"])
     assert d["n_gpus"] == 1 and d["parity"]["all_steps_ok"]
+
+
+def test_two_ranks_started_by_torchrun_as_the_driver_does():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`:
+    the command line of the driver's scaling runs (the ranks come from the environment, nothing is self-launched): one JSON line
+    from rank 0, weak scaling, both ranks' chunks in the parity check."""
+    env = dict(os.environ, PC_BENCH_DEVICES="0,0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-degree", "14", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dist"]["world_size"] == 2
+    assert d["parity"]["commit_ok"] and d["parity"]["open_ok"] and d["parity"]["commitments_checked"] == 3
