@@ -41,9 +41,11 @@ pub mod ipa_pc;
 pub mod kzg10_hip;
 pub mod ligero;
 pub mod marlin_kzg10;
+pub mod sonic_kzg10;
 
 pub use curve::{HipCurve, HipField};
 pub use group::HipGroupKey;
 pub use ipa_pc::HipIpaPC;
 pub use ligero::HipUnivariateLigero;
 pub use marlin_kzg10::HipMarlinKZG10;
+pub use sonic_kzg10::HipSonicKZG10;

@@ -1,0 +1,193 @@
+//! `HipSonicKZG10<E, P>`: `PolynomialCommitment` with EXACTLY the associated types of the reference's `SonicKZG10`
+//! (`poly-commit/src/sonic_pc/mod.rs:112-120`), so parameters, keys, commitments, states and proofs are interchangeable and
+//! `setup` / `trim` / `check` (and the `batch_*` / `*_combinations` methods) delegate to the reference.  Sonic reaches the MSM
+//! only through `kzg10::KZG10::commit` (`:318`) and `kzg10::KZG10::open` (`:378`); both are replaced by [`crate::kzg10_hip`]:
+//!
+//! * `commit` (`:273-338`): ONE commitment per polynomial, over `ck.shifted_powers(bound)` when it carries a degree bound (a
+//!   tail of the same resident key, found with its offset), over `ck.powers()` otherwise; hiding draws in the reference's order.
+//! * `open` (`:340-383`): the challenge loop is the reference's (one challenge up front, one after every polynomial); the
+//!   combination is accumulated on the device (`pc_hip_fr_lincomb` over the cached copies) when the polynomials are large, the
+//!   witness division and its MSM run there too.  The shifted key is not touched by `open`.
+use ark_crypto_primitives::sponge::CryptographicSponge;
+use ark_ec::{pairing::Pairing, VariableBaseMSM};
+use ark_poly::DenseUVPolynomial;
+use ark_poly_commit::{
+    kzg10,
+    sonic_pc::{CommitterKey, SonicKZG10, UniversalParams, VerifierKey},
+    BatchLCProof, Error, Evaluations, LabeledCommitment, LabeledPolynomial, LinearCombination, PCCommitterKey, PolynomialCommitment,
+    QuerySet, CHALLENGE_SIZE,
+};
+use ark_std::{marker::PhantomData, ops::Div, rand::RngCore};
+use core::ffi::c_void;
+
+use crate::curve::{HipCurve, HipField};
+use crate::device::{self, check, ctx, DevicePoly};
+use crate::{ffi, kzg10_hip};
+
+pub struct HipSonicKZG10<E: Pairing, P: DenseUVPolynomial<E::ScalarField>> {
+    _engine: PhantomData<E>,
+    _poly: PhantomData<P>,
+}
+
+// kzg10/mod.rs:424-449 (pub(crate) in the reference): restated verbatim
+fn check_degrees_and_bounds<F: ark_ff::PrimeField, P: DenseUVPolynomial<F>>(supported_degree: usize, max_degree: usize,
+                                                                             enforced_degree_bounds: Option<&[usize]>,
+                                                                             p: &LabeledPolynomial<F, P>) -> Result<(), Error> {
+    if let Some(bound) = p.degree_bound() {
+        let enforced_degree_bounds = enforced_degree_bounds.ok_or(Error::UnsupportedDegreeBound(bound))?;
+        if enforced_degree_bounds.binary_search(&bound).is_err() {
+            Err(Error::UnsupportedDegreeBound(bound))
+        } else if bound < p.degree() || bound > max_degree {
+            Err(Error::IncorrectDegreeBound { poly_degree: p.degree(), degree_bound: p.degree_bound().unwrap(), supported_degree, label: p.label().to_string() })
+        } else {
+            Ok(())
+        }
+    } else {
+        Ok(())
+    }
+}
+
+impl<E, P> PolynomialCommitment<E::ScalarField, P> for HipSonicKZG10<E, P>
+where
+    E: Pairing,
+    E::G1Affine: HipCurve,
+    E::ScalarField: HipField,
+    E::G1: VariableBaseMSM<MulBase = E::G1Affine>,
+    P: DenseUVPolynomial<E::ScalarField, Point = E::ScalarField>,
+    for<'a, 'b> &'a P: Div<&'b P, Output = P>,
+{
+    type UniversalParams = UniversalParams<E>;
+    type CommitterKey = CommitterKey<E>;
+    type VerifierKey = VerifierKey<E>;
+    type Commitment = kzg10::Commitment<E>;
+    type CommitmentState = kzg10::Randomness<E::ScalarField, P>;
+    type Proof = kzg10::Proof<E>;
+    type BatchProof = Vec<Self::Proof>;
+    type Error = Error;
+
+    fn setup<R: RngCore>(max_degree: usize, num_vars: Option<usize>, rng: &mut R) -> Result<Self::UniversalParams, Self::Error> {
+        SonicKZG10::<E, P>::setup(max_degree, num_vars, rng)                                // sonic_pc/mod.rs:124-131
+    }
+
+    fn trim(pp: &Self::UniversalParams, supported_degree: usize, supported_hiding_bound: usize, enforced_degree_bounds: Option<&[usize]>)
+        -> Result<(Self::CommitterKey, Self::VerifierKey), Self::Error> {
+        // (the upload happens at first use or in `warm`: see HipMarlinKZG10::trim for why not here)
+        SonicKZG10::<E, P>::trim(pp, supported_degree, supported_hiding_bound, enforced_degree_bounds)   // :133-271
+    }
+
+    fn commit<'a>(ck: &Self::CommitterKey, polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<E::ScalarField, P>>,
+                  rng: Option<&mut dyn RngCore>) -> Result<(Vec<LabeledCommitment<Self::Commitment>>, Vec<Self::CommitmentState>), Self::Error>
+    where
+        P: 'a,
+    {
+        let rng = &mut ark_poly_commit::optional_rng::OptionalRng(rng);
+        let mut labeled_comms = Vec::new();
+        let mut randomness = Vec::new();
+        for labeled_polynomial in polynomials {
+            let enforced_degree_bounds: Option<&[usize]> = ck.enforced_degree_bounds.as_ref().map(|bounds| bounds.as_slice());
+            check_degrees_and_bounds(ck.supported_degree(), ck.max_degree, enforced_degree_bounds, labeled_polynomial)?;   // :297-302
+            let polynomial: &P = labeled_polynomial.polynomial();
+            let degree_bound = labeled_polynomial.degree_bound();
+            let hiding_bound = labeled_polynomial.hiding_bound();
+            let label = labeled_polynomial.label();
+            let powers = if let Some(degree_bound) = degree_bound {                           // :312-316
+                ck.shifted_powers(degree_bound).unwrap()
+            } else {
+                ck.powers()
+            };
+            let (comm, rand) = kzg10_hip::commit::<E, P>(&powers, polynomial, hiding_bound, Some(rng))?;   // was :318
+            labeled_comms.push(LabeledCommitment::new(label.to_string(), comm, degree_bound));
+            randomness.push(rand);
+        }
+        Ok((labeled_comms, randomness))
+    }
+
+    fn open<'a>(ck: &Self::CommitterKey, labeled_polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<E::ScalarField, P>>,
+                _commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>, point: &'a P::Point,
+                sponge: &mut impl CryptographicSponge, states: impl IntoIterator<Item = &'a Self::CommitmentState>,
+                _rng: Option<&mut dyn RngCore>) -> Result<Self::Proof, Self::Error>
+    where
+        P: 'a,
+        Self::CommitmentState: 'a,
+        Self::Commitment: 'a,
+    {
+        let mut combined_rand = kzg10::Randomness::empty();
+        let mut terms: Vec<(E::ScalarField, &P)> = Vec::new();
+        let mut curr_challenge = sponge.squeeze_field_elements_with_sizes(&[CHALLENGE_SIZE])[0];                    // :357
+        for (polynomial, state) in labeled_polynomials.into_iter().zip(states) {
+            let enforced_degree_bounds: Option<&[usize]> = ck.enforced_degree_bounds.as_ref().map(|bounds| bounds.as_slice());
+            check_degrees_and_bounds(ck.supported_degree(), ck.max_degree, enforced_degree_bounds, polynomial)?;
+            terms.push((curr_challenge, polynomial.polynomial()));                                                   // :372, formed below
+            combined_rand += (curr_challenge, state);
+            curr_challenge = sponge.squeeze_field_elements_with_sizes(&[CHALLENGE_SIZE])[0];
+        }
+        let powers = ck.powers();
+        let n_out = terms.iter().map(|(_, q)| q.coeffs().len()).max().unwrap_or(0);
+        if n_out >= device::min_pairs() {                                                                            // was :378
+            let c = ctx()?;
+            let devs = terms.iter().map(|(_, q)| device::device_poly(q.coeffs())).collect::<Result<Vec<_>, _>>()?;
+            let ptrs: Vec<*const c_void> = devs.iter().map(|d| d.dev as *const c_void).collect();
+            let lens: Vec<usize> = terms.iter().map(|(_, q)| q.coeffs().len()).collect();
+            let xi: Vec<[u64; 4]> = terms.iter().map(|(ch, _)| ch.to_mont_limbs()).collect();
+            let comb = DevicePoly::alloc(n_out)?;
+            check(c, unsafe {
+                ffi::pc_hip_fr_lincomb(c.raw, <E::ScalarField as HipField>::FIELD_OF, ptrs.as_ptr(), ffi::PC_MEM_DEVICE, lens.as_ptr(), terms.len(),
+                                       xi.as_ptr() as *const c_void, comb.dev, ffi::PC_MEM_DEVICE, n_out)
+            })?;
+            kzg10_hip::open_device::<E, P>(&powers, &comb, n_out, *point, &combined_rand)
+        } else {
+            let mut combined_polynomial = P::zero();
+            for (challenge, q) in &terms {
+                combined_polynomial += (*challenge, *q);
+            }
+            kzg10_hip::open::<E, P>(&powers, &combined_polynomial, *point, &combined_rand)
+        }
+    }
+
+    fn check<'a>(vk: &Self::VerifierKey, commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>, point: &'a P::Point,
+                 values: impl IntoIterator<Item = E::ScalarField>, proof: &Self::Proof, sponge: &mut impl CryptographicSponge,
+                 rng: Option<&mut dyn RngCore>) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        SonicKZG10::<E, P>::check(vk, commitments, point, values, proof, sponge, rng)          // verifier side: the reference's (:385-430)
+    }
+
+    fn batch_check<'a, R: RngCore>(vk: &Self::VerifierKey, commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+                                   query_set: &QuerySet<P::Point>, values: &Evaluations<E::ScalarField, P::Point>, proof: &Self::BatchProof,
+                                   sponge: &mut impl CryptographicSponge, rng: &mut R) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        SonicKZG10::<E, P>::batch_check(vk, commitments, query_set, values, proof, sponge, rng)   // :432-510
+    }
+
+    fn check_combinations<'a, R: RngCore>(vk: &Self::VerifierKey, linear_combinations: impl IntoIterator<Item = &'a LinearCombination<E::ScalarField>>,
+                                          commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+                                          eqn_query_set: &QuerySet<P::Point>, eqn_evaluations: &Evaluations<P::Point, E::ScalarField>,
+                                          proof: &BatchLCProof<E::ScalarField, Self::BatchProof>, sponge: &mut impl CryptographicSponge,
+                                          rng: &mut R) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        SonicKZG10::<E, P>::check_combinations(vk, linear_combinations, commitments, eqn_query_set, eqn_evaluations, proof, sponge, rng)   // :600-680
+    }
+    // batch_open / open_combinations: the trait's provided methods (lib.rs:269-371, :435-500), which call the `open` above
+    // (SonicKZG10::open_combinations, :512-598, builds the combined polynomials and calls batch_open -- semantically the same).
+}
+
+impl<E, P> HipSonicKZG10<E, P>
+where
+    E: Pairing,
+    E::G1Affine: HipCurve,
+    P: DenseUVPolynomial<E::ScalarField>,
+{
+    /// Upload `ck.powers_of_g` (and `ck.shifted_powers_of_g`) and build their window tables now instead of at the first `commit`.
+    pub fn warm(ck: &CommitterKey<E>) -> Result<(), Error> {
+        device::resident(&ck.powers_of_g[..])?;
+        if let Some(sp) = ck.shifted_powers_of_g.as_ref() {
+            device::resident(&sp[..])?;
+        }
+        Ok(())
+    }
+}

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../poly_commit_amd/host/marlin_kzg10.hpp"
+#include "../../poly_commit_amd/host/sonic_kzg10.hpp"
 #include "../../poly_commit_amd/host/linear_codes.hpp"
 #include "../../poly_commit_amd/host/ipa_pc.hpp"
 #include "../../poly_commit_amd/host/hyrax.hpp"
@@ -165,6 +166,56 @@ static void run(pc_ctx* ctx, const char* name) {
       // a degree bound the key does not enforce is rejected (Error::UnsupportedDegreeBound, kzg10/mod.rs:430-434)
       LabeledPolynomial<E> bad = polys[0]; bad.degree_bound = 11;
       CHECK(M::check_degrees_and_bounds(ck, bad).kind == Error::UnsupportedDegreeBound);
+      ck.release();
+    }
+  }
+  // ---- SonicKZG10 (sonic_pc tests: the same single_poly / degree_bound / hiding shapes, sonic_pc/mod.rs:729-928): a bounded
+  // polynomial is committed ONCE, over the shifted powers (C_j = beta^(D - d_j) p_j(beta) g, its hiding term shifted alike); `open`
+  // is one combination over the plain powers.  The verifier's equation (accumulate_elems / check_elems, :540-680) in G1 with the
+  // trapdoor:   sum_j xi_j (beta^-(D - d_j) C_j - v_j g) - random_v gamma_g == (beta - z) w
+  {
+    typedef SonicKZG10<E> S;
+    struct Chal : ChallengeSource<E> { TestRng<E> r{0x50A1C}; std::vector<FrT<E>> log; FrT<E> squeeze_challenge() override { FrT<E> c = r.next_fr(); log.push_back(c); return c; } };
+    for (int variant = 0; variant < 3; variant++) {
+      const bool hiding = variant == 1;
+      std::vector<size_t> bounds = {9, 14, 20};
+      SonicCommitterKey<E> ck;
+      CHECK(!S::trim(ctx, pg, pgg, 22, 2, &bounds, ck));
+      CHECK(ck.shifted_powers_of_g->size() == 20 + 1 && ck.shifted_powers_of_gamma_g.size() == 3);
+      std::vector<LabeledPolynomial<E>> polys;
+      size_t degs[4] = {7, 14, 22, 3};
+      for (int j = 0; j < 4; j++) {
+        LabeledPolynomial<E> lp; lp.label = "s" + std::to_string(j); lp.polynomial = rand_poly<E>(degs[j], rng);
+        if (j == 0) lp.degree_bound = 9;
+        if (j == 1 && variant != 2) lp.degree_bound = 14;
+        if (hiding) lp.hiding_bound = 1;
+        polys.push_back(lp);
+      }
+      std::vector<Commitment<E>> comms; std::vector<Randomness<E>> states;
+      CHECK(!S::commit(ck, polys, hiding ? &rng : nullptr, comms, states));
+      auto shift_of = [&](int j) { Fr bp = Fr::one(); if (polys[j].degree_bound) for (size_t i = 0; i < ck.max_degree - *polys[j].degree_bound; i++) bp = bp * beta; return bp; };
+      if (!hiding) {      // the bounded commitment is the plain one times beta^(D - d)
+        Commitment<E> plain; Randomness<E> r0;
+        CHECK(!K::commit(ck.powers(), polys[0].polynomial, nullptr, nullptr, plain, r0));
+        CHECK(comms[0].comm == plain.comm.mul(shift_of(0)));
+      }
+      Fr z = rng.next_fr();
+      Chal sponge;
+      Proof<E> proof;
+      CHECK(!S::open(ck, polys, z, sponge, states, proof));
+      CHECK(proof.has_random_v == hiding && sponge.log.size() == 5);       // one challenge up front, one after every polynomial
+      G1Affine<E> lhs = G1Affine<E>::zero();
+      for (int j = 0; j < 4; j++) {
+        Fr v = polys[j].polynomial.evaluate(z);
+        lhs = lhs.add(comms[j].comm.mul(shift_of(j).inverse()).add(g.mul(v).neg()).mul(sponge.log[j]));
+      }
+      if (hiding) lhs = lhs.add(gamma_g.mul(proof.random_v).neg());
+      CHECK(lhs == proof.w.mul(beta - z));
+      LabeledPolynomial<E> bad = polys[0]; bad.degree_bound = 11;
+      CHECK(S::check_degrees_and_bounds(ck, bad).kind == Error::UnsupportedDegreeBound);
+      std::vector<size_t> too_high = {23};
+      SonicCommitterKey<E> ck2;
+      CHECK(S::trim(ctx, pg, pgg, 22, 2, &too_high, ck2).kind == Error::UnsupportedDegreeBound);       // sonic_pc/mod.rs:186-188
       ck.release();
     }
   }
