@@ -283,35 +283,49 @@ def madd_peak(curve):
 
 
 def cpu_baseline(curve, srs, log_d, budget_s=30.0):
-    """The CPU port (oracle/: restated ark-ec signed-digit Pippenger) timed on this box's cores on a bounded sample of
-    the same workload: one MSM over the leading 2^k points of the resident SRS, k as large as fits the budget
-    (k = log_d when the box is fast enough)."""
+    """The CPU port (oracle/fast_msm.hpp: ark-ec's signed-digit bucket method with XYZZ buckets, an unrolled 64-bit CIOS multiplier
+    and (window, chunk) tasks over all cores) timed on this box's cores on the same workload: ONE MSM over the leading 2^k points of
+    the resident true SRS -- k = log_d (the full size the metric is quoted on) when the box does it within the budget -- plus the
+    single-thread rate at 2^20 with ark-ec's own window rule (the per-core figure: ark-ec parallelises over windows only)."""
     import oracle_lib as O
     cores = os.cpu_count() or 1
     n0 = 1 << min(16, log_d)
     b = srs.read(1, n0)
     s = O.gen_scalars(curve, 1, n0)
     t = time.perf_counter()
-    O.msm_pippenger(curve, b, s, cores, 1)
+    O.msm_pippenger(curve, b, s, cores, 2)
     rate = n0 / max(time.perf_counter() - t, 1e-6)
+    t = time.perf_counter()
+    O.msm_pippenger(curve, b, s, 1, 2)
+    rate1 = n0 / max(time.perf_counter() - t, 1e-6)
+    # single thread: 2^20 if that fits a third of the budget (the rate per pair falls slowly with the size: wider windows)
+    lg1 = min(16, log_d)
+    while lg1 < min(20, log_d) and (1 << (lg1 + 1)) / rate1 < budget_s / 3:
+        lg1 += 1
     lg = min(16, log_d)
-    while lg < log_d and (1 << (lg + 1)) / rate * 2.2 < budget_s:      # both schedules are tried
+    while lg < log_d and (1 << (lg + 1)) / rate * 1.5 < budget_s / 2:
         lg += 1
     n = 1 << lg
     b = srs.read(1, n)
     s = O.gen_scalars(curve, 2, n)
-    best = None
-    for mode in (1, 0):   # chunk-parallel and window-parallel schedules; keep the faster
-        t = time.perf_counter()
-        O.msm_pippenger(curve, b, s, cores, mode)
-        dt = time.perf_counter() - t
-        best = dt if best is None else min(best, dt)
-        if dt > budget_s / 2:
-            break
-    return {"value": n / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs (the leading points of the same true SRS), restated ark-ec signed-digit "
-                      f"Pippenger (oracle/oracle.cpp), best of chunk-/window-parallel, {cores} threads",
-            "note": "context only: the port's rate swings 2.5x between boxes of the pool; never credit"}
+    t = time.perf_counter()
+    got = O.msm_pippenger(curve, b, s, cores, 2)
+    dt = time.perf_counter() - t
+    n1 = 1 << lg1
+    t = time.perf_counter()
+    got1 = O.msm_pippenger(curve, b[:n1], s[:n1], 1, 2)
+    dt1 = time.perf_counter() - t
+    # the port is itself checked here: the GPU's MSM over the same pairs (pc_hip_msm on the resident key) must give the same point
+    dev, _ = srs.msm(s, n=n, base_offset=1)
+    dev1, _ = srs.msm(np.ascontiguousarray(s[:n1]), n=n1, base_offset=1)
+    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs (the leading points of the same true SRS) on {cores} threads, {dt:.2f} s; "
+                      f"restated ark-ec signed-digit bucket method (oracle/fast_msm.hpp), NOT ark-ec itself",
+            "per_core": {"value": n1 / dt1, "unit": "pairs/s", "threads": 1,
+                         "sample": f"1 MSM of 2^{lg1} pairs on ONE thread with ark-ec's window rule, {dt1:.2f} s"},
+            "agrees_with_gpu": bool((got == dev).all() and (got1 == dev1).all()),
+            "note": "a port of the algorithm, not the reference crate (no Rust toolchain here): ark-ec 0.5 itself parallelises over its "
+                    "~16 windows only; its published per-core rates are of the order of 1e5 pairs/s"}
 
 
 # ------------------------------------------------------------------------------------------------------------

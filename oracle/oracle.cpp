@@ -121,12 +121,16 @@ static Jac<C> msm_wnaf(const uint64_t* bases, const uint64_t* scalars, size_t n,
   return total.add(wsum[0]);
 }
 
+#include "fast_msm.hpp"
+
 // mode 0: windows are the parallel unit (ark-ec msm_bigint_wnaf under rayon);
 // mode 1: input split into `threads` chunks, each a full sequential msm_wnaf, partial
-//         results added (the chunk-parallel schedule of later ark-ec releases).
+//         results added (the chunk-parallel schedule of later ark-ec releases);
+// mode 2: the tuned port (fast_msm.hpp: same bucket method, XYZZ buckets, (window, chunk) tasks) -- the CPU baseline of bench.py.
 template <class C>
 static Jac<C> msm_pippenger(const uint64_t* bases, const uint64_t* scalars, size_t n, int threads, int mode) {
   constexpr int N = C::FqP::N;
+  if (mode == 2) return fastmsm::msm<C>(bases, scalars, n, threads);
   if (mode == 0 || threads <= 1 || n < (size_t)threads * 64) return msm_wnaf<C>(bases, scalars, n, threads);
   size_t chunk = (n + threads - 1) / threads;
   size_t nch = (n + chunk - 1) / chunk;
@@ -362,7 +366,7 @@ int orc_kzg_commit(int curve, const uint64_t* powers, size_t n_powers, const uin
       for (size_t i = 0; i < m; i++) F::from_raw(coeffs + 4 * (lz + i)).to_canonical(&big[4 * i]);
       size_t nb = n_powers > lz ? n_powers - lz : 0;
       size_t pairs = std::min(nb, m);   // msm_bigint uses min(len)
-      store_aff<C>(msm_pippenger<C>(powers + 2 * N * lz, big.data(), pairs, threads, 1).to_affine(), out);
+      store_aff<C>(msm_pippenger<C>(powers + 2 * N * lz, big.data(), pairs, threads, 2).to_affine(), out);
     }
   });
   return rc;

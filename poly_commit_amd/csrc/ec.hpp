@@ -83,7 +83,7 @@ struct XyzzD {
     ZZ = ZZ.mul(PP); ZZZ = ZZZ.mul(PPP);
   }
   // The same mixed addition with LAZY coordinates (fp32.hpp, LAZY_OK): X, Y, ZZ, ZZZ stay in [0, 2p) between additions and
-  // none of the nine multiplier calls ends in a conditional subtraction; the affine operand is canonical, its negation
+  // none of the nine multiplier calls ends in a conditional subtraction (BN254: the fused pair keeps its one); the affine operand is canonical, its negation
   // (`negate`: the sign of the signed digit) is p - y without a zero special case.  Infinity stays the exact ZZ == 0: a
   // product ZZ * PP = 0 (mod p) needs P = 0 (mod p), which takes the branch below.  `canonical()` where the sum leaves the
   // chain (bucket store, partial list).
@@ -102,7 +102,8 @@ struct XyzzD {
     }
     Fq PP = Pp.sqr_lz(), PPP = Pp.mul_lz(PP), Q = X.mul_lz(PP);
     Fq X3 = R.sqr_lz().sub_lz(PPP).sub_lz(Q.dbl_lz());
-    Y = R.mul_add_mul_lz(Q.sub_lz(X3), Y.neg_lz(), PPP);      // R (Q - X3) + (2p - Y) PPP <= 8 p^2: one reduction, below 2p
+    Y = R.mul_add_mul_lz(Q.sub_lz(X3), Y.neg_lz(), PPP);      // R (Q - X3) + (2p - Y) PPP <= 8 p^2: one reduction, below 2p (R >= 8p), or
+                                                              // below 3p and one conditional subtraction (BN254)
     X = X3;
     ZZ = ZZ.mul_lz(PP); ZZZ = ZZZ.mul_lz(PPP);
   }

@@ -13,6 +13,11 @@
 #include <stdint.h>
 #include "field_constants.h"
 
+// tuning experiment switch (poly_commit_amd/build.py, PC_HIP_CXXFLAGS): 0 keeps the 8-limb fields on the canonical path
+#ifndef PC_LAZY_N8
+#define PC_LAZY_N8 1
+#endif
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PC_HD __host__ __device__ __forceinline__
@@ -210,10 +215,11 @@ struct Fd {
   __device__ __forceinline__ Fd mul(const Fd& o) const { return mul_impl<false>(o); }
   __device__ __forceinline__ Fd sqr() const { return sqr_inl(); }
   __device__ __forceinline__ Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl(b, c, d); }
-  // Lazy forms (see LAZY_OK below): operands in [0, 2p], no final conditional subtraction, result in [0, 2p)
+  // Lazy forms (see LAZY_OK below): operands in [0, 2p], result in [0, 2p); no final conditional subtraction (the fused pair
+  // keeps its one where R < 8p)
   __device__ __forceinline__ Fd mul_lz(const Fd& o) const { return mul_impl<false, false>(o); }
   __device__ __forceinline__ Fd sqr_lz() const { return sqr_inl<false>(); }
-  __device__ __forceinline__ Fd mul_add_mul_lz(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl<false>(b, c, d); }
+  __device__ __forceinline__ Fd mul_add_mul_lz(const Fd& b, const Fd& c, const Fd& d) const { return mul_add_mul_inl<!LAZY_FUSED_OK>(b, c, d); }
   // (the three products as real functions -- operands by value, in registers -- were measured against the ~50 KB of
   // inlined code of a mixed addition: accumulate 36.8 -> 44.0 ms; the instruction cache is not what limits it)
 
@@ -346,20 +352,50 @@ struct Fd {
 #if !defined(__HIP_DEVICE_COMPILE__)
   PC_HD Fd sqr() const { return mul(*this); }
   PC_HD Fd mul_add_mul(const Fd& b, const Fd& c, const Fd& d) const { return mul(b).add(c.mul(d)); }
-  // host: the CIOS multiplier canonicalises inputs below 2p as well (its result before the subtraction is below 2p), and a
-  // canonical value is a valid lazy one
-  PC_HD Fd mul_lz(const Fd& o) const { return mul(o); }
-  PC_HD Fd sqr_lz() const { return mul(*this); }
-  PC_HD Fd mul_add_mul_lz(const Fd& b, const Fd& c, const Fd& d) const { return canon().mul(b.canon()).add(c.canon().mul(d.canon())); }
+  // host: (a b [+ c d] + m p) / R by rows with ONE interleaved reduction and, for `reduce == false`, no final subtraction --
+  // Montgomery's m is determined by the sum alone, so these are the device's lazy values bit for bit (the CPU-stepped
+  // tests then exercise the real [0, 2p) ranges, not canonicalised stand-ins)
+  static inline Fd mont_rows_host(const Fd& a, const Fd& b, const Fd* c, const Fd* d, bool reduce) {
+    uint32_t t[N + 2];
+    for (int i = 0; i < N + 2; i++) t[i] = 0;
+    for (int i = 0; i < N; i++) {
+      for (int pass = 0; pass < (c ? 2 : 1); pass++) {
+        const Fd& x = pass ? *c : a; const uint32_t yi = pass ? d->l[i] : b.l[i];
+        uint64_t cy = 0;
+        for (int j = 0; j < N; j++) { cy += (uint64_t)x.l[j] * yi + t[j]; t[j] = (uint32_t)cy; cy >>= 32; }
+        cy += t[N]; t[N] = (uint32_t)cy; t[N + 1] += (uint32_t)(cy >> 32);
+      }
+      const uint32_t m = t[0] * P::INV;
+      uint64_t cy = (uint64_t)m * P::MOD[0] + t[0];
+      cy >>= 32;
+      for (int j = 1; j < N; j++) { cy += (uint64_t)m * P::MOD[j] + t[j]; t[j - 1] = (uint32_t)cy; cy >>= 32; }
+      cy += t[N]; t[N - 1] = (uint32_t)cy; cy >>= 32;
+      cy += t[N + 1]; t[N] = (uint32_t)cy; t[N + 1] = (uint32_t)(cy >> 32);
+    }
+    Fd r;
+    for (int i = 0; i < N; i++) r.l[i] = t[i];
+    if (reduce) cond_sub(r.l, t[N]);
+    return r;
+  }
+  PC_HD Fd mul_lz(const Fd& o) const { return mont_rows_host(*this, o, nullptr, nullptr, false); }
+  PC_HD Fd sqr_lz() const { return mont_rows_host(*this, *this, nullptr, nullptr, false); }
+  PC_HD Fd mul_add_mul_lz(const Fd& b, const Fd& c, const Fd& d) const { return mont_rows_host(*this, b, &c, &d, !LAZY_FUSED_OK); }
 #endif
 
   // ---- lazy reduction (Walter's bound) ---------------------------------------------------------------------------
-  // With R >= 8p a Montgomery product of operands in [0, 2p] is below (4p^2 + pR)/R < 2p WITHOUT the final conditional
-  // subtraction, and so is the fused a*b + c*d ((8p^2 + pR)/R < 2p): inside a long chain of multiplications (the mixed
-  // addition of the bucket accumulation: 9 multiplier calls) values are kept in [0, 2p) and canonicalised only where they
-  // leave the chain.  Additive operations then work modulo 2p.  R >= 8p holds for BLS12-381 Fq (381 + 3 <= 384); BN254 /
-  // Pallas (254 / 255 bits in 256) do not qualify and keep the canonical path.
-  static constexpr bool LAZY_OK = P::BITS + 3 <= 32 * N;
+  // With R >= 4p a Montgomery product of operands in [0, 2p] is below (4p^2 + pR)/R <= 2p WITHOUT the final conditional
+  // subtraction: inside a long chain of multiplications (the mixed addition of the bucket accumulation: 9 multiplier calls)
+  // values are kept in [0, 2p) and canonicalised only where they leave the chain; additive operations then work modulo 2p
+  // (their results, up to 4p, must fit N limbs: the same bound).  LAZY_OK: BLS12-381 Fq (381 bits in 384) and BN254 Fq
+  // (254 in 256; R = 5.29p); Pallas' p = 2^254 + ... has 4p > 2^256 and keeps the canonical path.
+  // The fused a*b + c*d is below (8p^2 + pR)/R: below 2p only when R >= 8p (LAZY_FUSED_OK: BLS12-381); with 4p <= R < 8p it is
+  // below 3p and keeps its ONE conditional subtraction, which brings it below 2p again (not necessarily below p).
+  // LAZY_STORE_OK (R >= 9p): lazily reduced coordinates may also LEAVE the accumulation as they are -- the consumers' formulas
+  // (XyzzD::add / dbl, canonical multiplier) start with products of loaded coordinates, except dbl()'s U = 2Y (one conditional
+  // subtraction: below 3p for Y < 2p), whose square needs 9p^2 < pR to come out canonical.
+  static constexpr bool LAZY_OK = P::BITS + 2 <= 32 * N && (N > 8 || PC_LAZY_N8);
+  static constexpr bool LAZY_FUSED_OK = P::BITS + 3 <= 32 * N;
+  static constexpr bool LAZY_STORE_OK = LAZY_FUSED_OK && ((uint64_t)P::MOD[N - 1] + 1) * 9 <= ((uint64_t)1 << 32);
   static PC_HD uint32_t mod2(int i) { return (P::MOD[i] << 1) | (i ? P::MOD[i - 1] >> 31 : 0u); }      // limbs of 2p
   // (a - b) mod 2p for a, b in [0, 2p]: in [0, 2p] (in [0, 2p) when a < 2p)
   PC_HD Fd sub_lz(const Fd& o) const {

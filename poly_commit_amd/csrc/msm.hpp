@@ -223,10 +223,16 @@ struct AccumulateBody {
   // the running sum is kept with lazily reduced coordinates where the field allows it (ec.hpp, add_affine_lz): canonical
   // again wherever it leaves the lane
   static constexpr bool LAZY = Pt::Fq::LAZY_OK;
+  // ... and may leave it that way only where the consumers' first operations absorb coordinates below 2p (fp32.hpp, LAZY_STORE_OK:
+  // R >= 9p, BLS12-381); BN254 (R = 5.3p) canonicalises at the flush
+  static constexpr bool LAZY_STORE = LAZY && Pt::Fq::LAZY_STORE_OK;
+  // the form in which a running sum leaves the lane (bucket store, partial list, the register copy the in-workgroup joins use)
+  static PC_HD Pt store_form(const Pt& acc) { if constexpr (LAZY && !LAZY_STORE) return acc.canonical(); else return acc; }
   PC_HD void flush(const Pt& acc_lz, uint32_t k, bool complete, uint32_t t, bool first, uint32_t& k0, uint32_t& k1) const {
-    // (the sum leaves the lane lazily reduced, coordinates in [0, 2p): every consumer -- the joins of k_accumulate, the segmented and
-    // the bucket reduction, the host tail -- feeds loaded coordinates into multiplications first (XyzzD::add / dbl), which accept
-    // them; infinity is the exact ZZ == 0 either way.  Saves four conditional subtractions per flush: 1.3 % of the kernel)
+    // (LAZY_STORE: the sum leaves the lane lazily reduced, coordinates in [0, 2p): every consumer -- the joins of k_accumulate, the
+    // segmented and the bucket reduction, the host tail -- feeds loaded coordinates into multiplications first (XyzzD::add), or doubles Y
+    // once and squares (XyzzD::dbl: 2Y < 3p after its conditional subtraction, 9p^2 < pR); infinity is the exact ZZ == 0 either way and
+    // Y = 0 (mod p) cannot occur (no 2-torsion on these curves).  Saves four conditional subtractions per flush: 1.3 % of the kernel)
     const Pt& acc = acc_lz;
     if (complete) { acc.store(buckets + (size_t)k * Pt::WORDS); return; }
     uint32_t slot = first ? 2 * t : 2 * t + 1;
@@ -263,7 +269,7 @@ struct AccumulateBody {
         // (waiting for the youngest load waits for all older ones: that stalled every wave on the
         // HBM latency of the prefetch it had just issued, on nearly every iteration).
         if (p == boundary) {
-          flush(acc, k, run_lo >= s, t, first, k0, k1);       // its end, p, is inside the chunk
+          flush(store_form(acc), k, run_lo >= s, t, first, k0, k1);       // its end, p, is inside the chunk
           first = false; acc = Pt::infinity();
           k++; run_lo = p; boundary = next_boundary;
           while (boundary <= p) { k++; boundary = offsets[k + 1]; }      // empty buckets (rare): all start at p
@@ -277,6 +283,7 @@ struct AccumulateBody {
         if constexpr (LAZY) acc.add_affine_lz(pt, (val >> 31) != 0); else acc.add_affine(pt.neg_if(val >> 31));
         val = nval; nval = nnval; pt = npt;
       }
+      acc = store_form(acc);
       flush(acc, k, run_lo >= s && boundary <= e, t, first, k0, k1);
       last = acc;
     }

@@ -172,14 +172,16 @@ __global__ void __launch_bounds__(256) k_bucket_level_coop2(uint32_t K, uint32_t
 // segmented Hillis-Steele scan over the workgroup's lanes (one step per doubling of the longest chain, none when no lane is
 // transparent), and the closing lane adds the scanned sum of its left neighbour.  Chains that leave the workgroup keep ONE
 // partial per side (k_accumulate_edges joins those); only chains longer than that still reach the partial list.
+// Occupancy the register allocator is held to (waves per SIMD; 1 = unconstrained): the 12-limb kernel needs ~212 VGPRs (2 waves);
+// the 8-limb kernels ~150 (3 waves), PC_ACC_WAVES_N8 = 4 holds them to 128
 #ifndef PC_ACC_WAVES_PER_EU
-#define PC_ACC_WAVES_PER_EU 0
+#define PC_ACC_WAVES_PER_EU 1
 #endif
-#if PC_ACC_WAVES_PER_EU
-#define PC_ACC_BOUNDS __launch_bounds__(256, PC_ACC_WAVES_PER_EU)
-#else
-#define PC_ACC_BOUNDS __launch_bounds__(256)
+#ifndef PC_ACC_WAVES_N8
+#define PC_ACC_WAVES_N8 1
 #endif
+template <class C> struct AccTune { static constexpr int WAVES = Fd<typename C::FqP>::N <= 8 ? PC_ACC_WAVES_N8 : PC_ACC_WAVES_PER_EU; };
+#define PC_ACC_BOUNDS __launch_bounds__(256, AccTune<C>::WAVES)
 template <class C>
 __global__ void PC_ACC_BOUNDS k_accumulate(AccumulateBody<C> b, uint32_t lanes) {
   typedef XyzzD<C> Pt;

@@ -185,6 +185,8 @@ template <class P> static void fop(int op, const uint32_t* a, const uint32_t* b,
     case 13: r = x.neg_lz_canonical(); break; case 14: r = x.canon(); break;
     case 15: r = F::zero(); r.l[0] = x.is_zero_lz() ? 1u : 0u; break;
     case 16: r = x.mul_lz(y).canon(); break; case 17: r = x.sqr_lz().canon(); break; case 18: r = x.mul_add_mul_lz(y, y, x).canon(); break;
+    // ... and their RAW values (the host forms skip the final subtraction exactly where the device's do): must stay below 2p
+    case 19: r = x.mul_lz(y); break; case 20: r = x.sqr_lz(); break; case 21: r = x.mul_add_mul_lz(y, y, x); break;
     default: r = x.to_mont(); break;
   }
   r.store(out);

@@ -23,7 +23,7 @@ def lib():
     if _lib is None:
         so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
         src_m = max(os.path.getmtime(os.path.join(ROOT, "oracle", f))
-                    for f in ("oracle.cpp", "oracle_field.hpp", "oracle_constants.h"))
+                    for f in ("oracle.cpp", "oracle_field.hpp", "oracle_constants.h", "fast_msm.hpp"))
         # several ranks of one node may get here at once (bench.py --gpus N): build under a file lock
         import fcntl
         os.makedirs(os.path.dirname(so), exist_ok=True)

@@ -29,6 +29,12 @@ def _p(curve):
     return R.FIELDS[R.CURVES[curve]["fr"]]["p"]
 
 
+def _oracle_mul(curve, g, k):
+    """k * g by the CPU oracle's double-and-add (NOT the product's host routine): the closed forms below are computed outside the library under test."""
+    fr = R.FIELDS[R.CURVES[curve]["fr"]]["p"]
+    return O.msm_naive(curve, np.ascontiguousarray(g).reshape(1, -1), O.ints_to_limbs([k % fr], 4))
+
+
 def _mont1(curve, v):
     return O.fr_mont_array(curve, [v % _p(curve)])[0]
 
@@ -57,14 +63,14 @@ def test_kzg_commit_open_deg_2p24_bls12_381_true_srs(ctx):
     srs = ctx.upload_srs(curve, pts.data_ptr(), n=n)
     del pw
     for i in (0, 1, 2, 12345, d - 1, d):          # spot-check the SRS against host scalar multiplications
-        assert (srs.read(i, 1)[0] == pc.point_mul(curve, g, _mont1(curve, pow(beta, i, p)))).all(), i
+        assert (srs.read(i, 1)[0] == _oracle_mul(curve, g, (pow(beta, i, p)))).all(), i
 
     coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0024, n))
     cdev = torch.from_numpy(coeffs.view(np.int64)).cuda()
     p_beta = _fr_int(curve, O.poly_eval(curve, coeffs, beta_m))
     p_z = _fr_int(curve, O.poly_eval(curve, coeffs, z_m))
-    want_c = pc.point_mul(curve, g, _mont1(curve, p_beta))
-    want_w = pc.point_mul(curve, g, _mont1(curve, (p_beta - p_z) * pow(beta - zi, -1, p)))
+    want_c = _oracle_mul(curve, g, (p_beta))
+    want_w = _oracle_mul(curve, g, ((p_beta - p_z) * pow(beta - zi, -1, p)))
 
     qdev = torch.empty((n - 1, 4), dtype=torch.int64, device="cuda")
     ctx.witness_poly(curve, cdev.data_ptr(), z_m, out=qdev.data_ptr(), n=n)
@@ -88,12 +94,12 @@ def test_kzg_commit_open_deg_2p24_bls12_381_true_srs(ctx):
     same = torch.from_numpy(np.ascontiguousarray(np.repeat(O.fr_mont_array(curve, [s]), n, axis=0)).view(np.int64)).cuda()
     geo = s * (pow(beta, n, p) - 1) * pow(beta - 1, -1, p) % p
     got, _ = srs.msm(same, n=n, montgomery=True)
-    assert (got == pc.point_mul(curve, g, _mont1(curve, geo))).all(), "all-equal scalars"
+    assert (got == _oracle_mul(curve, g, (geo))).all(), "all-equal scalars"
     del same
 
     # and one full-size comparison with the oracle's Pippenger on the host cores
     bases_host = srs.read(0, n)
-    want = O.msm_pippenger(curve, bases_host, O.f_from_mont(curve, 1, coeffs), CORES, 1)
+    want = O.msm_pippenger(curve, bases_host, O.f_from_mont(curve, 1, coeffs), CORES, 2)
     assert (comm == want).all(), "commitment differs from the oracle MSM"
     srs.free()
 
@@ -114,11 +120,11 @@ def test_marlin_batch_64_polys_deg_2p20_bn254(ctx, table):
     polys = [torch.from_numpy(O.f_to_mont(curve, 1, h).view(np.int64)).cuda() for h in host]
     comms = srs.msm_batch([t.data_ptr() for t in polys], [n] * k)
     for j in (0, 21, 42, 63):
-        assert (comms[j] == O.msm_pippenger(curve, bases, host[j], CORES, 1)).all(), j
+        assert (comms[j] == O.msm_pippenger(curve, bases, host[j], CORES, 2)).all(), j
     # all 64 tied together by linearity: sum_j xi_j C_j == commit(sum_j xi_j p_j)  (what MarlinKZG10::open relies on)
     xi = R.gen_scalars(curve + "_fr", 0x5EED0777, k)
     xi_m = O.fr_mont_array(curve, xi)
-    lhs = pc.points_sum(curve, np.stack([pc.point_mul(curve, comms[j], xi_m[j]) for j in range(k)]))
+    lhs = O.msm_naive(curve, np.ascontiguousarray(comms), O.ints_to_limbs(xi, 4))     # by the oracle, not the library's host routines
     comb = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     ctx.fr_lincomb(curve, [t.data_ptr() for t in polys], xi_m, n_out=n, out=comb.data_ptr(), lens=[n] * k)
     rhs, _ = srs.msm(comb, n=n, montgomery=True)

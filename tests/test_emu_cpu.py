@@ -64,13 +64,15 @@ def test_field_ops_32bit_vs_bigint(curve):
                 assert got == want, (fname, op, a, b)
 
 
-def test_lazy_reduction_helpers_bls12_381_fq():
-    """The mod-2p helpers behind the lazily reduced bucket accumulation (fp32.hpp LAZY_OK: BLS12-381 Fq only), on inputs
-    anywhere in [0, 2p] including the boundary representatives 0, p, 2p."""
-    fname = "bls12_381_fq"
+@pytest.mark.parametrize("ci,fname,n64", [(0, "bls12_381_fq", 6), (1, "bn254_fq", 4)])
+def test_lazy_reduction_helpers(ci, fname, n64):
+    """The mod-2p helpers behind the lazily reduced bucket accumulation (fp32.hpp LAZY_OK: BLS12-381 Fq with R >= 8p, BN254 Fq
+    with 4p <= R < 8p, where the fused pair keeps one conditional subtraction), on inputs anywhere in [0, 2p] including the
+    boundary representatives 0, p, 2p.  The host forms skip the final subtraction exactly where the device's do, so the raw
+    outputs (ops 19-21) show the real ranges."""
     p = R.FIELDS[fname]["p"]
-    n64 = 6
-    Rm = 1 << 384
+    Rm = 1 << (64 * n64)
+    assert 4 * p <= Rm
     Ri = pow(Rm, -1, p)
     rnd = random.Random(11)
     vals = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p] + [rnd.randrange(2 * p + 1) for _ in range(30)]
@@ -78,7 +80,7 @@ def test_lazy_reduction_helpers_bls12_381_fq():
     def run(op, a, b=0):
         A, B = O.ints_to_limbs([a], n64)[0], O.ints_to_limbs([b], n64)[0]
         out = np.zeros(n64, dtype=np.uint64)
-        emu().emu_fop(0, 0, op, p32(A.view(np.uint32)), p32(B.view(np.uint32)), p32(out.view(np.uint32)))
+        emu().emu_fop(ci, 0, op, p32(A.view(np.uint32)), p32(B.view(np.uint32)), p32(out.view(np.uint32)))
         return O.limbs_to_ints(out.reshape(1, -1))[0]
     for a in vals:
         assert run(14, a) == a % p                                        # canon
@@ -90,11 +92,20 @@ def test_lazy_reduction_helpers_bls12_381_fq():
         if a < p:
             assert run(13, a) == p - a                                    # neg_lz_canonical
         assert run(17, a) == a * a * Ri % p                               # sqr_lz
+        raw = run(20, a)
+        assert raw < 2 * p and raw % p == a * a * Ri % p and (raw * Rm - a * a) % p == 0
         for b in vals:
             s = run(10, a, b)
             assert 0 <= s <= 2 * p and (s - (a - b)) % p == 0 and (a == 2 * p or s < 2 * p)   # sub_lz stays in range
             assert run(16, a, b) == a * b * Ri % p                        # mul_lz
             assert run(18, a, b) == (a * b + b * a) * Ri % p              # fused pair
+            raw = run(19, a, b)
+            assert raw < 2 * p and raw % p == a * b * Ri % p
+            # Montgomery's quotient is determined by the product alone: the raw value is exactly (a b + m p) / R
+            m = (-a * b * pow(p, -1, Rm)) % Rm
+            assert raw == (a * b + m * p) // Rm
+            raw = run(21, a, b)
+            assert raw < 2 * p and raw % p == 2 * a * b * Ri % p
 
 
 @pytest.mark.parametrize("curve", CURVES)
@@ -111,7 +122,7 @@ def test_xyzz_group_law_all_special_cases(curve):
                                p32(out.view(np.uint32)))
                 want = R.ec_add(curve, Pi, Pj) if op < 2 else R.ec_add(curve, Pi, Pi)
                 assert O.array_to_points(curve, out)[0] == want, (op, i, j)
-            if curve == "bls12_381":        # the lazily reduced mixed addition (same special cases; op 5 negates twice; op 6 chains three)
+            if curve in ("bls12_381", "bn254"):        # the lazily reduced mixed addition (same special cases; op 5 negates twice; op 6 chains three)
                 for op, want in ((4, R.ec_add(curve, Pi, Pj)), (5, R.ec_add(curve, Pi, Pj)), (6, R.ec_add(curve, Pi, Pj))):
                     out = np.zeros(arr.shape[1], dtype=np.uint64)
                     emu().emu_ecop(O.CURVES[curve], op, p32(arr[i].view(np.uint32)), p32(arr[j].view(np.uint32)), p32(out.view(np.uint32)))
@@ -178,6 +189,22 @@ def test_msm_stepped_adversarial_scalars():
         want = O.msm_naive(curve, b, sc)
         for (c, T, T2, K0) in ((0, 0, 0, 0), (6, 4, 4, 2), (9, 7, 5, 4)):
             assert (run_msm(curve, b, sc, c, T, T2, K0) == want).all(), (name, c, T)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_msm_stepped_equal_partial_sums_meet_in_the_joins(curve):
+    """ONE base repeated under ONE scalar: every chunk of a bucket's run sums to the same point, so the segmented reduction (and
+    the bucket reduction behind it) adds equal multi-entry partial sums -- XyzzD::add takes its doubling branch on coordinates
+    that left the accumulation lazily reduced (BLS12-381: in [0, 2p), fp32.hpp LAZY_STORE_OK; BN254: canonical at the flush).
+    Round-3 advisor finding: dbl()'s U = 2Y is not a product, its headroom is now stated and asserted."""
+    n = 64
+    g = O.gen_bases(curve, 3)
+    b = np.ascontiguousarray(np.repeat(g[2:3], n, axis=0))
+    k = O.gen_scalars(curve, 5, 1)
+    for sc in (np.ascontiguousarray(np.repeat(k, n, axis=0)), O.ints_to_limbs([1] * n, 4), O.ints_to_limbs([3] * n, 4)):
+        want = O.msm_naive(curve, b, sc)
+        for (c, T, T2, K0) in ((4, 4, 4, 2), (6, 8, 4, 2), (5, 2, 4, 4), (7, 16, 4, 2), (3, 1, 4, 2)):
+            assert (run_msm(curve, b, sc, c, T, T2, K0) == want).all(), (c, T)
 
 
 @pytest.mark.parametrize("n_srs,n", [(1024, 1023), (1024, 512), (1024, 31), (2048, 2047), (33, 31), (300, 255)])

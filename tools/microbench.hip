@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256) k_madd_lazy(uint32_t* out, const uint32_t
   out[t] = r;
 }
 
+
 template <class K>
 static float timeit(K launch) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -130,6 +131,54 @@ static float timeit(K launch) {
   hipDeviceSynchronize();
   hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
   float ms = 0; hipEventElapsedTime(&ms, a, b); return ms;
+}
+
+// memory-free loops of the bucket accumulation's mixed addition for one curve: canonical, the same at 2 and 4 waves per SIMD, and
+// (where the field has the headroom, fp32.hpp LAZY_OK) lazily reduced -- checked lane by lane against the canonical loop
+template <class C, int W>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) k_madd_waves(uint32_t* out, const uint32_t* pts, int npts, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  pc::XyzzD<C> acc = pc::XyzzD<C>::infinity();
+  constexpr int AW = 2 * C::FqP::N;
+  for (int it = 0; it < iters; it++) {
+    pc::AffD<C> p = pc::AffD<C>::load(pts + (size_t)((t * 31 + it) % npts) * AW);
+    if constexpr (pc::Fd<typename C::FqP>::LAZY_OK) acc.add_affine_lz(p, false); else acc.add_affine(p);
+  }
+  if constexpr (pc::Fd<typename C::FqP>::LAZY_OK) acc = acc.canonical();
+  uint32_t r = 0; for (int i = 0; i < C::FqP::N; i++) r ^= acc.X.l[i] ^ acc.ZZ.l[i];
+  out[t] = r;
+}
+template <class C>
+static int bench_madd(const char* name, uint32_t* out, int blocks, int threads) {
+  constexpr int FN = C::FqP::N, AW = 2 * FN;
+  const size_t lanes = (size_t)blocks * threads;
+  std::vector<uint32_t> h(AW * 64);
+  pc::AffD<C> g; for (int i = 0; i < FN; i++) { g.x.l[i] = C::GX[i]; g.y.l[i] = C::GY[i]; }
+  pc::XyzzD<C> acc = pc::XyzzD<C>::from_affine(g);
+  for (int i = 0; i < 64; i++) { pc::AffD<C> a = acc.to_affine(); a.store(&h[i * AW]); acc.add_affine(g); }
+  uint32_t* dp; CHECK(hipMalloc(&dp, h.size() * 4)); CHECK(hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  const int it = FN > 8 ? 64 : 128;
+  float ms = timeit([&]() { hipLaunchKernelGGL(k_madd<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+  printf("XYZZ madd %-12s         %8.3f ms  %8.2f M madd/s\n", name, ms, (double)lanes * it / ms * 1e-3);
+  std::vector<uint32_t> ref(lanes), got(lanes);
+  CHECK(hipMemcpy(ref.data(), out, lanes * 4, hipMemcpyDeviceToHost));
+  ms = timeit([&]() { hipLaunchKernelGGL(k_madd_2waves<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+  printf("  same, 2 waves per SIMD     %8.3f ms  %8.2f M madd/s\n", ms, (double)lanes * it / ms * 1e-3);
+  if constexpr (pc::Fd<typename C::FqP>::LAZY_OK) {
+    ms = timeit([&]() { hipLaunchKernelGGL(k_madd_lazy<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    CHECK(hipMemcpy(got.data(), out, lanes * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; for (size_t i = 0; i < lanes; i++) bad += got[i] != ref[i];
+    printf("  lazily reduced %-12s %8.3f ms  %8.2f M madd/s   (differs from the canonical loop on %zu of %zu lanes)\n", name, ms,
+           (double)lanes * it / ms * 1e-3, bad, (size_t)lanes);
+  }
+  // the kernel's own addition (lazy where allowed) by occupancy
+  { float m2 = timeit([&]() { hipLaunchKernelGGL((k_madd_waves<C, 2>), dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    float m3 = timeit([&]() { hipLaunchKernelGGL((k_madd_waves<C, 3>), dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    float m4 = timeit([&]() { hipLaunchKernelGGL((k_madd_waves<C, 4>), dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    printf("  kernel form %-12s at 2 / 3 / 4 waves per SIMD: %8.2f / %8.2f / %8.2f M madd/s\n", name,
+           (double)lanes * it / m2 * 1e-3, (double)lanes * it / m3 * 1e-3, (double)lanes * it / m4 * 1e-3); }
+  CHECK(hipFree(dp));
+  return 0;
 }
 
 int main() {
@@ -150,6 +199,8 @@ int main() {
     printf("fmul bls12_381_fq (12 limbs) %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
     ms = timeit([&]() { hipLaunchKernelGGL(k_fmul<pc_bn254_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
     printf("fmul bn254_fq (8 limbs)      %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
+    ms = timeit([&]() { hipLaunchKernelGGL(k_fmul<pc_pallas_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
+    printf("fmul pallas_fq (8 limbs)     %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
     for (int rep = 0; rep < 2; rep++) {
       ms = rep == 0 ? timeit([&]() { hipLaunchKernelGGL(k_fsqr<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); })
                     : timeit([&]() { hipLaunchKernelGGL(k_fsqr<pc_bn254_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
@@ -167,27 +218,8 @@ int main() {
     ms = timeit([&]() { hipLaunchKernelGGL(k_fadd<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it * 8); });
     printf("fadd+fsub bls12_381_fq       %8.3f ms  %8.2f G addsub/s\n", ms, (double)lanes * it * 8 * 2 / ms * 1e-6);
   }
-  {
-    // a few points on the curve: (i+1)G is not needed for timing; use the generator only plus doubles
-    typedef pc_curve_bls12_381 C;
-    constexpr int AW = 24;
-    std::vector<uint32_t> h(AW * 64);
-    pc::AffD<C> g; for (int i = 0; i < 12; i++) { g.x.l[i] = C::GX[i]; g.y.l[i] = C::GY[i]; }
-    pc::XyzzD<C> acc = pc::XyzzD<C>::from_affine(g);
-    for (int i = 0; i < 64; i++) { pc::AffD<C> a = acc.to_affine(); a.store(&h[i * AW]); acc.add_affine(g); }
-    uint32_t* dp; CHECK(hipMalloc(&dp, h.size() * 4)); CHECK(hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    const int it = 64;
-    float ms = timeit([&]() { hipLaunchKernelGGL(k_madd<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
-    printf("XYZZ madd bls12_381          %8.3f ms  %8.2f M madd/s\n", ms, (double)lanes * it / ms * 1e-3);
-    std::vector<uint32_t> ref(lanes), got(lanes);
-    CHECK(hipMemcpy(ref.data(), out, lanes * 4, hipMemcpyDeviceToHost));
-    ms = timeit([&]() { hipLaunchKernelGGL(k_madd_2waves<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
-    printf("  same, 2 waves per SIMD     %8.3f ms  %8.2f M madd/s\n", ms, (double)lanes * it / ms * 1e-3);
-    ms = timeit([&]() { hipLaunchKernelGGL(k_madd_lazy<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
-    CHECK(hipMemcpy(got.data(), out, lanes * 4, hipMemcpyDeviceToHost));
-    size_t bad = 0; for (size_t i = 0; i < lanes; i++) bad += got[i] != ref[i];
-    printf("  lazily reduced (no cond. subtraction) %8.3f ms  %8.2f M madd/s   (differs from the canonical loop on %zu of %zu lanes)\n", ms,
-           (double)lanes * it / ms * 1e-3, bad, (size_t)lanes);
-  }
+  if (bench_madd<pc_curve_bls12_381>("bls12_381", out, blocks, threads)) return 1;
+  if (bench_madd<pc_curve_bn254>("bn254", out, blocks, threads)) return 1;
+  if (bench_madd<pc_curve_pallas>("pallas", out, blocks, threads)) return 1;
   return 0;
 }
