@@ -237,11 +237,14 @@ def oracle_scalar_mul(curve, g_xy, k):
 def pmc_traffic(key, field="accumulate_hbm_bytes_per_launch"):
     """HBM bytes per launch from the committed PMC summary (profiles/r03_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 note of
     MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of the same workload -- NOT a measurement of this run)."""
-    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    try:
-        return json.load(open(f)).get(field, {}).get(key)
-    except Exception:
-        return None
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        try:
+            v = json.load(open(os.path.join(ROOT, "profiles", name))).get(field, {}).get(key)
+            if v is not None:
+                return v
+        except Exception:
+            pass
+    return None
 
 
 def union_ms(intervals):
@@ -255,31 +258,54 @@ def union_ms(intervals):
     return tot
 
 
-_MADD_PEAK = {}
+_MADD_PEAK = None
+_MADD_COMMITTED = {"bls12_381": 6.56e9, "bn254": 14.0e9, "pallas": 15.85e9}      # profiles/r04_microbench.txt
 
 
 def madd_peak(curve):
-    """Mixed additions per second of a pure-arithmetic loop (no memory traffic) of the same XYZZ += affine addition
-    the accumulate kernel runs: tools/microbench measured live on this GPU (rank 0, once), else the committed figure."""
-    if curve != "bls12_381":
-        return None
-    if curve in _MADD_PEAK:
-        return _MADD_PEAK[curve]
-    res = None
-    exe = os.path.join(ROOT, "tools", "microbench")
-    if os.path.exists(exe):
-        try:
-            import subprocess
-            txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
-            for line in txt.splitlines():
-                if line.startswith("XYZZ madd bls12_381"):
-                    res = {"madd_per_s": float(line.split()[-3]) * 1e6, "source": "tools/microbench, this run"}
-        except Exception:
-            res = None
-    if res is None:
-        res = {"madd_per_s": 5.726e9, "source": "profiles/r02_microbench.txt"}
-    _MADD_PEAK[curve] = res
-    return res
+    """Mixed additions per second of a pure-arithmetic loop (no memory traffic) of the same XYZZ += affine addition the accumulate
+    kernel runs for this curve (lazily reduced where the field allows it): tools/microbench measured live on this GPU (rank 0,
+    once: its 'kernel form <curve> at 2 / 3 / 4 waves per SIMD' line, best of the three), else the committed figure."""
+    global _MADD_PEAK
+    if _MADD_PEAK is None:
+        _MADD_PEAK = {}
+        exe = os.path.join(ROOT, "tools", "microbench")
+        if os.path.exists(exe):
+            try:
+                import subprocess
+                txt = subprocess.run([exe], capture_output=True, text=True, timeout=180).stdout
+                for line in txt.splitlines():
+                    t = line.split()
+                    if line.strip().startswith("kernel form") and "M madd/s" in line:
+                        nums = [float(x) for x in t if x.replace(".", "", 1).isdigit() and "." in x]
+                        if nums:
+                            _MADD_PEAK[t[2]] = {"madd_per_s": max(nums) * 1e6, "source": "tools/microbench, this run"}
+            except Exception:
+                pass
+    if curve not in _MADD_PEAK:
+        _MADD_PEAK[curve] = {"madd_per_s": _MADD_COMMITTED[curve], "source": "profiles/r04_microbench.txt"}
+    return _MADD_PEAK[curve]
+
+
+def msm_roofline(curve, pairs_per_launch, digits, kernel_ms, launches, kernel, traffic_key=None, extra=None):
+    """The prescribed HBM roofline of one accumulate launch (128 / 96 algorithmic bytes per pair) and, beside it, the
+    bound that actually holds (VALU: mixed additions per second against a memory-free loop of the same addition)."""
+    bytes_per_launch = pairs_per_launch * PAIR_BYTES[curve]
+    ach = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
+    pk = madd_peak(curve)
+    adds = pairs_per_launch * digits
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS if ach else None,
+         "traffic": pmc_traffic(traffic_key) if traffic_key else None,
+         "traffic_source": "profiles/r04_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE doubled per "
+                           "the guide's gfx950 note; not measured in this run)",
+         "kernel": kernel, "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+         "arithmetic": {"bound": "valu", "unit": "mixed additions/s (XYZZ += affine, 8M + 2S in Fq)",
+                        "achieved": adds / (kernel_ms * 1e-3) if kernel_ms else None, "peak": pk["madd_per_s"],
+                        "frac": adds / (kernel_ms * 1e-3) / pk["madd_per_s"] if kernel_ms else None, "peak_source": pk["source"],
+                        "additions_per_launch": adds, "digits_per_scalar": digits}}
+    if extra:
+        r.update(extra)
+    return r
 
 
 def cpu_baseline(curve, srs, log_d, budget_s=30.0):
@@ -526,14 +552,12 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
     trait = None
     if world == 1:
         hostc = host_u64(host if host is not None else coeffs)
-        qdev = torch.empty((n, 4), dtype=torch.int64, device="cuda")
         zm = mont_limbs(curve, S.z)
         reps = 3 if log_degree >= 22 else 10
 
         def trait_step():
             c, _ = eng.srs.msm(hostc, n=n, base_offset=1, montgomery=True)
-            ctx.witness_poly(curve, hostc, zm, out=qdev.data_ptr(), n=n)
-            w, _ = eng.srs.msm(qdev, n=n - 1, base_offset=1, montgomery=True)
+            w, _ = eng.srs.kzg_open(hostc, zm, n=n, base_offset=1)
             return c, w
         c, w = trait_step()
         torch.cuda.synchronize()
@@ -552,8 +576,7 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
         def cached_step():
             ctx.memcpy_h2d(pbuf, hostc[:n])
             c, _ = eng.srs.msm(pbuf, n=n, base_offset=1, montgomery=True)
-            ctx.witness_poly(curve, pbuf, zm, out=qdev.data_ptr(), n=n)
-            w, _ = eng.srs.msm(qdev, n=n - 1, base_offset=1, montgomery=True)
+            w, _ = eng.srs.kzg_open(pbuf, zm, n=n, base_offset=1)
             return c, w
         c2, w2 = cached_step()
         t0 = time.perf_counter()
@@ -565,10 +588,11 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
                  "with_shim_polynomial_cache_ms": dt_s * 1e3, "with_shim_polynomial_cache_parity_ok": bool((c2 == want_c).all() and (w2 == want_w).all()),
                  "commit_open_per_s": 1.0 / dt_t, "value": (2 * n - 1) / dt_t, "unit": "pairs/s",
                  "parity_ok": bool((c == want_c).all() and (w == want_w).all()),
-                 "note": "blocking pc_hip_msm with PC_MEM_HOST coefficients (pageable numpy memory, one H2D inside the call), "
-                         "then pc_hip_witness_poly host -> device + blocking pc_hip_msm: the call sequence of the trait's "
-                         "commit(&poly) / open(&poly) with nothing cached between them"}
-        del qdev
+                 "note": "blocking pc_hip_msm with PC_MEM_HOST coefficients (pageable numpy memory, the H2D inside the call), then "
+                         "pc_hip_kzg_open with the same host coefficients (copy + witness division + MSM in one call): the call "
+                         "sequence of the trait's commit(&poly) / open(&poly) with nothing cached between them; from 2^23 "
+                         "coefficients on both calls run as two halves on two pipelines, the second half's PCIe copy under the "
+                         "first half's MSM"}
 
     # The kernels without a second pipeline competing for the CUs: strictly serial MSMs after the timed region.
     eng.blocking = False
@@ -666,12 +690,10 @@ def latency_sweep(ctx, curve, logs, cpu_max_log):
         tbl_ms = (time.perf_counter() - t0) * 1e3
         co = rand_fr_device(0x5EED1000 + lg, n)
         hostc = host_u64(co)
-        qdev = torch.empty((n, 4), dtype=torch.int64, device="cuda")
 
         def gpu_step():
             c, _ = srs.msm(hostc, n=n, montgomery=True)
-            ctx.witness_poly(curve, hostc, zm, out=qdev.data_ptr(), n=n)
-            w, _ = srs.msm(qdev, n=n - 1, montgomery=True)
+            w, _ = srs.kzg_open(hostc, zm, n=n)
             return c, w
         for _ in range(3):
             c, w = gpu_step()
@@ -707,7 +729,7 @@ def latency_sweep(ctx, curve, logs, cpu_max_log):
                 crossover = lg
         rows[f"2^{lg}"] = row
         srs.free()
-        del co, qdev
+        del co
     del pts
     torch.cuda.empty_cache()
     return {"curve": curve, "rows": rows,
@@ -770,6 +792,22 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
             lo_r, _ = sharded.ShardedBatch.chunk_range(total, r, world)
             pb = (pb + pow(beta, lo_r, p) * from_mont_limbs(curve, allv[r, j])) % p
         ok = ok and bool((out[j] == oracle_scalar_mul(curve, g, pb)).all())
+    # the accumulate launches of ONE more step, by hipEvent brackets on the two pass pipelines (pc_hip_last_msm_phases_ms after a batch:
+    # sums over the passes, the union of their accumulate intervals, the pass count)
+    ctx.set_timing(True)
+    job.commit_batch(vec, lens)
+    ph = ctx.last_msm_phases_ms()
+    shape = ctx.last_msm_shape()
+    passes = int(round(ph[7])) if ph[7] > 0 else 0
+    roof = None
+    if passes and rank == 0:
+        roof = msm_roofline(curve, polys * n / passes, shape["digits_per_scalar"], ph[6] / passes, passes,
+                            "pc::k_accumulate<bn254> (bucket accumulation of one many-MSM pass: 8 polynomials, one bucket set each)",
+                            traffic_key=f"bn254:batch{polys}x2^{log_degree}:table" if world == 1 else None,
+                            extra={"kernel_ms_definition": "union of the [start, end] hipEvent intervals of the passes' accumulate launches / passes (the passes of the two "
+                                                           "pipelines overlap with each other's sort and reductions)",
+                                   "bracket_ms_mean": ph[3] / passes, "window_bits": shape["window_bits"], "buckets_per_polynomial": shape["buckets"] // max(1, min(8, polys)),
+                                   "pass_phase_ms_sum": {k: float(v) for k, v in zip(["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], ph[:6])}})
     eng.srs.free()
     del vec
     torch.cuda.empty_cache()
@@ -777,7 +815,7 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
     return {"workload": f"{polys} x MarlinKZG10<Bn254> commit, deg 2^{log_degree}, one SRS in {world} contiguous chunk(s) (BASELINE configs[2])",
             "value": pairs * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "ms_per_commitment": dt / steps * 1e3 / polys, "per_rank_ms_per_step": [float(x) / steps * 1e3 for x in per_rank],
-            "srs_window_table_build_ms": eng.precompute_ms,
+            "srs_window_table_build_ms": eng.precompute_ms, "roofline": roof,
             "parity": {"all_commitments_closed_form_ok": bool(ok), "oracle_horner_checked": len(pick), "oracle_horner_ok": bool(ok_eval),
                        "method": "every C_j == p_j(beta) g on the true SRS (p_j(beta) from the device's evaluation kernel, "
                                  f"{len(pick)} of them re-evaluated by the oracle's Horner; scalar multiplication by the oracle)"}}
@@ -819,6 +857,7 @@ def ipa_case(ctx, log_n, reps):
     for _ in range(reps):
         comm, _ = srs.msm(cdev.data_ptr(), n=n, montgomery=True)
     t_commit = (time.perf_counter() - t0) / reps
+    ph_c, shape_c = ctx.last_msm_phases_ms(), ctx.last_msm_shape()
     best, tm_best, proof = None, None, None
     for _ in range(reps):
         it = iter(range(log_n))
@@ -847,6 +886,12 @@ def ipa_case(ctx, log_n, reps):
     return {"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: cm_commit MSM + open's {log_n} halving rounds (BASELINE configs[3])",
             "commit_ms": t_commit * 1e3, "open_ms": best * 1e3, "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / best,
             "open_breakdown_ms": {k: round(v, 2) for k, v in tm_best.items()}, "per_round_ms": [round(x, 2) for x in per_round],
+            "roofline": msm_roofline(curve, n, shape_c["digits_per_scalar"], float(ph_c[3]), 1,
+                                     "pc::k_accumulate<pallas> (bucket accumulation of the cm_commit MSM; the opening's 2 x 22 round MSMs run the same kernel "
+                                     "on n/2 .. 1 pairs)", traffic_key=f"pallas:2^{log_n}:table",
+                                     extra={"kernel_ms_definition": "hipEvent bracket of the accumulate launch of the last blocking commit MSM",
+                                            "commit_msm_phase_ms": {k: float(v) for k, v in zip(["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], ph_c[:6])},
+                                            "window_bits": shape_c["window_bits"], "buckets": shape_c["buckets"]}),
             "key_gen_ms": key_gen_ms, "key_tables_build_ms": key_tables_ms,
             "key_tables_note": "window table + fold table (131 x n/2 points) of the committer key, built once per key outside the timing",
             "parity": {"commit_ok": ok_commit, "final_comm_key_ok": ok_key,
@@ -1129,7 +1174,7 @@ def main():
                   "dtype": "u32 limbs (254-bit modular integer)", "data": "synthetic", "dist": D.info(),
                   "config": {"workload": r["workload"], "polys_per_s": args.polys / (r["ms_per_step"] * 1e-3),
                              "parallelism": "1 GPU" if world == 1 else f"SRS sharded over {world} GPUs, all_gather of {args.polys} partial points"},
-                  **{k: r[k] for k in ("per_rank_ms_per_step", "ms_per_commitment", "srs_window_table_build_ms", "parity")}})
+                  **{k: r[k] for k in ("per_rank_ms_per_step", "ms_per_commitment", "srs_window_table_build_ms", "roofline", "parity")}})
         ok = r["parity"]["all_commitments_closed_form_ok"] and r["parity"]["oracle_horner_ok"]
         D.close()
         if not ok:

@@ -131,7 +131,9 @@ int pc_hip_job_wait(pc_ctx* ctx, pc_job* job);
 int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
 
 /* Kernel-only timing of the last MSM issued on this ctx, in milliseconds, by phase
- * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py. */
+ * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py.
+ * After pc_hip_msm_batch over a window table (many-MSM passes): [0..5] summed over the passes, [6] the union of the passes'
+ * accumulate intervals (passes overlap on two pipelines), [7] the number of passes. */
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
 /* The same phase boundaries of the last completed MSM as offsets (ms) from the moment pc_hip_set_timing(ctx, 1) was last
  * called: out[0] = the call was queued, out[1..6] = end of digits+hist, scan, scatter, accumulate, seg-reduce,
@@ -258,6 +260,13 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
  * host); out: n-1 Fr.  Keeps the quotient in HBM between commit and open. */
 int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_mem where_in, size_t n,
                         const void* z_host, void* out, pc_mem where_out);
+/* KZG10::open without hiding as ONE call (poly-commit/src/kzg10/mod.rs:287-310 = compute_witness_polynomial :217-240 +
+ * the MSM of open_with_witness_polynomial :255-258):  out = sum_j q[j] * bases[base_offset + j],  q = p / (x - z), n - 1 pairs.
+ * coeffs: n Fr (Montgomery), host or device; the quotient never leaves the device.  Large HOST polynomials are processed as
+ * two halves so that the second half's PCIe copy runs under the first half's MSM (see pc_hip_msm: the same split).  The
+ * reference's degree checks (kzg10/mod.rs:393-407) stay with the caller; n - 1 > srs length - base_offset is PC_ERR_INVALID_ARG. */
+int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* coeffs, pc_mem where, size_t n,
+                    const void* z_host, void* out_xy, int* out_is_infinity);
 /* p(z) for n coefficients (Montgomery; z and the result on the host): Polynomial::evaluate, which
  * KZG10::open applies to the blinding polynomial (poly-commit/src/kzg10/mod.rs:276) and every
  * caller to the opened polynomial; for a polynomial sharded over GPUs it is the value each shard

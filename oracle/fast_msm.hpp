@@ -187,6 +187,12 @@ static Jac<C> msm(const uint64_t* bases, const uint64_t* scalars, size_t n, int 
   if (n == 0) return Jac<C>::infinity();
   const int bits = C::FrP::BITS;
   if (threads < 1) threads = 1;
+  {   // a thread is worth starting for ~2^11 bucket operations (~1 ms); small MSMs stay on few threads
+    const int c0 = choose_c(n, bits, 1);
+    const size_t ops = n * (size_t)(bits / c0 + 1);
+    const size_t worth = ops / ((size_t)1 << 11) + 1;
+    if ((size_t)threads > worth) threads = (int)worth;
+  }
   // tasks: W windows x `chunks` slices of the pairs, about three per thread
   int c = choose_c(n, bits, 1);
   size_t chunks = 1;

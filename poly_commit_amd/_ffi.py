@@ -83,6 +83,7 @@ def load_library():
     lib.pc_hip_ntt_batch.argtypes = [vp, ip, vp, ip, sz, sz, C.c_uint, vp, ip]
     lib.pc_hip_last_ntt_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_witness_poly.argtypes = [vp, ip, vp, ip, sz, vp, vp, ip]
+    lib.pc_hip_kzg_open.argtypes = [vp, vp, sz, vp, ip, sz, vp, vp, C.POINTER(C.c_int)]
     lib.pc_hip_column_hash.argtypes = [vp, ip, vp, ip, sz, sz, ip, vp, ip]
     lib.pc_hip_column_hash_part.argtypes = [vp, ip, ip, vp, sz, sz, sz, sz, sz, ip, ip, vp, vp]
     lib.pc_hip_merkle_tree.argtypes = [vp, ip, vp, ip, sz, ip, vp, ip]
@@ -429,6 +430,19 @@ class Srs:
         self.ctx.check(self.ctx.lib.pc_hip_msm(self.ctx.h, self.h, base_offset, p,
                                                PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
                                                where, n, C.c_void_p(out.ctypes.data), C.byref(inf)))
+        return out, bool(inf.value)
+
+    def kzg_open(self, coeffs, z, n=None, base_offset=0):
+        """KZG10::open without hiding as one call (pc_hip_kzg_open): W = MSM(bases[base_offset ..], p / (x - z)); coeffs: (n, 4)
+        uint64 host array (Montgomery) or a device pointer with n.  Returns (xy uint64 array, is_infinity)."""
+        p, where = _ptr(coeffs)
+        if n is None:
+            n = coeffs.shape[0]
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros(2 * FQ_BYTES[self.curve] // 8, dtype=np.uint64)
+        inf = C.c_int(0)
+        self.ctx.check(self.ctx.lib.pc_hip_kzg_open(self.ctx.h, self.h, base_offset, p, where, n, C.c_void_p(z.ctypes.data),
+                                                    C.c_void_p(out.ctypes.data), C.byref(inf)))
         return out, bool(inf.value)
 
     def msm_many(self, scalars, m=None, n_msms=None, base_offset=0, montgomery=False):

@@ -428,12 +428,50 @@ int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t
 size_t pc_hip_srs_len(const pc_srs* srs) { return srs ? srs->n : 0; }
 void* pc_hip_srs_device_ptr(const pc_srs* srs) { return srs ? srs->bases : nullptr; }
 
+// Scalars that arrive in HOST memory are copied inside the call (the trait hands over &[F]: 512 MB at degree 2^24, ~9 ms of PCIe).
+// Every step of one MSM needs all of its scalars, so nothing of that MSM can hide the copy -- but the MSM is a sum: from
+// host_split_min() pairs on, the call runs as TWO half-size MSMs on two pipelines, the second half's copy under the first half's
+// sort and accumulation, and adds the two points on the host (the fold of per-GPU partial results, pc_hip_points_sum).
+// a job on this call's stack must not outlive it inside a pipeline (an exception between two enqueues would leave the lane with a
+// dangling pointer): completed on scope exit if it still is in flight
+struct StackJob {
+  pc_ctx* ctx; pc_job job;
+  explicit StackJob(pc_ctx* c) : ctx(c) {}
+  ~StackJob() { if (job.srs && !job.done) { try { complete_job(ctx, &job); } catch (...) {} } }
+};
+static size_t host_split_min() {
+  static const size_t v = []() { const char* e = getenv("PC_HIP_HOST_SPLIT_LOG2"); int lg = e ? atoi(e) : 23; return lg <= 0 ? (size_t)-1 : (size_t)1 << (lg > 40 ? 40 : lg); }();
+  return v;
+}
+// sum of two affine results into out_xy / out_is_infinity
+static void fold_two(pc_srs* srs, const uint32_t* a, const uint32_t* b, void* out_xy, int* out_is_infinity) {
+  std::vector<uint32_t> two(2 * (size_t)srs->aw);
+  memcpy(two.data(), a, (size_t)srs->aw * 4); memcpy(two.data() + srs->aw, b, (size_t)srs->aw * 4);
+  pc::curve_ops(srs->curve).points_sum(two.data(), 2, (uint32_t*)out_xy);
+  if (out_is_infinity) { uint32_t acc = 0; for (int i = 0; i < srs->aw; i++) acc |= ((const uint32_t*)out_xy)[i]; *out_is_infinity = acc == 0; }
+}
+
 int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void* scalars, pc_scalar_form form,
                pc_mem where, size_t n, void* out_xy, int* out_is_infinity) {
   pc_srs* srs = const_cast<pc_srs*>(srs_c);
   if (!ctx || !srs || !out_xy || srs->ctx != ctx) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
+    const size_t avail = base_offset <= srs->n ? srs->n - base_offset : 0;
+    const size_t ne = n < avail ? n : avail;
+    if (where == PC_MEM_HOST && scalars && ne >= host_split_min() && base_offset <= srs->n) {
+      const size_t h = ne / 2;
+      std::vector<uint32_t> r1(srs->aw), r2(srs->aw);
+      StackJob j1(ctx), j2(ctx);
+      int rc = enqueue_job(ctx, srs, base_offset, scalars, form, where, h, r1.data(), nullptr, &j1.job, true);
+      if (rc != PC_OK) return rc;
+      rc = enqueue_job(ctx, srs, base_offset + h, (const uint8_t*)scalars + h * 32, form, where, ne - h, r2.data(), nullptr, &j2.job, true);
+      if (rc != PC_OK) return rc;
+      if (!j1.job.done) complete_job(ctx, &j1.job);
+      if (!j2.job.done) complete_job(ctx, &j2.job);
+      fold_two(srs, r1.data(), r2.data(), out_xy, out_is_infinity);
+      return (int)PC_OK;
+    }
     pc_job job;
     int rc = enqueue_job(ctx, srs, base_offset, scalars, form, where, n, out_xy, out_is_infinity, &job, false);
     if (rc != PC_OK) return rc;
@@ -514,9 +552,18 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
           const size_t pb = (size_t)srs->aw * 4;
           std::vector<uint32_t> tmp[2]; tmp[0].resize(G * srs->aw); tmp[1].resize(G * srs->aw);
           size_t pending_first[2] = {0, 0}, pending_cnt[2] = {0, 0};
+          // phase brackets of the passes (pc_hip_last_msm_phases_ms after a batch): [0..5] summed over the passes, [6] the union of
+          // the passes' accumulate intervals (consecutive passes overlap on the two pipelines), [7] the number of passes
+          float ph_sum[8] = {0}; std::vector<std::pair<float, float>> acc_iv;
           auto drain = [&](int li) {
             if (!pending_cnt[li]) return;
             B.lanes[li]->runner->finish(tmp[li].data());
+            pc::HipBackend& lbe = B.lanes[li]->be;
+            if (lbe.timing && lbe.n_ev >= 5) {
+              for (int i = 0; i + 1 < lbe.n_ev && i < 6; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, lbe.ev[i], lbe.ev[i + 1]); ph_sum[i] += ms; }
+              if (ctx->epoch) { float a = 0, b = 0; (void)hipEventElapsedTime(&a, ctx->epoch, lbe.ev[3]); (void)hipEventElapsedTime(&b, ctx->epoch, lbe.ev[4]); acc_iv.push_back({a, b}); }
+              ph_sum[7] += 1.0f;
+            }
             for (size_t k = 0; k < pending_cnt[li]; k++) {
               uint8_t* o = (uint8_t*)out_xy + (pending_first[li] + k) * pb;
               memcpy(o, tmp[li].data() + k * srs->aw, pb);
@@ -535,6 +582,14 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
             pending_first[li] = first; pending_cnt[li] = cnt;
           }
           drain(li); drain(li ^ 1);
+          if (ctx->be.timing) {
+            std::sort(acc_iv.begin(), acc_iv.end());
+            float tot = 0, end = -1e30f;
+            for (auto& iv : acc_iv) { if (iv.second <= end) continue; tot += iv.second - std::max(iv.first, end); end = iv.second; }
+            ph_sum[6] = tot;
+            for (int i = 0; i < 8; i++) ctx->phases[i] = ph_sum[i];
+            B.lanes[0]->runner->shape(ctx->shape);
+          }
           return (int)PC_OK;
         }
       }
@@ -784,6 +839,54 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
     const uint32_t* z = (const uint32_t*)z_host;
     pc::field_ops(field_of).witness(ctx->be, (const uint32_t*)sin.dev, n, z, (uint32_t*)sout.dev, scan_fan());
     if (where_out == PC_MEM_HOST) ctx->be.copy_d2h(out, sout.dev, (n - 1) * 32);
+    return (int)PC_OK;
+  });
+}
+
+// KZG10::open without hiding (poly-commit/src/kzg10/mod.rs:287-310: compute_witness_polynomial :217-240, then
+// open_with_witness_polynomial's MSM :255-258) as ONE call: W = sum_j q[j] * powers[base_offset + j], q = p / (x - z).
+// The quotient never leaves the device.  Host coefficients of at least host_split_min() elements run as two halves, top half
+// first (its quotient needs nothing from below): copy + division + MSM of the top half, the bottom half's copy under that MSM,
+// its division with the carry q[h], its MSM on a second pipeline, and the two points added.
+int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void* coeffs, pc_mem where, size_t n, const void* z_host,
+                    void* out_xy, int* out_is_infinity) {
+  pc_srs* srs = const_cast<pc_srs*>(srs_c);
+  if (!ctx || !srs || srs->ctx != ctx || !out_xy || !z_host || (n && !coeffs)) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 32)) return PC_ERR_TOO_LARGE;
+  if (base_offset > srs->n || (n > 1 && n - 1 > srs->n - base_offset)) return PC_ERR_INVALID_ARG;     // the reference checks the degree before (kzg10/mod.rs:393-407)
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    if (n <= 1) { memset(out_xy, 0, (size_t)srs->aw * 4); if (out_is_infinity) *out_is_infinity = 1; return (int)PC_OK; }
+    const pc::FieldOps& F = pc::field_ops(srs->curve);
+    const uint32_t* z = (const uint32_t*)z_host;
+    const size_t m = n - 1;                                       // quotient length; x[j] = p[j + 1]
+    uint32_t* q = (uint32_t*)ctx->be.stage(1, m * 32);
+    if (where == PC_MEM_DEVICE || m < host_split_min()) {
+      Staged sin(ctx->be, coeffs, where, n * 32, true, 0);
+      F.witness(ctx->be, (const uint32_t*)sin.dev, n, z, q, scan_fan());
+      pc_job job;
+      int rc = enqueue_job(ctx, srs, base_offset, q, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, m, out_xy, out_is_infinity, &job, false);
+      if (rc != PC_OK) return rc;
+      complete_job(ctx, &job);
+      return (int)PC_OK;
+    }
+    uint32_t* x = (uint32_t*)ctx->be.stage(0, m * 32);
+    const uint8_t* src = (const uint8_t*)coeffs + 32;
+    const size_t h = m / 2;
+    std::vector<uint32_t> r1(srs->aw), r2(srs->aw), carry(8);
+    StackJob j1(ctx), j2(ctx);
+    ctx->be.copy_h2d(x + h * 8, src + h * 32, (m - h) * 32);
+    F.div_scan(ctx->be, x + h * 8, m - h, z, nullptr, q + h * 8, scan_fan());          // (returns with the stream drained)
+    int rc = enqueue_job(ctx, srs, base_offset + h, q + h * 8, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, m - h, r1.data(), nullptr, &j1.job, true);
+    if (rc != PC_OK) return rc;
+    ctx->be.copy_h2d(x, src, h * 32);
+    ctx->be.copy_d2h(carry.data(), q + h * 8, 32);
+    F.div_scan(ctx->be, x, h, z, carry.data(), q, scan_fan());
+    rc = enqueue_job(ctx, srs, base_offset, q, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, h, r2.data(), nullptr, &j2.job, true);
+    if (rc != PC_OK) return rc;
+    if (!j1.job.done) complete_job(ctx, &j1.job);
+    if (!j2.job.done) complete_job(ctx, &j2.job);
+    fold_two(srs, r1.data(), r2.data(), out_xy, out_is_infinity);
     return (int)PC_OK;
   });
 }

@@ -53,8 +53,10 @@
     for (int pc_i_ = 0; pc_i_ < PC_N_; pc_i_ += 4) asm volatile("" ::"v"((PT).x.l[pc_i_]), "v"((PT).y.l[pc_i_]));     \
     asm volatile("" ::"v"(IDX));                                                                                        \
   } while (0)
+#define PC_ARRIVED_WORD(W) asm volatile("" ::"v"(W))
 #else
 #define PC_ARRIVED(PT, IDX) ((void)0)
+#define PC_ARRIVED_WORD(W) ((void)0)
 #endif
 
 namespace pc {
@@ -252,34 +254,41 @@ struct AccumulateBody {
       // the run of bucket k is [run_lo, boundary); `next_boundary` = offsets[k + 2] is fetched one bucket
       // ahead so that a boundary costs no dependent load (it is hit on nearly every iteration by some lane)
       uint32_t run_lo = offsets[k], boundary = offsets[k + 1];
-      uint32_t next_boundary = (k + 2 <= g.NB) ? offsets[k + 2] : 0xffffffffu;
+      uint32_t next_boundary = offsets[k + 2 <= g.NB ? k + 2 : g.NB];
       Pt acc = Pt::infinity();
       bool first = true;
       uint32_t val = entries[s];
       uint32_t nval = (s + 1 < e) ? entries[s + 1] : val;
       AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * g.pt_stride);
       for (uint32_t p = s; p < e; p++) {
-        // Everything in flight here (the base and the index gathered during the previous addition) has had a whole addition
-        // to arrive: wait for it NOW, before the boundary block below issues its bucket stores and `offsets` loads.  The
-        // memory counter is in order, so the compiler's own wait -- at the first use of `pt`, behind that block -- became
-        // vmcnt(0) over the just-issued stores: every wave sat out a store round trip on the ~50 % of iterations in which
-        // one of its lanes crosses a bucket boundary (13 % of the wave cycles waiting in the SQ counters).
+        // Everything in flight here (the base, the index and the bucket offset gathered during the previous addition) has had a
+        // whole addition to arrive: wait for it NOW, before the boundary block below issues its bucket stores.  The memory counter is
+        // in order, so the compiler's own wait -- at the first use of `pt`, behind that block -- became vmcnt(0) over the just-issued
+        // stores: every wave sat out a store round trip on the iterations in which one of its lanes crosses a bucket boundary.
         PC_ARRIVED(pt, nval);
-        // Bucket boundary first: its loads of `offsets` must not sit behind this iteration's gathers
-        // (waiting for the youngest load waits for all older ones: that stalled every wave on the
-        // HBM latency of the prefetch it had just issued, on nearly every iteration).
+        PC_ARRIVED_WORD(next_boundary);
+        // Bucket boundary.  NOTHING in this block may wait on memory: some lane of a wave crosses a boundary in 50 % (96 entries per
+        // bucket) to 90 % (26) of the iterations.  Until round 4 the look-ahead offsets[k + 2] was loaded HERE -- the compiler
+        // copied the loaded value into the loop-carried register at the end of the block, i.e. waited for it, and (in-order counter)
+        // for the bucket stores issued just before: a full memory round trip per boundary iteration, ~3 us of a 13 us (254-bit) or
+        // 22 us (381-bit) iteration -- the 24 % / 12 % of wave cycles in s_waitcnt that the SQ counters showed.  The look-ahead now
+        // rides in the prefetch group below (one more 4-byte load per iteration, nearly always the same cached line).
         if (p == boundary) {
           flush(store_form(acc), k, run_lo >= s, t, first, k0, k1);       // its end, p, is inside the chunk
           first = false; acc = Pt::infinity();
           k++; run_lo = p; boundary = next_boundary;
           while (boundary <= p) { k++; boundary = offsets[k + 1]; }      // empty buckets (rare): all start at p
-          next_boundary = (k + 2 <= g.NB) ? offsets[k + 2] : 0xffffffffu;
         }
-        // Software pipeline, issued right before the long addition: the base of entry p+1 (its index
-        // arrived an iteration ago) and the index of entry p+2.
-        uint32_t nnval = nval; AffD<C> npt = pt;
-        if (p + 1 < e) npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride);
-        if (p + 2 < e) nnval = entries[p + 2];
+        // Software pipeline, issued right before the long addition: the base of entry p+1 (its index arrived an iteration ago), the
+        // index of entry p+2 and the end of the NEXT bucket's run, offsets[k + 2] (clamped to offsets[NB] = M behind the last bucket:
+        // no position of the chunk reaches it)
+        // (all three UNCONDITIONAL, with clamped positions -- behind the chunk's end `nval` repeats a valid index: under `if (p + 1 < e)`
+        // the compiler gathered into scratch registers and assembled `npt` from them with copies, i.e. waited for the gather it had
+        // just issued -- s_waitcnt vmcnt(3) / vmcnt(2) right behind the four loads of the 8-limb kernels, a memory round trip in
+        // EVERY iteration)
+        const AffD<C> npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride);
+        const uint32_t nnval = entries[p + 2 < e ? p + 2 : e - 1];
+        next_boundary = offsets[k + 2 <= g.NB ? k + 2 : g.NB];
         if constexpr (LAZY) acc.add_affine_lz(pt, (val >> 31) != 0); else acc.add_affine(pt.neg_if(val >> 31));
         val = nval; nval = nnval; pt = npt;
       }
@@ -357,14 +366,15 @@ struct BucketLevelBody {
     const size_t stride = (size_t)cnt * Pt::WORDS;
     // (the next point is loaded while the current one is added: the lanes of a wave read K * 192 bytes apart, so every
     // load is a DRAM/L2 round trip of its own, and with one wave per SIMD nothing else hides it -- the SQ counters
-    // showed 47 % of this kernel's wave cycles in s_waitcnt)
+    // showed 47 % of this kernel's wave cycles in s_waitcnt.  Unconditional with a clamped index: guarded by `if (j > 0)` the
+    // compiler loaded into scratch registers and copied, waiting for part of the prefetch right behind its issue)
     if (a == 0) {
       const uint32_t* base = x + (size_t)gidx * K * Pt::WORDS;
       Pt run = Pt::infinity(), acc = Pt::infinity();
       Pt nxt = Pt::load(base + (size_t)(K - 1) * Pt::WORDS);
       for (uint32_t j = K; j-- > 0;) {
         const Pt cur = nxt;
-        if (j > 0) nxt = Pt::load(base + (size_t)(j - 1) * Pt::WORDS);
+        nxt = Pt::load(base + (size_t)(j > 0 ? j - 1 : 0) * Pt::WORDS);      // unconditional (clamped): see AccumulateBody::chunk
         run.add(cur);
         if (j + weight_off > 0) acc.add(run);
       }
@@ -376,7 +386,7 @@ struct BucketLevelBody {
       Pt nxt = Pt::load(base);
       for (uint32_t j = 0; j < K; j++) {
         const Pt cur = nxt;
-        if (j + 1 < K) nxt = Pt::load(base + (size_t)(j + 1) * Pt::WORDS);
+        nxt = Pt::load(base + (size_t)(j + 1 < K ? j + 1 : j) * Pt::WORDS);
         acc.add(cur);
       }
       acc.store(out + (size_t)(1 + a) * stride + (size_t)gidx * Pt::WORDS);

@@ -95,3 +95,46 @@ def test_two_ranks_started_by_torchrun_as_the_driver_does():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dist"]["world_size"] == 2
     assert d["parity"]["commit_ok"] and d["parity"]["open_ok"] and d["parity"]["commitments_checked"] == 3
+
+
+# ---- eight ranks: the driver's scaling run rehearsed on one device (no 8-GPU node has ever been available to a round) -------------
+EIGHT = {"PC_BENCH_DEVICES": ",".join(["0"] * 8)}
+
+
+def test_eight_ranks_started_by_torchrun_as_the_driver_does():
+    """The driver's N = 8 command line, all eight ranks on device 0 (gloo carries the collective: RCCL refuses ranks that share a
+    device): ONE polynomial of 8 x 2^13 coefficients over eight real chunks of one true SRS, every commitment / proof of the timed
+    region against the closed form of the WHOLE polynomial; the line carries what the N = 1 line carries."""
+    env = dict(os.environ, **EIGHT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29793", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--log-degree", "13", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "weak" and d["dist"]["world_size"] == 8
+    assert len(d["per_rank_ms_per_step"]) == 8 and all(x > 0 for x in d["per_rank_ms_per_step"])
+    assert d["config"]["pairs_per_step"] == 8 * 2 * (1 << 13) - 1
+    assert d["parity"]["commit_ok"] and d["parity"]["open_ok"] and d["parity"]["commitments_checked"] == 3 and d["parity"]["proofs_checked"] == 3
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] > 0 and rf["kernel_ms"] > 0 and rf["arithmetic"]["frac"] > 0
+    assert d["exchange_host_ms"]["calls"] >= 3
+    assert d.get("cpu_baseline") is None          # reported on rank 0 at N = 1 only (the bench contract)
+
+
+def test_eight_ranks_batch_and_rows():
+    d = run_bench(["--gpus", "8", "--workload", "batch", "--small", "--polys", "8", "--steps", "2"], EIGHT, timeout=1200)
+    assert d["n_gpus"] == 8 and d["dist"]["world_size"] == 8 and len(d["per_rank_ms_per_step"]) == 8
+    assert d["parity"]["all_commitments_closed_form_ok"] and d["parity"]["oracle_horner_ok"]
+    d = run_bench(["--gpus", "8", "--workload", "ntt", "--small", "--steps", "2"], EIGHT, timeout=1200)
+    assert d["n_gpus"] == 8 and d["parity"]["horner_spot_checks_ok"] and d["parity"]["one_row_vs_oracle_ntt_ok"]
+    assert d["sharded_commit"]["root_equal_on_all_ranks"] and d["sharded_commit"]["root_vs_host_rehash_ok"] is True
+    assert d["roofline"]["frac"] > 0
+
+
+def test_group_mode_eight_contexts():
+    d = run_bench(["--mode", "group", "--gpus", "8", "--log-degree", "12", "--steps", "3"], EIGHT, timeout=1200)
+    assert d["n_gpus"] == 8 and d["parity"]["all_steps_ok"] and d["parity"]["checked"] == 3

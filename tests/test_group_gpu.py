@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("curve,n,ndev,table", [("bls12_381", 5000, 3, False), ("bn254", 4097, 2, True), ("pallas", 1 << 12, 4, False),
-                                                ("bn254", 5, 3, False)])
+                                                ("bn254", 5, 3, False), ("bls12_381", (1 << 13) + 1, 8, True), ("bn254", 8 * 1000 + 3, 8, False)])
 def test_group_commit_open_matches_oracle(curve, n, ndev, table):
     import poly_commit_amd as pc
     g = pc.Group([0] * ndev)
@@ -92,7 +92,7 @@ def test_group_commit_open_async_jobs(curve, n, ndev, table):
     g.close()
 
 
-@pytest.mark.parametrize("ndev,rows", [(1, 7), (2, 8), (3, 7), (4, 16), (4, 3)])
+@pytest.mark.parametrize("ndev,rows", [(1, 7), (2, 8), (3, 7), (4, 16), (4, 3), (8, 32), (8, 19)])
 def test_group_ligero_commit_chained_digests(ndev, rows):
     """pc_hip_group_ligero_commit: rows encoded on different device contexts, column digests chained through them
     (pc_hip_column_hash_part), tree on the last -- node array and leaves identical to the single-context pc_hip_ligero_commit."""
