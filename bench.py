@@ -308,13 +308,36 @@ def msm_roofline(curve, pairs_per_launch, digits, kernel_ms, launches, kernel, t
     return r
 
 
+def effective_cores():
+    """CPUs this process can actually use: the logical CPU count, cut by the scheduler affinity and by the container's cgroup CPU
+    quota (the GPU boxes of this pool show 256 logical CPUs and a quota of 16: 256 threads there are 16 cores' worth)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(int(q) / int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(curve, srs, log_d, budget_s=30.0):
     """The CPU port (oracle/fast_msm.hpp: ark-ec's signed-digit bucket method with XYZZ buckets, an unrolled 64-bit CIOS multiplier
     and (window, chunk) tasks over all cores) timed on this box's cores on the same workload: ONE MSM over the leading 2^k points of
     the resident true SRS -- k = log_d (the full size the metric is quoted on) when the box does it within the budget -- plus the
     single-thread rate at 2^20 with ark-ec's own window rule (the per-core figure: ark-ec parallelises over windows only)."""
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     n0 = 1 << min(16, log_d)
     b = srs.read(1, n0)
     s = O.gen_scalars(curve, 1, n0)
@@ -345,7 +368,9 @@ def cpu_baseline(curve, srs, log_d, budget_s=30.0):
     dev, _ = srs.msm(s, n=n, base_offset=1)
     dev1, _ = srs.msm(np.ascontiguousarray(s[:n1]), n=n1, base_offset=1)
     return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs (the leading points of the same true SRS) on {cores} threads, {dt:.2f} s; "
+            "logical_cpus": os.cpu_count(),
+            "sample": f"1 MSM of 2^{lg} {curve} G1 pairs (the leading points of the same true SRS) on {cores} threads (= the CPUs the container's "
+                      f"cgroup quota / affinity gives this process, of {os.cpu_count()} logical), {dt:.2f} s; "
                       f"restated ark-ec signed-digit bucket method (oracle/fast_msm.hpp), NOT ark-ec itself",
             "per_core": {"value": n1 / dt1, "unit": "pairs/s", "threads": 1,
                          "sample": f"1 MSM of 2^{lg1} pairs on ONE thread with ark-ec's window rule, {dt1:.2f} s"},
@@ -679,7 +704,7 @@ def latency_sweep(ctx, curve, logs, cpu_max_log):
     zm = mont_limbs(curve, z)
     nmax = (1 << max(logs)) + 1
     pts = true_srs_points(ctx, curve, g, beta, 0, nmax)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     rows = {}
     crossover = None
     for lg in logs:

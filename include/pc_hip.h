@@ -126,6 +126,18 @@ int pc_hip_msm_async(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const v
                      pc_job** out_job);
 int pc_hip_job_wait(pc_ctx* ctx, pc_job* job);
 
+/* Residency accounting (bytes of device memory), so that a caller -- the Rust shim's key / polynomial caches, which replace the
+ * residency hook MarlinKZG10::trim cannot offer (marlin_pc/mod.rs:80-169 returns the key by value) -- can hold a budget:
+ *   pc_hip_srs_bytes_resident  one key: out[0] bases, [1] window table(s), [2] fold table, [3] workspaces of its MSM pipelines
+ *   pc_hip_ctx_bytes_resident  out[0] everything this library holds on the context's device (all contexts of the process on that
+ *                              device), [1] bases of this context's keys, [2] their window tables, [3] their fold tables,
+ *                              [4] the context's staging / scratch buffers, [5] number of key objects alive
+ *   pc_hip_ctx_trim            give back what can be rebuilt on demand: staging and scratch buffers, NTT plans, the working keys
+ *                              that pc_hip_ec_fold_from caches per committer key, idle pipelines' sort scratch. */
+int pc_hip_srs_bytes_resident(const pc_srs* srs, size_t out[4]);
+int pc_hip_ctx_bytes_resident(pc_ctx* ctx, size_t out[6]);
+int pc_hip_ctx_trim(pc_ctx* ctx);
+
 /* Tuning (optional): window bits c (0 = auto), level-0 chunk length T (0 = auto).  Applies
  * to SRS objects uploaded afterwards. */
 int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
@@ -318,7 +330,7 @@ int pc_hip_ec_fold_from(pc_ctx* ctx, const pc_srs* src, size_t n_half, const voi
 /* Once per committer key (like pc_hip_srs_precompute, at `trim`): the fold table T[b][j] = 2^b * key[n/2 + j], b < 131, of the
  * upper half of the key (131 x n/2 affine points: 17 GB for a 2^22-point Pallas key), used by pc_hip_ec_fold_from: every
  * opening's first fold multiplies THIS half by its round challenge.  Nothing in the reference corresponds to it.  n even. */
-int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs);
+int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs);   /* PC_ERR_UNSUPPORTED when the table would exceed half of the free device memory (PC_HIP_FOLD_TABLE_MAX_FRAC) */
 /* Late halving rounds without folding the key (same l_vec / r_vec / final_comm_key, bit for bit): once n has
  * shrunk to n0 the resident key K0 = key[0..n0) stays as it is and the per-base factors s_j that the remaining
  * folds `k_l += k_r * u` (ipa_pc/mod.rs:699-701) would have applied are kept as a device vector s (n0 Fr,

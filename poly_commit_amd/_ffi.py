@@ -76,6 +76,9 @@ def load_library():
     lib.pc_hip_job_wait.argtypes = [vp, vp]
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
     lib.pc_hip_set_timing.argtypes = [vp, ip]
+    lib.pc_hip_srs_bytes_resident.argtypes = [vp, C.POINTER(sz)]
+    lib.pc_hip_ctx_bytes_resident.argtypes = [vp, C.POINTER(sz)]
+    lib.pc_hip_ctx_trim.argtypes = [vp]
     lib.pc_hip_last_msm_phases_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_last_msm_marks_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pc_hip_last_msm_shape.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -386,6 +389,15 @@ class Context:
     def upload_srs(self, curve, bases, n=None, stride_bytes=0):
         return Srs(self, curve, bases, n, stride_bytes)
 
+    def bytes_resident(self):
+        """pc_hip_ctx_bytes_resident: device bytes by kind."""
+        out = (C.c_size_t * 6)()
+        self.check(self.lib.pc_hip_ctx_bytes_resident(self.h, out))
+        return dict(zip(("device_total", "keys", "window_tables", "fold_tables", "scratch", "n_keys"), [int(x) for x in out]))
+
+    def trim(self):
+        self.check(self.lib.pc_hip_ctx_trim(self.h))
+
     def load_serialized_srs(self, curve, data, compressed, max_points=0):
         """Resident SRS from the ark-serialize bytes of a Vec<G1Affine> (the head of kzg10::UniversalParams):
         returns (Srs, bytes_consumed)."""
@@ -498,6 +510,11 @@ class Srs:
     def clone(self):
         """A second resident copy (device-to-device): what a destructive consumer -- the IPA key fold -- works on."""
         return Srs(self.ctx, self.curve, self.device_ptr(), n=self.n)
+
+    def bytes_resident(self):
+        out = (C.c_size_t * 4)()
+        self.ctx.check(self.ctx.lib.pc_hip_srs_bytes_resident(self.h, out))
+        return dict(zip(("bases", "window_tables", "fold_table", "pipelines"), [int(x) for x in out]))
 
     def serialize(self, offset=0, count=None, compressed=False):
         """ark-serialize bytes of resident points as a Vec<G1Affine> (pc_hip_srs_serialize)."""

@@ -42,6 +42,7 @@ struct pc_ctx {
   float marks[8] = {0};          // the same marks as offsets from `epoch` (pc_hip_last_msm_marks_ms)
   hipEvent_t epoch = nullptr;    // recorded by pc_hip_set_timing(on)
   uint32_t shape[4] = {0};
+  std::vector<struct pc_srs*> keys;   // every key object of this context that is alive (pc_hip_ctx_bytes_resident, pc_hip_ctx_trim)
 };
 
 // Independent pipelines per SRS (stream + workspace each), used round-robin; a pipeline that still
@@ -161,7 +162,7 @@ static uint32_t scan_fan() {
 
 static void drop_many(pc_srs* srs) {
   delete srs->many.lane; srs->many.lane = nullptr;
-  if (srs->many.table) (void)hipFree(srs->many.table);
+  if (srs->many.table) srs->ctx->be.free(srs->many.table);
   srs->many.table = nullptr; srs->many.m = srs->many.B = srs->many.base_offset = 0;
 }
 
@@ -175,7 +176,7 @@ static void drop_table(pc_srs* srs) {
   drop_batch_many(srs);
   if (!srs->table) return;
   for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
-  (void)hipFree(srs->table); srs->table = nullptr;
+  srs->ctx->be.free(srs->table); srs->table = nullptr;
   srs->cfg.tbl = nullptr; srs->cfg.tbl_c = 0; srs->cfg.tbl_stride = 0; srs->cfg.tbl_min_n = 0;
 }
 
@@ -245,6 +246,7 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
   pc_srs* srs = new (std::nothrow) pc_srs();
   if (!srs) return PC_ERR_OOM;
   srs->ctx = ctx; srs->curve = curve; srs->n = n; srs->aw = (int)(pb / 4);
+  ctx->keys.push_back(srs);
   int rc = guarded(ctx, [&]() {
     srs->bases = (uint32_t*)ctx->be.alloc((n ? n : 1) * pb);
     if (n) {
@@ -388,10 +390,11 @@ void pc_hip_srs_free(pc_srs* srs) {
     }
     delete srs->lanes[i];
   }
-  if (srs->bases) (void)hipFree(srs->bases);
-  if (srs->fold_tbl) (void)hipFree(srs->fold_tbl);
+  if (srs->ctx) { auto& ks = srs->ctx->keys; ks.erase(std::remove(ks.begin(), ks.end(), srs), ks.end()); }
+  if (srs->bases) srs->ctx->be.free(srs->bases);
+  if (srs->fold_tbl) srs->ctx->be.free(srs->fold_tbl);
   drop_batch_many(srs);
-  if (srs->table) (void)hipFree(srs->table);
+  if (srs->table) srs->ctx->be.free(srs->table);
   drop_many(srs);
   delete srs;
 }
@@ -667,6 +670,56 @@ int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* sc
     for (int i = 0; i < 8; i++) ctx->phases[i] = 0;
   L->runner->shape(ctx->shape);
     if (L->be.timing) for (int i = 0; i + 1 < L->be.n_ev && i < 8; i++) (void)hipEventElapsedTime(&ctx->phases[i], L->be.ev[i], L->be.ev[i + 1]);
+    return (int)PC_OK;
+  });
+}
+
+static size_t lane_bytes(const MsmLane* L) { return L ? L->be.bytes_live : 0; }
+static void srs_bytes(const pc_srs* s, size_t out[4]) {
+  const size_t pb = (size_t)s->aw * 4;
+  out[0] = (s->n ? s->n : 1) * pb;
+  out[1] = 0;
+  if (s->table) { const uint32_t bits = pc::curve_ops(s->curve).scalar_bits; out[1] = (size_t)pc::msm_num_windows(bits, s->cfg.tbl_c) * s->n * s->cfg.tbl_pt_stride * 4; }
+  if (s->many.table) { const uint32_t bits = pc::curve_ops(s->curve).scalar_bits; out[1] += (size_t)pc::msm_num_windows(bits, pc::msm_choose_table_c(s->many.m, bits, 0)) * s->many.m * pb; }
+  out[2] = s->fold_tbl ? (size_t)pc::curve_ops(s->curve).fold_rows * s->fold_half * pb : 0;
+  out[3] = 0;
+  for (int i = 0; i < PC_MSM_LANES; i++) out[3] += lane_bytes(s->lanes[i]);
+  out[3] += lane_bytes(s->many.lane) + lane_bytes(s->bm.lanes[0]) + lane_bytes(s->bm.lanes[1]);
+}
+int pc_hip_srs_bytes_resident(const pc_srs* srs, size_t out[4]) {
+  if (!srs || !out) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(srs->ctx->mu);
+  srs_bytes(srs, out);
+  return PC_OK;
+}
+int pc_hip_ctx_bytes_resident(pc_ctx* ctx, size_t out[6]) {
+  if (!ctx || !out) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  for (int i = 0; i < 6; i++) out[i] = 0;
+  out[0] = pc::dev_bytes_held(ctx->device);
+  for (const pc_srs* s : ctx->keys) {
+    size_t b[4]; srs_bytes(s, b);
+    out[1] += b[0]; out[2] += b[1]; out[3] += b[2];
+  }
+  out[4] = ctx->be.scratch_bytes();
+  out[5] = ctx->keys.size();
+  return PC_OK;
+}
+int pc_hip_ctx_trim(pc_ctx* ctx) {
+  if (!ctx) return PC_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    ctx->be.sync();
+    ctx->be.trim();
+    ctx->ntt_plans.clear();
+    // working keys that an opening handed back (pc_hip_ec_fold_from keeps one per committer key, with its three pipelines)
+    std::vector<pc_srs*> cached;
+    for (pc_srs* s : ctx->keys) if (s->work_cache) { cached.push_back(s->work_cache); s->work_cache = nullptr; }
+    for (pc_srs* w : cached) { w->parent = nullptr; pc_hip_srs_free(w); }
+    // idle pipelines give their sort / scan scratch back (the plan's own workspace stays: it is what makes the next call cheap)
+    for (pc_srs* s : ctx->keys)
+      for (int i = 0; i < PC_MSM_LANES; i++)
+        if (s->lanes[i] && !s->lanes[i]->inflight) { s->lanes[i]->be.sync(); s->lanes[i]->be.trim(); }
     return (int)PC_OK;
   });
 }
@@ -1085,7 +1138,7 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) 
     if (!n_half) return (int)PC_OK;
     drop_table(srs);                            // the key changes: its window tables are stale
     drop_many(srs);
-    if (srs->fold_tbl) { (void)hipFree(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
+    if (srs->fold_tbl) { ctx->be.free(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
     pc::curve_ops(srs->curve).ec_fold(ctx->be, srs->bases, n_half, (const uint32_t*)u_host);
     return (int)PC_OK;
   });
@@ -1094,9 +1147,21 @@ int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs) {
   if (!ctx || !srs || srs->ctx != ctx || srs->n < 2 || (srs->n & 1)) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    if (srs->fold_tbl) { (void)hipFree(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
+    if (srs->fold_tbl) { ctx->be.free(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
     const size_t half = srs->n / 2, pb = (size_t)srs->aw * 4;
     const pc::CurveOps& ops = pc::curve_ops(srs->curve);
+    // 131 rows x n/2 points (17.6 GB for a 2^22-point Pallas key): refused above a share of the device's FREE memory
+    // (PC_HIP_FOLD_TABLE_MAX_FRAC, default 0.5) instead of driving a shared GPU out of memory; the opening then runs the GLV ladder
+    {
+      static const double frac = []() { const char* e = getenv("PC_HIP_FOLD_TABLE_MAX_FRAC"); double v = e ? atof(e) : 0.5; return v < 0 ? 0.0 : v > 1 ? 1.0 : v; }();
+      size_t free_b = 0, total_b = 0;
+      PC_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+      const size_t need = (size_t)ops.fold_rows * half * pb;
+      if ((double)need > frac * (double)free_b) {
+        ctx->last_error = "fold table of " + std::to_string(need >> 20) + " MiB exceeds " + std::to_string(frac) + " of the free device memory (" + std::to_string(free_b >> 20) + " MiB)";
+        return (int)PC_ERR_UNSUPPORTED;
+      }
+    }
     uint32_t* t = (uint32_t*)ctx->be.alloc((size_t)ops.fold_rows * half * pb);
     try { ops.fold_table_build(ctx->be, srs->bases + half * (size_t)srs->aw, half, t); }
     catch (...) { ctx->be.free(t); throw; }
@@ -1117,6 +1182,7 @@ int pc_hip_ec_fold_from(pc_ctx* ctx, const pc_srs* src, size_t n_half, const voi
     dst = new (std::nothrow) pc_srs();
     if (!dst) return PC_ERR_OOM;
     dst->ctx = ctx; dst->curve = src->curve; dst->n = n_half; dst->aw = src->aw;
+    ctx->keys.push_back(dst);
   }
   int rc = guarded(ctx, [&]() {
     if (fresh) { dst->bases = (uint32_t*)ctx->be.alloc(n_half * (size_t)src->aw * 4); dst->cfg = ctx->msm_cfg; }

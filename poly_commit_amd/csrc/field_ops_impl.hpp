@@ -43,8 +43,8 @@ struct FieldOpsImpl {
     h.resize((size_t)lanes * FrP::N);
     const size_t need = ((size_t)wide + lanes) * FrP::N * 4;
     if (need > be.scan_tmp_bytes) {      // reuse the backend's small scratch buffer
-      if (be.scan_tmp) { be.sync(); (void)hipFree(be.scan_tmp); be.scan_tmp = nullptr; be.scan_tmp_bytes = 0; }
-      PC_HIP_CHECK(hipMalloc(&be.scan_tmp, need)); be.scan_tmp_bytes = need;
+      if (be.scan_tmp) { be.sync(); be.free(be.scan_tmp); be.scan_tmp = nullptr; be.scan_tmp_bytes = 0; }
+      be.scan_tmp = be.alloc(need); be.scan_tmp_bytes = need;
     }
     uint32_t* part1 = (uint32_t*)be.scan_tmp; uint32_t* part = part1 + (size_t)wide * FrP::N;
     FrDotBody<FrP> body{a, b, (uint32_t)n, wide, part1};
@@ -61,8 +61,8 @@ struct FieldOpsImpl {
     uint32_t blocks = (q + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks == 0) blocks = 1;
     const size_t need = ((size_t)blocks + 1) * 2 * FrP::N * 4;
     if (need > be.scan_tmp_bytes) {      // reuse the backend's small scratch buffer (as fr_dot does)
-      if (be.scan_tmp) { be.sync(); (void)hipFree(be.scan_tmp); be.scan_tmp = nullptr; be.scan_tmp_bytes = 0; }
-      PC_HIP_CHECK(hipMalloc(&be.scan_tmp, need)); be.scan_tmp_bytes = need;
+      if (be.scan_tmp) { be.sync(); be.free(be.scan_tmp); be.scan_tmp = nullptr; be.scan_tmp_bytes = 0; }
+      be.scan_tmp = be.alloc(need); be.scan_tmp_bytes = need;
     }
     uint32_t* partial = (uint32_t*)be.scan_tmp; uint32_t* fin = partial + (size_t)blocks * 2 * FrP::N;
     const F fu = u ? F::load(u) : F::zero(), fui = ui ? F::load(ui) : F::zero();

@@ -8,6 +8,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 
 namespace pc {
 
@@ -22,6 +24,31 @@ struct HipError : std::runtime_error {
     hipError_t _e = (expr);                                       \
     if (_e != hipSuccess) throw ::pc::HipError(_e, #expr);        \
   } while (0)
+
+// Every hipMalloc / hipFree of the library goes through these two: per-device totals of what it holds (pc_hip_ctx_bytes_resident).
+struct DevMemLedger {
+  std::mutex mu; std::unordered_map<void*, std::pair<int, size_t>> live; std::unordered_map<int, size_t> total;
+};
+inline DevMemLedger& dev_mem_ledger() { static DevMemLedger l; return l; }
+inline hipError_t dev_malloc(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    DevMemLedger& l = dev_mem_ledger(); std::lock_guard<std::mutex> lk(l.mu);
+    l.live[*p] = {dev, bytes}; l.total[dev] += bytes;
+  }
+  return e;
+}
+inline size_t dev_free(void* p) {        // returns the size that was recorded for p
+  size_t bytes = 0;
+  if (!p) return 0;
+  { DevMemLedger& l = dev_mem_ledger(); std::lock_guard<std::mutex> lk(l.mu);
+    auto it = l.live.find(p);
+    if (it != l.live.end()) { bytes = it->second.second; l.total[it->second.first] -= bytes; l.live.erase(it); } }
+  (void)hipFree(p);
+  return bytes;
+}
+inline size_t dev_bytes_held(int device) { DevMemLedger& l = dev_mem_ledger(); std::lock_guard<std::mutex> lk(l.mu); auto it = l.total.find(device); return it == l.total.end() ? 0 : it->second; }
 
 // The short, latency-bound kernels around the bucket accumulation (division scan levels, bucket / segmented reduction
 // levels, cooperative reductions; a k_run body opts in, see body_latency_bound) usually share the chip with an accumulation of another pipeline whose waves issue
@@ -140,10 +167,7 @@ struct HipBackend {
     PC_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
   void destroy() {
-    if (scan_tmp) (void)hipFree(scan_tmp);
-    if (sort_ws) (void)hipFree(sort_ws);
-    if (work_ws) (void)hipFree(work_ws);
-    for (int i = 0; i < 2; i++) if (stage_ws[i]) (void)hipFree(stage_ws[i]);
+    trim();
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
     if (done) (void)hipEventDestroy(done);
     if (main_stream) stream = main_stream;
@@ -151,16 +175,25 @@ struct HipBackend {
     if (tail_ev) (void)hipEventDestroy(tail_ev);
     if (stream) (void)hipStreamDestroy(stream);
   }
+  // release every grow-only scratch buffer (they come back on demand); the stream must be idle
+  void trim() {
+    free(scan_tmp); scan_tmp = nullptr; scan_tmp_bytes = 0;
+    free(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0;
+    free(work_ws); work_ws = nullptr; work_ws_bytes = 0;
+    for (int i = 0; i < 2; i++) { free(stage_ws[i]); stage_ws[i] = nullptr; stage_bytes[i] = 0; }
+  }
+  size_t scratch_bytes() const { return scan_tmp_bytes + sort_ws_bytes + work_ws_bytes + stage_bytes[0] + stage_bytes[1]; }
   void mark() { if (timing && n_ev < MAX_EV) PC_HIP_CHECK(hipEventRecord(ev[n_ev++], stream)); }
 
-  void* alloc(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 4)); return p; }
-  void free(void* p) { if (p) (void)hipFree(p); }
+  size_t bytes_live = 0;      // device bytes currently allocated through THIS backend (a pipeline's workspace, a context's buffers)
+  void* alloc(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(dev_malloc(&p, bytes ? bytes : 4)); bytes_live += bytes ? bytes : 4; return p; }
+  void free(void* p) { if (p) bytes_live -= dev_free(p); }
   // Grow-only scratch for the short kernels of one call (division scan levels): hipMalloc/hipFree per
   // call would synchronise the whole device and drain the MSM pipelines running on other streams.
   void* workspace(size_t bytes) {
     if (bytes > work_ws_bytes) {
-      if (work_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(work_ws); work_ws = nullptr; work_ws_bytes = 0; }
-      PC_HIP_CHECK(hipMalloc(&work_ws, bytes)); work_ws_bytes = bytes;
+      if (work_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); free(work_ws); work_ws = nullptr; work_ws_bytes = 0; }
+      work_ws = alloc(bytes); work_ws_bytes = bytes;
     }
     return work_ws;
   }
@@ -170,8 +203,8 @@ struct HipBackend {
   static constexpr size_t STAGE_KEEP = (size_t)1 << 30;
   void* stage(int slot, size_t bytes) {
     if (bytes > stage_bytes[slot]) {
-      if (stage_ws[slot]) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(stage_ws[slot]); stage_ws[slot] = nullptr; stage_bytes[slot] = 0; }
-      PC_HIP_CHECK(hipMalloc(&stage_ws[slot], bytes ? bytes : 4)); stage_bytes[slot] = bytes ? bytes : 4;
+      if (stage_ws[slot]) { PC_HIP_CHECK(hipStreamSynchronize(stream)); free(stage_ws[slot]); stage_ws[slot] = nullptr; stage_bytes[slot] = 0; }
+      stage_ws[slot] = alloc(bytes ? bytes : 4); stage_bytes[slot] = bytes ? bytes : 4;
     }
     return stage_ws[slot];
   }
@@ -203,8 +236,8 @@ struct HipBackend {
     const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles > (1u << 20)) throw std::runtime_error("exclusive_scan_u32: input too large");
     if (tiles * 4 > scan_tmp_bytes) {
-      if (scan_tmp) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(scan_tmp); }
-      PC_HIP_CHECK(hipMalloc(&scan_tmp, tiles * 4)); scan_tmp_bytes = tiles * 4;
+      if (scan_tmp) { PC_HIP_CHECK(hipStreamSynchronize(stream)); free(scan_tmp); scan_tmp = nullptr; }
+      scan_tmp = alloc(tiles * 4); scan_tmp_bytes = tiles * 4;
     }
     uint32_t* sums = (uint32_t*)scan_tmp;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)tiles), dim3(256), 0, stream, in, n, sums);

@@ -23,8 +23,8 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   const size_t rec_off = ((gw + 2 * nb1) * 4 + 15) & ~(size_t)15;
   const size_t need = rec_off + (size_t)g.n * g.Wd * 8;
   if (need > sort_ws_bytes) {
-    if (sort_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0; }
-    PC_HIP_CHECK(hipMalloc(&sort_ws, need)); sort_ws_bytes = need;
+    if (sort_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); free(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0; }
+    sort_ws = alloc(need); sort_ws_bytes = need;
   }
   uint32_t* G = (uint32_t*)sort_ws; uint32_t* bintotal = G + gw; uint32_t* binbase = bintotal + nb1;
   uint2* records = (uint2*)((char*)sort_ws + rec_off);

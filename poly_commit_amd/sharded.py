@@ -348,6 +348,8 @@ class ShardedRows:
         import torch
         e = self.e
         wire = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+        if n_rows <= 0:
+            raise ValueError("ShardedRows.commit: the matrix has no rows (LinearCodePCS::commit never builds an empty matrix)")
         ranges = [self.row_range(n_rows, r) for r in range(self.world)]
         active = [r for r in range(self.world) if ranges[r][1] > ranges[r][0]]
         lo, hi = ranges[self.rank]

@@ -10,11 +10,16 @@
 //!   `pc_srs` + `base_offset`.  The first time a key allocation is seen it is uploaded (the `trim` hook the survey asks
 //!   for, taken lazily: `marlin_pc/mod.rs:80-169` returns a plain struct) and its window table is built
 //!   (`pc_hip_srs_precompute`); later calls find it by address range, length and a fingerprint of sampled points.
-//! * [`device_poly`] does the same for coefficient vectors, bounded by `PC_HIP_POLY_CACHE_MB` (default 4096; 0 turns the
-//!   cache off): `commit` uploads a polynomial once, `open` of the same `&LabeledPolynomial` finds the device copy and
-//!   sends nothing over PCIe.  The fingerprint samples 64 coefficients; a caller that rewrites a polynomial IN PLACE
-//!   between `commit` and `open` without touching any sampled coefficient would get a stale copy -- such a caller sets
-//!   the cache to 0.
+//!   Resident keys are bounded by a BYTE budget (`PC_HIP_KEY_BUDGET_MB`, default 65536: bases + window tables + fold tables +
+//!   pipelines as `pc_hip_srs_bytes_resident` reports them) and by `PC_HIP_MAX_KEYS`; least recently used keys go first, and
+//!   [`release`] drops a key explicitly (`HipMarlinKZG10::release(&ck)`).
+//! * [`device_poly`] does the same for coefficient vectors.  It is OPT-IN (`PC_HIP_POLY_CACHE_MB`, default 0 = off): with it
+//!   `commit` uploads a polynomial once and `open` of the same `&LabeledPolynomial` finds the device copy and sends nothing
+//!   over PCIe -- but a cached copy is identified by address, length and 64 sampled coefficients, so a caller that rewrites a
+//!   polynomial IN PLACE (or frees it and allocates another at the same address) without touching a sampled coefficient would
+//!   get a proof for the OLD polynomial (round-3 advisor finding).  Only a caller whose polynomials are immutable between
+//!   `commit` and `open` should turn it on.  With the cache off `commit` and `open` hand the host slice to `pc_hip_msm` /
+//!   `pc_hip_kzg_open`, which overlap the PCIe copy with the MSM themselves (two halves on two pipelines from 2^23 coefficients).
 use ark_poly_commit::Error;
 use core::ffi::{c_int, c_void};
 use std::collections::VecDeque;
@@ -167,10 +172,56 @@ pub fn resident<G: HipCurve>(bases: &[G]) -> Result<(Arc<ResidentKey>, usize), E
     }
     let key = Arc::new(ResidentKey { srs, n: bases.len(), fold_table_built: std::sync::atomic::AtomicBool::new(false), host_addr: addr, host_bytes: bases.len() * elem, elem_bytes: elem, fingerprint: fingerprint_points(bases) });
     q.push_front(key.clone());
-    while q.len() > env_usize("PC_HIP_MAX_KEYS", 8) {
+    evict_over_budget(&mut q);
+    Ok((key, 0))
+}
+
+/// Device bytes of one resident key: bases + window table(s) + fold table + the workspaces of its MSM pipelines.
+pub fn key_bytes(k: &ResidentKey) -> usize {
+    let mut b = [0usize; 4];
+    if unsafe { ffi::pc_hip_srs_bytes_resident(k.srs, b.as_mut_ptr()) } == ffi::PC_OK { b.iter().sum() } else { k.host_bytes }
+}
+
+/// Least recently used keys leave until the cache holds at most `PC_HIP_MAX_KEYS` (default 8) keys and `PC_HIP_KEY_BUDGET_MB`
+/// (default 65536) of device memory; the key just used always stays.  A key still referenced by a running call is freed when
+/// that call drops its `Arc`.
+fn evict_over_budget(q: &mut VecDeque<Arc<ResidentKey>>) {
+    let max_keys = env_usize("PC_HIP_MAX_KEYS", 8).max(1);
+    let budget = env_usize("PC_HIP_KEY_BUDGET_MB", 65536) << 20;
+    while q.len() > max_keys {
         q.pop_back();
     }
-    Ok((key, 0))
+    let mut total: usize = q.iter().map(|k| key_bytes(k)).sum();
+    while total > budget && q.len() > 1 {
+        total -= q.pop_back().map(|k| key_bytes(&k)).unwrap_or(0);
+    }
+}
+
+/// Drop the resident copy (bases, tables, pipelines) of the key allocation that contains `bases`, if there is one: the explicit
+/// counterpart of the lazy upload (`HipMarlinKZG10::release(&ck)`).  Returns whether a key was dropped.
+pub fn release<G: HipCurve>(bases: &[G]) -> bool {
+    let elem = core::mem::size_of::<G>();
+    let addr = bases.as_ptr() as usize;
+    let Some(keys) = KEYS.get() else { return false };
+    let mut q = keys.lock().unwrap();
+    let before = q.len();
+    q.retain(|k| !(k.elem_bytes == elem && addr >= k.host_addr && addr < k.host_addr + k.host_bytes.max(1)));
+    before != q.len()
+}
+
+/// Device memory the library holds for this process's context, by kind (`pc_hip_ctx_bytes_resident`): `[all, key bases, window
+/// tables, fold tables, staging + scratch, number of keys]`.
+pub fn bytes_resident() -> Result<[usize; 6], Error> {
+    let c = ctx()?;
+    let mut out = [0usize; 6];
+    check(c, unsafe { ffi::pc_hip_ctx_bytes_resident(c.raw, out.as_mut_ptr()) })?;
+    Ok(out)
+}
+
+/// Give back staging buffers, scratch and cached working keys (`pc_hip_ctx_trim`); they come back on demand.
+pub fn trim() -> Result<(), Error> {
+    let c = ctx()?;
+    check(c, unsafe { ffi::pc_hip_ctx_trim(c.raw) })
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -229,10 +280,16 @@ fn fingerprint_scalars<F: HipField>(c: &[F]) -> Vec<u64> {
     sample_positions(c.len(), 64).flat_map(|i| c[i].to_mont_limbs()).collect()
 }
 
+/// Bytes the polynomial cache may hold (`PC_HIP_POLY_CACHE_MB`; default 0: the cache is off, see the module documentation).
+pub fn poly_cache_bytes() -> usize {
+    static V: OnceLock<usize> = OnceLock::new();
+    *V.get_or_init(|| env_usize("PC_HIP_POLY_CACHE_MB", 0) << 20)
+}
+
 /// The device copy of `coeffs`: found by address, length and fingerprint, else uploaded and remembered (LRU, bounded by
-/// `PC_HIP_POLY_CACHE_MB`).  `commit` calls this; `open` of the same polynomial then sends nothing over PCIe.
+/// `PC_HIP_POLY_CACHE_MB`).  With the cache on, `commit` calls this and `open` of the same polynomial sends nothing over PCIe.
 pub fn device_poly<F: HipField>(coeffs: &[F]) -> Result<Arc<DevicePoly>, Error> {
-    let cap = env_usize("PC_HIP_POLY_CACHE_MB", 4096) << 20;
+    let cap = poly_cache_bytes();
     if cap == 0 || coeffs.is_empty() {
         return Ok(Arc::new(DevicePoly::upload(coeffs)?));
     }

@@ -151,7 +151,8 @@ where
     Ok(randomness)
 }
 
-/// `KZG10::commit` (`kzg10/mod.rs:157-210`).  The polynomial's device copy stays cached for `open` (`device::device_poly`).
+/// `KZG10::commit` (`kzg10/mod.rs:157-210`).  With the opt-in polynomial cache (`device::device_poly`) the device copy stays for
+/// `open`; without it the host slice goes to `pc_hip_msm`, which overlaps the copy with the MSM itself.
 pub fn commit<E, P>(powers: &Powers<E>, polynomial: &P, hiding_bound: Option<usize>, rng: Option<&mut dyn RngCore>)
     -> Result<(Commitment<E>, Randomness<E::ScalarField, P>), Error>
 where
@@ -163,7 +164,8 @@ where
     check_degree_is_too_large(polynomial.degree(), powers.size())?;
     let coeffs = polynomial.coeffs();
     let lz = leading_zeros(coeffs);
-    let mut commitment: E::G1 = if coeffs.len() - lz >= device::min_pairs() {
+    let mut commitment: E::G1 = if coeffs.len() - lz >= device::min_pairs() && device::poly_cache_bytes() > 0 {
+        // opt-in polynomial cache: the device copy made here serves `open`
         let dev = device::device_poly(coeffs)?;
         msm::<E::G1Affine>(&powers.powers_of_g[lz..], Scalars::Device { buf: &dev, first: lz, n: coeffs.len() - lz })?
     } else {
@@ -256,7 +258,7 @@ where
     finish_open::<E, P>(powers, point, rand, w, hiding_witness.as_ref())
 }
 
-/// `KZG10::open` for a polynomial in host memory: its device copy (cached by `commit`) is used.
+/// `KZG10::open` for a polynomial in host memory (`kzg10/mod.rs:287-310`).
 pub fn open<E, P>(powers: &Powers<E>, p: &P, point: E::ScalarField, rand: &Randomness<E::ScalarField, P>) -> Result<Proof<E>, Error>
 where
     E: Pairing,
@@ -274,6 +276,36 @@ where
         let hiding = if rand.is_hiding() { Some(&rand.blinding_polynomial / &divisor) } else { None };
         return open_with_witness_polynomial::<E, P>(powers, point, rand, &witness, hiding.as_ref());
     }
-    let dev = device::device_poly(p.coeffs())?;
-    open_device::<E, P>(powers, &dev, n, point, rand)
+    if device::poly_cache_bytes() > 0 {
+        let dev = device::device_poly(p.coeffs())?;
+        return open_device::<E, P>(powers, &dev, n, point, rand);
+    }
+    // host coefficients: copy + witness division + MSM as ONE call (pc_hip_kzg_open; large polynomials as two halves, the
+    // second half's copy under the first half's MSM)
+    let hiding_witness = if rand.is_hiding() {
+        let divisor = P::from_coefficients_vec(vec![-point, E::ScalarField::from(1u64)]);
+        Some(&rand.blinding_polynomial / &divisor)                                   // :228-236
+    } else {
+        None
+    };
+    let c = ctx()?;
+    let (key, base_offset) = device::resident(&powers.powers_of_g[..])?;
+    let z = point.to_mont_limbs();
+    let mut xy = [0u64; 12];
+    let mut inf = 0i32;
+    let rc = if <E::ScalarField as HipField>::layout_is_abi() {
+        unsafe {
+            ffi::pc_hip_kzg_open(c.raw, key.srs, base_offset, p.coeffs().as_ptr() as *const c_void, ffi::PC_MEM_HOST, n, z.as_ptr() as *const c_void,
+                                 xy.as_mut_ptr() as *mut c_void, &mut inf)
+        }
+    } else {
+        let packed = pack_scalars(p.coeffs());
+        unsafe {
+            ffi::pc_hip_kzg_open(c.raw, key.srs, base_offset, packed.as_ptr() as *const c_void, ffi::PC_MEM_HOST, n, z.as_ptr() as *const c_void,
+                                 xy.as_mut_ptr() as *mut c_void, &mut inf)
+        }
+    };
+    check(c, rc)?;
+    let w = if inf != 0 { E::G1::zero() } else { <E::G1Affine as HipCurve>::read_xy(&xy).into_group() };
+    finish_open::<E, P>(powers, point, rand, w, hiding_witness.as_ref())
 }

@@ -262,4 +262,15 @@ where
         }
         Ok(())
     }
+
+    /// Drop the device copies (bases, window tables, pipelines) of `ck`'s powers now, instead of waiting for the key cache's
+    /// byte budget (`PC_HIP_KEY_BUDGET_MB`) to push them out: `trim` returns the key by value (`marlin_pc/mod.rs:80-169`), so
+    /// no `Drop` of the reference's type can do this.  A later `commit` / `open` with the same key uploads it again.
+    pub fn release(ck: &CommitterKey<E>) -> bool {
+        let mut any = device::release(&ck.powers[..]);
+        if let Some(sp) = ck.shifted_powers.as_ref() {
+            any |= device::release(&sp[..]);
+        }
+        any
+    }
 }

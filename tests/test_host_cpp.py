@@ -71,3 +71,11 @@ def test_hyrax_and_general_ipa_host_mirrors_compile():
                                "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
         r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
         assert r.returncode == 2 and "usage" in r.stdout
+
+
+def test_sharded_rows_commit_rejects_an_empty_matrix():
+    """Round-3 advisor finding: n_rows == 0 left no active rank (IndexError on active[-1]); now a clean ValueError."""
+    import pytest
+    from poly_commit_amd import sharded
+    with pytest.raises(ValueError):
+        sharded.ShardedRows(engine=None, rank=0, world=2).commit(None, 0, 16, None)
