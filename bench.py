@@ -396,6 +396,7 @@ class KzgSetup:
         self.beta = seed_fr(curve, 0xBE7A24)
         self.z = seed_fr(curve, 0x2EE7)
         self.eng = sharded.HipEngine(ctx, curve)
+        self.eng.glv_table = None if args.glv_table < 0 else bool(args.glv_table)
         self.job = sharded.ShardedKzg(self.eng, curve, D.rank, D.world, D.dist)
         t0 = time.perf_counter()
         pts = true_srs_points(ctx, curve, self.g, self.beta, D.rank * n - 1, n + 1)
@@ -781,6 +782,7 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
     g = O.gen_bases(curve, 1)[0]
     beta = seed_fr(curve, 0xBE7A25)
     eng = sharded.HipEngine(ctx, curve)
+    eng.glv_table = None if args.glv_table < 0 else bool(args.glv_table)
     job = sharded.ShardedBatch(eng, curve, rank, world, D.dist)
     pts = true_srs_points(ctx, curve, g, beta, lo, n)            # this rank's REAL chunk of the one SRS
     job.load_srs_chunk(pts.data_ptr(), precompute=bool(args.precompute), n=n)
@@ -1148,6 +1150,9 @@ def main():
                          "pc_hip_group_commit_open_async (persistent worker thread per device)")
     ap.add_argument("--group-value", type=int, default=0, help="--mode group: also return p(z) with every proof (one more evaluation pass per shard)")
     ap.add_argument("--group-coeffs", default="host", choices=["host", "pinned", "device"], help="--mode group: coefficients handed over as one host array (pageable, or page-locked), or as resident per-device shards")
+    ap.add_argument("--glv-table", type=int, default=-1,
+                    help="form of the SRS window table: 1 = GLV (half the memory: the windows of the scalars' 128-bit halves, "
+                         "pc_hip_srs_precompute_ex PC_HIP_TABLE_GLV), 0 = full, -1 (default) = the library's policy (full unless HBM is tight)")
     ap.add_argument("--precompute", type=int, default=1,
                     help="1 (default): build the SRS window table in HBM once after the upload "
                          "(pc_hip_srs_precompute; part of SRS residency, outside the timed region); 0: table-free MSM")
@@ -1272,7 +1277,7 @@ def main():
                                                             "arithmetic crates are not buildable here (DESIGN.md section 2)"),
             "config": {"workload": cfg(log_degree), "curve": curve, "log_degree": log_degree,
                        "pairs_per_step": prim["pairs_per_step"], "inflight": max(0, args.inflight),
-                       "srs_window_table": bool(args.precompute),
+                       "srs_window_table": bool(args.precompute), "srs_window_table_form": {-1: "library policy (full unless HBM is tight)", 0: "full", 1: "GLV (half size)"}[args.glv_table],
                        "srs_window_table_build_ms": prim["srs_window_table_build_ms"],    # once per key, outside the timed region
                        "srs_gen_ms": prim["srs_gen_ms"],
                        "coefficients": "device-resident when the timed region starts (value); pinned host memory "

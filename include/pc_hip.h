@@ -94,6 +94,16 @@ int pc_hip_universal_params_layout(pc_curve curve, const void* bytes, size_t n_b
  * the table (the key changes).  Nothing in the reference corresponds to it: ark-ec's
  * VariableBaseMSM has no fixed-base state. */
 int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs);
+/* The same with the form of the table chosen by the caller.  PC_HIP_TABLE_GLV: the table holds only the windows of the ~128-bit halves of
+ * the GLV split k = k1 + k2*lambda (BLS12-381, BN254 and Pallas all have the j = 0 endomorphism phi(x, y) = (beta x, y)): HALF the
+ * memory and build time (12.9 instead of 25.8 GB for a 2^24-point BLS12-381 key); every scalar is split on the device, the digits of
+ * k2 go to a second bucket set with the SAME table points, and phi is applied once to that set's reduced sum -- the same number of
+ * bucket additions, one more bucket set to reduce (+3 % per MSM at 2^24, more below 2^22).  PC_HIP_TABLE_GLV_IF_TIGHT: the GLV form
+ * only when the full table would take more than half of the free device memory (what pc_hip_srs_precompute does unless
+ * PC_HIP_TABLE_GLV=0/1 is set).  Results are bit-identical in every form. */
+#define PC_HIP_TABLE_GLV 1
+#define PC_HIP_TABLE_GLV_IF_TIGHT 2
+int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs, unsigned flags);
 size_t pc_hip_srs_len(const pc_srs* srs);
 /* Device pointer of the packed (x||y) resident bases, for callers that build on it. */
 void* pc_hip_srs_device_ptr(const pc_srs* srs);

@@ -76,6 +76,7 @@ def load_library():
     lib.pc_hip_job_wait.argtypes = [vp, vp]
     lib.pc_hip_set_msm_tuning.argtypes = [vp, C.c_uint, C.c_uint]
     lib.pc_hip_set_timing.argtypes = [vp, ip]
+    lib.pc_hip_srs_precompute_ex.argtypes = [vp, vp, C.c_uint, sz, C.c_uint]
     lib.pc_hip_srs_bytes_resident.argtypes = [vp, C.POINTER(sz)]
     lib.pc_hip_ctx_bytes_resident.argtypes = [vp, C.POINTER(sz)]
     lib.pc_hip_ctx_trim.argtypes = [vp]
@@ -422,9 +423,13 @@ class Srs:
         ctx.check(ctx.lib.pc_hip_srs_upload(ctx.h, CURVES[curve], p, n, stride_bytes, where, C.byref(h)))
         self.h, self.n = h, n
 
-    def precompute(self, window_bits=0, min_pairs=0):
-        """Build the window table of this SRS in HBM (pc_hip_srs_precompute)."""
-        self.ctx.check(self.ctx.lib.pc_hip_srs_precompute(self.ctx.h, self.h, window_bits, min_pairs))
+    def precompute(self, window_bits=0, min_pairs=0, glv=None):
+        """Build the window table of this SRS in HBM (pc_hip_srs_precompute).  glv=True: the half-size table over the GLV halves of
+        the scalars (pc_hip_srs_precompute_ex, PC_HIP_TABLE_GLV); False: the full table; None: the library's policy."""
+        if glv is None:
+            self.ctx.check(self.ctx.lib.pc_hip_srs_precompute(self.ctx.h, self.h, window_bits, min_pairs))
+        else:
+            self.ctx.check(self.ctx.lib.pc_hip_srs_precompute_ex(self.ctx.h, self.h, window_bits, min_pairs, 1 if glv else 0))
         return self
 
     def free(self):

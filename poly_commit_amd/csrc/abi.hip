@@ -177,7 +177,7 @@ static void drop_table(pc_srs* srs) {
   if (!srs->table) return;
   for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
   srs->ctx->be.free(srs->table); srs->table = nullptr;
-  srs->cfg.tbl = nullptr; srs->cfg.tbl_c = 0; srs->cfg.tbl_stride = 0; srs->cfg.tbl_min_n = 0;
+  srs->cfg.tbl = nullptr; srs->cfg.tbl_c = 0; srs->cfg.tbl_stride = 0; srs->cfg.tbl_min_n = 0; srs->cfg.tbl_glv = false;
 }
 
 extern "C" {
@@ -398,35 +398,56 @@ void pc_hip_srs_free(pc_srs* srs) {
   drop_many(srs);
   delete srs;
 }
-int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {
-  if (!ctx || !srs || srs->ctx != ctx || window_bits == 1 || window_bits > 23) return PC_ERR_INVALID_ARG;
+// windows of the key's table: the 255-bit scalar's, or those of its 130-bit GLV halves
+static uint32_t table_windows(const pc_srs* srs, uint32_t c, bool glv) {
+  return pc::msm_num_windows(glv ? pc::GLV_HALF_BITS : pc::curve_ops(srs->curve).scalar_bits, c);
+}
+int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs, unsigned flags) {
+  if (!ctx || !srs || srs->ctx != ctx || window_bits == 1 || window_bits > 23 || (flags & ~(unsigned)(PC_HIP_TABLE_GLV | PC_HIP_TABLE_GLV_IF_TIGHT))) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     for (int i = 0; i < PC_MSM_LANES; i++)
       if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
     drop_table(srs);
     if (!srs->n) return (int)PC_OK;
-    const uint32_t bits = srs->curve == PC_CURVE_BN254 ? 254u : 255u;
-    const uint32_t c = window_bits ? window_bits : pc::msm_choose_table_c(srs->n, bits);
-    const uint32_t Wd = pc::msm_num_windows(bits, c);
-    if ((uint64_t)Wd * srs->n >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;     // entry = 31-bit table index + sign
+    const uint32_t bits = pc::curve_ops(srs->curve).scalar_bits;
     // 96-byte points (BLS12-381) are padded to one 128-byte line each: a gather then touches one
     // DRAM line instead of 1.5 on average (the table no longer fits the 256 MB MALL)
     uint32_t pt_stride = srs->aw == 24 ? 32u : (uint32_t)srs->aw;
     if (const char* e = getenv("PC_HIP_TBL_PAD")) { if (!atoi(e)) pt_stride = (uint32_t)srs->aw; }      // =0: packed 96-byte rows
-    const size_t bytes = (size_t)Wd * srs->n * pt_stride * 4;
+    bool glv = (flags & PC_HIP_TABLE_GLV) != 0;
+    auto geometry = [&](bool g, uint32_t& c, uint32_t& Wt, size_t& bytes) {
+      c = window_bits ? window_bits : pc::msm_choose_table_c(srs->n, bits, 5, g);
+      Wt = table_windows(srs, c, g);
+      bytes = (size_t)Wt * srs->n * pt_stride * 4;
+    };
+    uint32_t c, Wt; size_t bytes;
+    geometry(glv, c, Wt, bytes);
+    if (!glv && (flags & PC_HIP_TABLE_GLV_IF_TIGHT)) {
+      // the full table (bits / c + 1 copies of the key: 25.8 GB for 2^24 BLS12-381 points) only when it leaves half of the free
+      // memory to everything else; otherwise the GLV form (half the windows: the same additions, one more bucket set to reduce)
+      size_t free_b = 0, total_b = 0;
+      PC_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+      if (bytes > free_b / 2) { glv = true; geometry(glv, c, Wt, bytes); }
+    }
+    if ((uint64_t)Wt * srs->n >= (1ull << 31)) return (int)PC_ERR_TOO_LARGE;     // entry = 31-bit table index + sign
     uint32_t* table = (uint32_t*)ctx->be.alloc(bytes);
     try {
-      pc::curve_ops(srs->curve).window_table(ctx->be, srs->bases, (uint32_t)srs->n, c, Wd, table, pt_stride);
+      pc::curve_ops(srs->curve).window_table(ctx->be, srs->bases, (uint32_t)srs->n, c, Wt, table, pt_stride);
     } catch (...) { ctx->be.free(table); throw; }
     for (int i = 0; i < PC_MSM_LANES; i++) { delete srs->lanes[i]; srs->lanes[i] = nullptr; }
     srs->table = table;
-    srs->cfg.tbl = table; srs->cfg.tbl_c = c; srs->cfg.tbl_stride = (uint32_t)srs->n; srs->cfg.tbl_pt_stride = pt_stride;
+    srs->cfg.tbl = table; srs->cfg.tbl_c = c; srs->cfg.tbl_stride = (uint32_t)srs->n; srs->cfg.tbl_pt_stride = pt_stride; srs->cfg.tbl_glv = glv;
     srs->cfg.tbl_min_n = min_pairs ? min_pairs : (srs->n + 3) / 4;
     try { srs_lane(srs, 0); }                     // workspace for the table geometry; on failure fall back
     catch (...) { drop_table(srs); srs_lane(srs, 0); throw; }
     return (int)PC_OK;
   });
+}
+int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {
+  // PC_HIP_TABLE_GLV=1: every table in the GLV form; =0: never; unset: the full table unless device memory is tight
+  static const unsigned flags = []() { const char* e = getenv("PC_HIP_TABLE_GLV"); return !e ? (unsigned)PC_HIP_TABLE_GLV_IF_TIGHT : atoi(e) ? (unsigned)PC_HIP_TABLE_GLV : 0u; }();
+  return pc_hip_srs_precompute_ex(ctx, srs, window_bits, min_pairs, flags);
 }
 size_t pc_hip_srs_len(const pc_srs* srs) { return srs ? srs->n : 0; }
 void* pc_hip_srs_device_ptr(const pc_srs* srs) { return srs ? srs->bases : nullptr; }
@@ -535,9 +556,9 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
         static const size_t Gmax = []() { const char* e = getenv("PC_HIP_BATCH_G"); int v = e ? atoi(e) : 8; return (size_t)(v < 0 ? 0 : v); }();
         const size_t m = n[0];
         size_t G = std::min(Gmax, n_polys);
-        const uint32_t bits = pc::curve_ops(srs->curve).scalar_bits;
-        const uint32_t Wd = pc::msm_num_windows(bits, srs->cfg.tbl_c);
-        while (G >= 2 && ((uint64_t)G * m * Wd >= (1ull << 32) || ((uint64_t)G << (srs->cfg.tbl_c - 1)) >= (1ull << 31))) G /= 2;
+        const uint32_t sets = srs->cfg.tbl_glv ? 2u : 1u;
+        const uint32_t Wd = sets * table_windows(srs, srs->cfg.tbl_c, srs->cfg.tbl_glv);      // digits per scalar
+        while (G >= 2 && ((uint64_t)G * m * Wd >= (1ull << 32) || ((uint64_t)G * sets << (srs->cfg.tbl_c - 1)) >= (1ull << 31))) G /= 2;
         if (G >= 2) {
           pc_srs::BatchMany& B = srs->bm;
           if (B.m != m || B.G != G) {
@@ -679,7 +700,7 @@ static void srs_bytes(const pc_srs* s, size_t out[4]) {
   const size_t pb = (size_t)s->aw * 4;
   out[0] = (s->n ? s->n : 1) * pb;
   out[1] = 0;
-  if (s->table) { const uint32_t bits = pc::curve_ops(s->curve).scalar_bits; out[1] = (size_t)pc::msm_num_windows(bits, s->cfg.tbl_c) * s->n * s->cfg.tbl_pt_stride * 4; }
+  if (s->table) out[1] = (size_t)table_windows(s, s->cfg.tbl_c, s->cfg.tbl_glv) * s->n * s->cfg.tbl_pt_stride * 4;
   if (s->many.table) { const uint32_t bits = pc::curve_ops(s->curve).scalar_bits; out[1] += (size_t)pc::msm_num_windows(bits, pc::msm_choose_table_c(s->many.m, bits, 0)) * s->many.m * pb; }
   out[2] = s->fold_tbl ? (size_t)pc::curve_ops(s->curve).fold_rows * s->fold_half * pb : 0;
   out[3] = 0;

@@ -59,6 +59,57 @@ inline GlvSplit glv_decompose(const uint64_t* k) {
   return s;
 }
 
+// The same decomposition in 32-bit limbs, host AND device (the MSM's GLV table mode splits every scalar in its digit passes):
+// k (8 limbs, canonical) -> sign-magnitude halves m[0] = |k1|, m[1] = |k2| (5 limbs each) with k = +-|k1| +- |k2| lambda (mod r).
+// Bit for bit the values of glv_decompose above (CPU-stepped test against it and against Python big ints).
+// Bound: the basis vectors are below 2^128 (glv_constants.h), Babai rounding with truncated quotients leaves |k_i| below
+// (|a_1| + |a_2|) / 2 plus two basis vectors: under 2^130 for the three curves (GLV_HALF_BITS), so MSM_HALF windows of the signed
+// radix-2^c recoding cover it (msm_num_windows(GLV_HALF_BITS, c)).
+static constexpr uint32_t GLV_HALF_BITS = 130;
+template <class C>
+struct GlvHalves {
+  typedef typename GlvOf<C>::T G;
+  uint32_t m[2][5]; uint32_t neg[2];
+  static PC_HD uint32_t limb(const uint64_t* a, int i) { return (uint32_t)(a[i >> 1] >> ((i & 1) * 32)); }
+  // out[NA + NB] = a * b over 32-bit limbs (a given as 64-bit words)
+  template <int NA, int NB, class FA, class FB>
+  static PC_HD void mul32(FA fa, FB fb, uint32_t* out) {
+    PC_UNROLL for (int i = 0; i < NA + NB; i++) out[i] = 0;
+    PC_UNROLL for (int i = 0; i < NA; i++) {
+      uint64_t c = 0;
+      const uint32_t ai = fa(i);
+      PC_UNROLL for (int j = 0; j < NB; j++) { c += (uint64_t)ai * fb(j) + out[i + j]; out[i + j] = (uint32_t)c; c >>= 32; }
+      out[i + NB] = (uint32_t)c;
+    }
+  }
+  // acc (12 limbs, two's complement) += / -= t (12 limbs, magnitude)
+  static PC_HD void addsub(uint32_t* acc, const uint32_t* t, bool subtract) {
+    uint64_t c = subtract ? 1 : 0;
+    PC_UNROLL for (int i = 0; i < 12; i++) { c += (uint64_t)acc[i] + (subtract ? ~t[i] : t[i]); acc[i] = (uint32_t)c; c >>= 32; }
+  }
+  PC_HD void split(const uint32_t* k) {
+    uint32_t prod[18], c1[6], c2[6], t[12];
+    mul32<10, 8>([](int i) { return limb(G::G1, i); }, [&](int j) { return k[j]; }, prod);
+    PC_UNROLL for (int i = 0; i < 6; i++) c1[i] = prod[12 + i];                    // floor(g1 k / 2^384)
+    mul32<10, 8>([](int i) { return limb(G::G2, i); }, [&](int j) { return k[j]; }, prod);
+    PC_UNROLL for (int i = 0; i < 6; i++) c2[i] = prod[12 + i];
+    const bool c1neg = G::N1_NEG != 0, c2neg = G::N2_NEG != 0;
+    uint32_t k1[12], k2[12];
+    PC_UNROLL for (int i = 0; i < 12; i++) { k1[i] = i < 8 ? k[i] : 0u; k2[i] = 0u; }
+    mul32<6, 6>([&](int i) { return c1[i]; }, [](int j) { return limb(G::A1, j); }, t); addsub(k1, t, !(c1neg ^ (G::A1_NEG != 0)));
+    mul32<6, 6>([&](int i) { return c2[i]; }, [](int j) { return limb(G::A2, j); }, t); addsub(k1, t, !(c2neg ^ (G::A2_NEG != 0)));
+    mul32<6, 6>([&](int i) { return c1[i]; }, [](int j) { return limb(G::B1, j); }, t); addsub(k2, t, !(c1neg ^ (G::B1_NEG != 0)));
+    mul32<6, 6>([&](int i) { return c2[i]; }, [](int j) { return limb(G::B2, j); }, t); addsub(k2, t, !(c2neg ^ (G::B2_NEG != 0)));
+    fin(k1, 0); fin(k2, 1);
+  }
+  PC_HD void fin(uint32_t* v, int h) {
+    const uint32_t ng = v[11] >> 31;
+    if (ng) { uint64_t c = 1; PC_UNROLL for (int i = 0; i < 12; i++) { c += (uint64_t)(~v[i]); v[i] = (uint32_t)c; c >>= 32; } }
+    neg[h] = ng;
+    PC_UNROLL for (int i = 0; i < 5; i++) m[h][i] = v[i];
+  }
+};
+
 // key[i] = affine(key[i] + k * key[half + i]),  k = (+-k1) + (+-k2) * lambda
 template <class C>
 struct EcFoldGlvBody {

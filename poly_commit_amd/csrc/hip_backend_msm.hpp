@@ -29,24 +29,30 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   uint32_t* G = (uint32_t*)sort_ws; uint32_t* bintotal = G + gw; uint32_t* binbase = bintotal + nb1;
   uint2* records = (uint2*)((char*)sort_ws + rec_off);
   const size_t lds = (size_t)sg.NC * 4;
-  if (lds > 64 * 1024) {
-    PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  auto pass = [&](auto scatter_tag, const uint32_t* bb, uint2* rec, int threads) {
+    constexpr bool SC = decltype(scatter_tag)::value;
+    if (g.glv) {
+      if (lds > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, SC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_sort_pass<C, SC, true>), dim3(sg.nblocks), dim3(threads), lds, stream, sg, scalars, G, bb, rec);
+    } else {
+      if (lds > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, SC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_sort_pass<C, SC, false>), dim3(sg.nblocks), dim3(threads), lds, stream, sg, scalars, G, bb, rec);
+    }
+    PC_HIP_CHECK(hipGetLastError());
+  };
   // 512 workgroups cover the chip twice at most: with 256 lanes each that is 2 waves per SIMD for two passes that are bound
   // by DRAM latency (a scalar load, ~13 LDS atomics and as many 8-byte stores per lane and iteration).  16 waves per workgroup
   // give 8 per SIMD; the LDS histogram (<= 64 KiB) still allows two workgroups per CU.  PC_HIP_SORT_THREADS overrides (tuning).
+  // (the GLV passes hold the scalar split's temporaries: ~94 VGPRs, one 1024-lane workgroup per CU)
   static const int threads_env = []() { const char* e = getenv("PC_HIP_SORT_THREADS"); return e ? atoi(e) : 0; }();
   const int sort_threads = threads_env ? threads_env : (lds > 32 * 1024 || g.n >= 65536) ? 1024 : 256;
-  hipLaunchKernelGGL((k_sort_pass<C, false>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)nullptr, (uint2*)nullptr);
-  PC_HIP_CHECK(hipGetLastError());
+  pass(std::false_type{}, (const uint32_t*)nullptr, (uint2*)nullptr, sort_threads);
   mark();   // 1: digits + coarse histogram
   hipLaunchKernelGGL(k_sort_binscan, dim3((sg.NC + 15) / 16), dim3(256), 0, stream, G, sg.nblocks, sg.NC, bintotal);
   PC_HIP_CHECK(hipGetLastError());
   exclusive_scan_u32(bintotal, binbase, nb1);
   mark();   // 2: scans
-  hipLaunchKernelGGL((k_sort_pass<C, true>), dim3(sg.nblocks), dim3(sort_threads), lds, stream, sg, scalars, G, (const uint32_t*)binbase, records);
-  PC_HIP_CHECK(hipGetLastError());
+  pass(std::true_type{}, (const uint32_t*)binbase, records, sort_threads);
   hipLaunchKernelGGL(k_sort_fine, dim3(sg.NC), dim3(FT), 0, stream, sg, (const uint32_t*)binbase, (const uint2*)records, entries, offsets);
   PC_HIP_CHECK(hipGetLastError());
   mark();   // 3: coarse scatter + fine sort

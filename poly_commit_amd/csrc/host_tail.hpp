@@ -84,6 +84,7 @@ struct Xyzz64 {
   Fq X, Y, ZZ, ZZZ;
   static Xyzz64 infinity() { Xyzz64 r; r.X = r.Y = r.ZZ = r.ZZZ = Fq::zero(); return r; }
   bool is_inf() const { return ZZ.is_zero(); }
+  void store(uint32_t* p) const { X.store(p); Y.store(p + FW); ZZ.store(p + 2 * FW); ZZZ.store(p + 3 * FW); }
   static Xyzz64 load(const uint32_t* p) { Xyzz64 r; r.X = Fq::load(p); r.Y = Fq::load(p + FW); r.ZZ = Fq::load(p + 2 * FW); r.ZZZ = Fq::load(p + 3 * FW); return r; }
   Xyzz64 dbl() const {   // dbl-2008-s-1, a = 0
     if (is_inf() || Y.is_zero()) return infinity();

@@ -42,6 +42,7 @@
 #include <stdexcept>
 #include <vector>
 #include "ec.hpp"
+#include "glv.hpp"
 #include "host_tail.hpp"
 
 // "these values must have arrived": an empty asm that reads one register of every 16-byte load of an affine point (and
@@ -92,11 +93,17 @@ struct MsmGeom {
                        // bases (table mode only): sub-MSM s owns bucket set s, scalar i adds table[w][i mod m_sub]
   const uint64_t* scalar_tab;   // many-MSM mode, optional: device array of one scalar-vector address per sub-MSM (the
                                 // polynomials of a batch lie in separate buffers); null: one contiguous n x Fr array
+  uint32_t glv;        // table mode only: the table holds Wd / 2 windows (2^(c w) P_i for the 130-bit halves of the GLV split
+                       // k = k1 + k2 lambda); the digits of k1 go to bucket set 0, those of k2 to bucket set 1 with the SAME table
+                       // point, and phi (x -> beta x) is applied once to the reduced sum of set 1 (phi is a homomorphism):
+                       // half the table, the same number of additions.  Wd then counts the digits of BOTH halves.
   // address of scalar i = (sub, j)
   PC_HD const uint32_t* scalar_at(const uint32_t* scalars, uint32_t i, uint32_t sub, uint32_t j, int fr_words) const {
     return scalar_tab ? reinterpret_cast<const uint32_t*>(scalar_tab[sub]) + (size_t)j * fr_words : scalars + (size_t)i * fr_words;
   }
-  PC_HD uint32_t key_window(uint32_t w, uint32_t sub) const { return m_sub ? sub : tbl_stride ? 0u : w; }
+  PC_HD uint32_t sets_per_msm() const { return glv ? 2u : 1u; }
+  PC_HD uint32_t windows() const { return glv ? Wd / 2 : Wd; }      // windows a (half-)scalar is cut into
+  PC_HD uint32_t key_window(uint32_t w, uint32_t sub, uint32_t h = 0) const { return m_sub ? sub * sets_per_msm() + h : tbl_stride ? h : w; }
   PC_HD uint32_t base_index(uint32_t w, uint32_t j) const { return tbl_stride ? w * tbl_stride + base_off + j : base_off + j; }
   // scalar i -> (sub-MSM, position inside it)
   PC_HD void split(uint32_t i, uint32_t& sub, uint32_t& j) const { if (m_sub) { sub = i / m_sub; j = i - sub * m_sub; } else { sub = 0; j = i; } }
@@ -140,6 +147,56 @@ struct ScalarDigits {
   }
 };
 
+// the windows of a little-endian limb array (same shift register as ScalarDigits::for_each_window, any limb count)
+template <int NL, class F>
+PC_HD void for_each_window_limbs(const uint32_t* s, uint32_t c, uint32_t Wd, F f) {
+  uint64_t buf = 0; uint32_t have = 0, w = 0;
+  const uint32_t mask = (1u << c) - 1u;
+  PC_UNROLL for (int i = 0; i < NL; i++) {
+    if (w >= Wd) break;
+    buf |= (uint64_t)s[i] << have; have += 32;
+    while (have >= c && w < Wd) { f(w, (uint32_t)buf & mask); buf >>= c; have -= c; w++; }
+  }
+  while (w < Wd) { f(w, (uint32_t)buf & mask); buf >>= c; w++; }
+}
+
+// Every non-zero signed digit of one scalar: f(half, window, magnitude in [1, 2^(c-1)], negative).  Plain mode: half = 0, the
+// scalar's Wd windows.  GLV table mode (Geo::glv): the scalar is split into k1, k2 (GlvHalves), each half is recoded over
+// Wd / 2 windows and a half's own sign flips its digits' signs.  Geo: MsmGeom or SortGeom.
+template <class C, bool GLV, class Geo, class F>
+PC_HD void for_each_signed_digit_t(const Geo& g, const uint32_t* scalar, F f) {
+  typedef typename C::FrP FrP;
+  ScalarDigits<FrP> sd; sd.load(scalar, g.from_mont);
+  const uint32_t half = 1u << (g.c - 1);
+  if constexpr (!GLV) {
+    uint32_t carry = 0;
+    sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
+      const uint32_t raw = bits + carry;
+      carry = raw > half;
+      const uint32_t mag = carry ? (2 * half - raw) : raw;
+      if (mag) f(0u, w, mag, carry);
+    });
+  } else {
+    GlvHalves<C> hv; hv.split(sd.s);
+    PC_UNROLL for (int h = 0; h < 2; h++) {
+      uint32_t carry = 0;
+      const uint32_t ng = hv.neg[h];
+      for_each_window_limbs<5>(hv.m[h], g.c, g.Wd / 2, [&](uint32_t w, uint32_t bits) {
+        const uint32_t raw = bits + carry;
+        carry = raw > half;
+        const uint32_t mag = carry ? (2 * half - raw) : raw;
+        if (mag) f((uint32_t)h, w, mag, carry ^ ng);
+      });
+    }
+  }
+}
+// (the mode as a run-time flag: the CPU-stepped bodies and the atomic reference sort; the LDS sort's kernels take it as a template
+// parameter -- the split's temporaries would triple the registers of the plain passes, 33 -> 94 VGPRs, and halve their occupancy)
+template <class C, class Geo, class F>
+PC_HD void for_each_signed_digit(const Geo& g, const uint32_t* scalar, F f) {
+  if (g.glv) for_each_signed_digit_t<C, true>(g, scalar, f); else for_each_signed_digit_t<C, false>(g, scalar, f);
+}
+
 // ---------------------------------------------------------------------------------------
 // 1. digits + histogram
 // ---------------------------------------------------------------------------------------
@@ -150,14 +207,9 @@ struct DigitsHistBody {
   const uint32_t* scalars;   // n x FrP::N
   uint32_t* hist;            // NB counters (zeroed)
   PC_HD void operator()(uint32_t i) const {
-    uint32_t carry = 0, sub, j; g.split(i, sub, j);
-    ScalarDigits<FrP> sd; sd.load(g.scalar_at(scalars, i, sub, j, FrP::N), g.from_mont);
-    const uint32_t half = 1u << (g.c - 1);
-    sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
-      uint32_t raw = bits + carry;
-      carry = raw > half;
-      uint32_t mag = carry ? (2 * half - raw) : raw;
-      if (mag) atomic_inc_u32(hist + (size_t)g.key_window(w, sub) * g.nb_win + (mag - 1));
+    uint32_t sub, j; g.split(i, sub, j);
+    for_each_signed_digit<C>(g, g.scalar_at(scalars, i, sub, j, FrP::N), [&](uint32_t h, uint32_t w, uint32_t mag, uint32_t) {
+      atomic_inc_u32(hist + (size_t)g.key_window(w, sub, h) * g.nb_win + (mag - 1));
     });
   }
 };
@@ -173,17 +225,10 @@ struct ScatterBody {
   uint32_t* cursor;          // NB, initialised to the bucket offsets
   uint32_t* entries;         // M = offsets[NB] slots
   PC_HD void operator()(uint32_t i) const {
-    uint32_t carry = 0, sub, j; g.split(i, sub, j);
-    ScalarDigits<FrP> sd; sd.load(g.scalar_at(scalars, i, sub, j, FrP::N), g.from_mont);
-    const uint32_t half = 1u << (g.c - 1);
-    sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
-      uint32_t raw = bits + carry;
-      carry = raw > half;
-      uint32_t mag = carry ? (2 * half - raw) : raw;
-      if (mag) {
-        uint32_t pos = atomic_inc_u32(cursor + (size_t)g.key_window(w, sub) * g.nb_win + (mag - 1));
-        entries[pos] = g.base_index(w, j) | (carry << 31);
-      }
+    uint32_t sub, j; g.split(i, sub, j);
+    for_each_signed_digit<C>(g, g.scalar_at(scalars, i, sub, j, FrP::N), [&](uint32_t h, uint32_t w, uint32_t mag, uint32_t neg) {
+      const uint32_t pos = atomic_inc_u32(cursor + (size_t)g.key_window(w, sub, h) * g.nb_win + (mag - 1));
+      entries[pos] = g.base_index(w, j) | (neg << 31);
     });
   }
 };
@@ -533,8 +578,17 @@ void build_window_table_batched(Backend& be, const uint32_t* bases, uint32_t n, 
 }
 
 // window width for the table mode: n * (bits/c + 1) mixed adds against ~3 * 2^(c-1) reduction adds
-inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255, uint32_t min_top_bits = 5) {
+inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255, uint32_t min_top_bits = 5, bool glv = false) {
   uint32_t best = 8; double best_cost = 1e300;
+  if (glv) {      // two halves of ~128 significant bits (recoded over GLV_HALF_BITS), two bucket sets
+    for (uint32_t c = 8; c <= 23; c++) {
+      const uint32_t Wh = GLV_HALF_BITS / c + 1;
+      if (128 > (Wh - 1) * c ? 128 - (Wh - 1) * c < min_top_bits : true) continue;     // top digit of fewer than 5 (or no) significant bits
+      const double cost = 2.0 * (double)n * Wh + 6.0 * (double)((size_t)1 << (c - 1));
+      if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+  }
   for (uint32_t c = 8; c <= 23; c++) {
     // a top digit of fewer than 5 bits lands in <= 2^4 buckets with n / 2^4 .. n / 2 entries each: chains of hundreds of chunks
     // (c = 11, 12, 14 at 255 bits; 2^14 pairs with c = 14: 8 buckets of 2048 entries, 7 scan steps in k_accumulate).  The many-MSM
@@ -602,6 +656,7 @@ struct MsmConfig {
   const uint32_t* tbl = nullptr;
   uint32_t tbl_c = 0, tbl_stride = 0;
   uint32_t tbl_pt_stride = 0;            // words per table entry
+  bool tbl_glv = false;                  // the table covers the GLV_HALF_BITS-bit halves of the scalar split (MsmGeom::glv)
   size_t tbl_min_n = 0;
   // The shared bucket set is denser where the short top digit lands (56 instead of 24 entries per
   // bucket at n = 2^20, c = 20): chunks of M / 2^18 = 52 entries would cut those buckets twice, which
@@ -713,8 +768,8 @@ class MsmPlan {
       pp_[i] = (uint32_t*)be_.alloc(slots * (size_t)Pt::WORDS * 4);
       slots = 2 * (size_t)ceil_div_u32(slots, cfg_.T2);
     }
-    red_ = (uint32_t*)be_.alloc((red_max + subs_) * (size_t)Pt::WORDS * 4);       // + the folded sub-MSM results
-    result_host_ = (uint32_t*)be_.alloc_host(std::max<size_t>(res_max, subs_) * Pt::WORDS * 4);
+    red_ = (uint32_t*)be_.alloc((red_max + 2 * (size_t)subs_) * (size_t)Pt::WORDS * 4);       // + the folded results of every bucket set
+    result_host_ = (uint32_t*)be_.alloc_host(std::max<size_t>(res_max, 2 * (size_t)subs_) * Pt::WORDS * 4);
     red_points_ = red_max;
     } catch (...) { release(); throw; }   // a failed hipMalloc must not leak the earlier buffers
     plan_geometry(n_max);
@@ -839,6 +894,18 @@ class MsmPlan {
     if (subs_) {      // subs_ affine points: batch-normalise the folded XYZZ results (one inversion in all)
       if (pending_empty_) { for (size_t i = 0; i < (size_t)subs_ * AW; i++) out_host[i] = 0; return; }
       be_.wait_done();
+      if (g_.glv) {      // sub-MSM k = set 2k + phi(set 2k + 1)
+        typedef host64::Xyzz64<C> P64;
+        std::vector<uint32_t> sum((size_t)subs_ * Pt::WORDS);
+        for (uint32_t k = 0; k < subs_; k++) {
+          P64 a = P64::load(result_host_ + (size_t)(2 * k) * Pt::WORDS), b = P64::load(result_host_ + (size_t)(2 * k + 1) * Pt::WORDS);
+          b.X = b.X.mul(P64::Fq::load(GlvOf<C>::T::BETA_MONT));
+          a.add(b);
+          a.store(&sum[(size_t)k * Pt::WORDS]);
+        }
+        host64::batch_to_affine<C>(sum.data(), subs_, out_host);
+        return;
+      }
       host64::batch_to_affine<C>(result_host_, subs_, out_host);
       return;
     }
@@ -853,7 +920,10 @@ class MsmPlan {
     const bool tbl = subs_ || (cfg_.tbl && cfg_.tbl_c && n >= cfg_.tbl_min_n);
     uint32_t c = tbl ? cfg_.tbl_c : cfg_.c ? cfg_.c : msm_choose_c(n, FrP::BITS);
     if (c < 2 || c > 24) throw std::runtime_error("MsmPlan: window width out of range (2..24)");   // ScalarDigits' shift register, the sort passes
-    g_.c = c; g_.Wd = msm_num_windows(FrP::BITS, c); g_.W = subs_ ? subs_ : tbl ? 1u : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u; g_.m_sub = 0;
+    const bool glv = tbl && cfg_.tbl_glv;
+    g_.glv = glv ? 1u : 0u;
+    g_.c = c; g_.Wd = glv ? 2 * msm_num_windows(GLV_HALF_BITS, c) : msm_num_windows(FrP::BITS, c);
+    g_.W = subs_ ? subs_ * (glv ? 2u : 1u) : tbl ? (glv ? 2u : 1u) : g_.Wd; g_.tbl_stride = tbl ? cfg_.tbl_stride : 0u; g_.m_sub = 0;
     g_.nb_win = 1u << (c - 1); g_.NB = g_.W * g_.nb_win;
     g_.pt_stride = tbl ? cfg_.tbl_pt_stride : (uint32_t)AW;
     g_.n = (uint32_t)n; g_.base_off = 0; g_.from_mont = 0; g_.T = 0; g_.T2 = cfg_.T2; g_.T2b = cfg_.T2b; g_.scalar_tab = nullptr;
@@ -898,14 +968,25 @@ class MsmPlan {
   // Horner over (level, window) on the host.  P_j[w] has weight 2^(c*w + k_0 + ... + k_{j-1}).
   void host_tail(uint32_t* out_host) {
     const uint32_t L = n_levels_, W = g_.W;
+    // classic mode: bucket set w is window w, weight 2^(c w); table mode: the sets share the weights (one set, or the two of the
+    // GLV split: the points of set 1 go through phi -- X * beta in XYZZ coordinates -- before the one Horner chain)
+    const uint32_t cw = g_.tbl_stride ? 0u : g_.c;
+    const size_t narr = L == 0 ? 1 : arr_exp_.size();
+    if (g_.glv) {
+      typedef host64::Xyzz64<C> P64;
+      for (size_t a = 0; a < narr; a++) {
+        uint32_t* p = &result_host_[(a * W + 1) * Pt::WORDS];
+        P64::Fq::load(p).mul(P64::Fq::load(GlvOf<C>::T::BETA_MONT)).store(p);
+      }
+    }
     std::vector<host64::WeightedPoint> items;
     if (L == 0) {   // c == 1: one bucket per window, weight 1
-      for (uint32_t w = 0; w < W; w++) items.push_back({g_.c * w, &result_host_[(size_t)w * Pt::WORDS]});
+      for (uint32_t w = 0; w < W; w++) items.push_back({cw * w, &result_host_[(size_t)w * Pt::WORDS]});
     } else {
       // arrays after S of the last level, weights 2^(c*w + arr_exp_[a])
       for (size_t a = 0; a < arr_exp_.size(); a++)
         for (uint32_t w = 0; w < W; w++)
-          items.push_back({g_.c * w + arr_exp_[a], &result_host_[(a * W + w) * Pt::WORDS]});
+          items.push_back({cw * w + arr_exp_[a], &result_host_[(a * W + w) * Pt::WORDS]});
     }
     host64::horner_to_affine<C>(items, out_host);
   }

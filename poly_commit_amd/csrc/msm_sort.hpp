@@ -21,7 +21,7 @@
 namespace pc {
 
 struct SortGeom {
-  uint32_t n, c, W, nb_win, NB, base_off, from_mont, Wd, tbl_stride, m_sub;
+  uint32_t n, c, W, nb_win, NB, base_off, from_mont, Wd, tbl_stride, m_sub, glv;
   uint32_t fine_bits, cb, ncw /* coarse bins per window */, NC /* total coarse bins */, S /* scalars per block */, nblocks;
   uint32_t top_w, top_fine_bits;   // the last window only uses 2^(tb-1) buckets: it gets its own (smaller) fine width
   const uint64_t* scalar_tab;      // see MsmGeom
@@ -30,7 +30,7 @@ struct SortGeom {
 inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   SortGeom s;
   s.n = g.n; s.c = g.c; s.W = g.W; s.nb_win = g.nb_win; s.NB = g.NB; s.base_off = g.base_off; s.from_mont = g.from_mont;
-  s.Wd = g.Wd; s.tbl_stride = g.tbl_stride; s.m_sub = g.m_sub; s.scalar_tab = g.scalar_tab;
+  s.Wd = g.Wd; s.tbl_stride = g.tbl_stride; s.m_sub = g.m_sub; s.scalar_tab = g.scalar_tab; s.glv = g.glv;
   uint32_t bbits = g.c - 1;                               // bucket bits per window
   uint32_t cb_max = 0; while ((2u << cb_max) * g.W <= 32768u) cb_max++;
   // fine width: buckets per coarse bin = 2^fine (<= 2048, the LDS histogram of the fine pass).  Fewer, larger coarse bins
@@ -59,7 +59,7 @@ inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   return s;
 }
 
-template <class C, bool SCATTER>
+template <class C, bool SCATTER, bool GLV = false>
 __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t* scalars, uint32_t* G, const uint32_t* binbase,
                                                   uint2* records) {
   typedef typename C::FrP FrP;
@@ -69,25 +69,20 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
   __syncthreads();
   const uint32_t lo = blockIdx.x * sg.S;
   const uint32_t hi = (sg.n - lo > sg.S) ? lo + sg.S : sg.n;
-  const uint32_t half = 1u << (sg.c - 1);
+  constexpr uint32_t sets = GLV ? 2u : 1u;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    uint32_t carry = 0, sub = 0, j = i;
-    if (sg.m_sub) { sub = i / sg.m_sub; j = i - sub * sg.m_sub; }      // many-MSM mode: bucket set `sub`
-    ScalarDigits<FrP> sd;
-    sd.load(sg.scalar_tab ? reinterpret_cast<const uint32_t*>(sg.scalar_tab[sub]) + (size_t)j * FrP::N : scalars + (size_t)i * FrP::N, sg.from_mont);
-    sd.for_each_window(sg.c, sg.Wd, [&](uint32_t w, uint32_t bits) {
-      uint32_t raw = bits + carry;
-      carry = raw > half;
-      uint32_t mag = carry ? (2 * half - raw) : raw;
-      if (mag) {
-        const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
-        uint32_t b = mag - 1, cbin = b >> fb;
-        if (cbin >= sg.ncw) cbin = sg.ncw - 1;           // (top window, magnitude 2^(tb-1): one past its range)
-        uint32_t bin = (sg.m_sub ? sub * sg.ncw : sg.tbl_stride ? 0u : w * sg.ncw) + cbin;
-        uint32_t pos = atomicAdd(&cnt[bin], 1u);
-        const uint32_t base = sg.tbl_stride ? w * sg.tbl_stride + sg.base_off + j : sg.base_off + j;
-        if (SCATTER) records[pos] = make_uint2(base | (carry << 31), b - (cbin << fb));
-      }
+    uint32_t sub = 0, j = i;
+    if (sg.m_sub) { sub = i / sg.m_sub; j = i - sub * sg.m_sub; }      // many-MSM mode: bucket set(s) of `sub`
+    const uint32_t* sp = sg.scalar_tab ? reinterpret_cast<const uint32_t*>(sg.scalar_tab[sub]) + (size_t)j * FrP::N : scalars + (size_t)i * FrP::N;
+    for_each_signed_digit_t<C, GLV>(sg, sp, [&](uint32_t h, uint32_t w, uint32_t mag, uint32_t neg) {
+      const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
+      uint32_t b = mag - 1, cbin = b >> fb;
+      if (cbin >= sg.ncw) cbin = sg.ncw - 1;           // (top window, magnitude 2^(tb-1): one past its range)
+      const uint32_t set = sg.m_sub ? sub * sets + h : sg.tbl_stride ? h : w;      // MsmGeom::key_window
+      const uint32_t bin = set * sg.ncw + cbin;
+      uint32_t pos = atomicAdd(&cnt[bin], 1u);
+      const uint32_t base = sg.tbl_stride ? w * sg.tbl_stride + sg.base_off + j : sg.base_off + j;
+      if (SCATTER) records[pos] = make_uint2(base | (neg << 31), b - (cbin << fb));
     });
   }
   if (!SCATTER) {

@@ -80,6 +80,8 @@ class HipEngine:
         self.marks = []      # absolute phase boundaries of the same MSMs (Context.last_msm_marks_ms)
         self.blocking = False   # True: every MSM is the BLOCKING pc_hip_msm call (bench.py --inflight 0)
 
+    glv_table = None     # None: the library's policy; True / False: force the GLV (half-size) / the full window table
+
     def load_srs(self, bases, precompute=False, n=None):
         """bases: host array of affine points, or a device pointer with `n` (a chunk generated on the device)."""
         self.srs = self.ctx.upload_srs(self.curve, bases if isinstance(bases, int) else np.ascontiguousarray(bases), n=n)
@@ -87,7 +89,7 @@ class HipEngine:
         if precompute:          # window table in HBM (pc_hip_srs_precompute): once per key, like the upload
             import time
             t0 = time.perf_counter()
-            self.srs.precompute()
+            self.srs.precompute(glv=self.glv_table)
             self.precompute_ms = (time.perf_counter() - t0) * 1e3
         # The SRS's MSM pipelines (streams + workspace, GBs for a large SRS) are created on first use:
         # touch all of them now so that no later call pays for it.

@@ -105,17 +105,41 @@ extern "C" int emu_msm_sized(int curve, const uint32_t* bases, size_t n_srs, con
 // plan with one shared bucket set.  n_srs bases, MSM over [base_off, base_off + n).
 template <class C>
 static void run_table(const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int K0,
-                      int from_mont, uint32_t* out) {
+                      int from_mont, uint32_t* out, bool glv = false) {
   CpuStepBackend be;
   constexpr int AW = 2 * pc::Fd<typename C::FqP>::N;
-  const uint32_t Wd = pc::msm_num_windows(C::FrP::BITS, (uint32_t)c);
+  const uint32_t Wd = pc::msm_num_windows(glv ? pc::GLV_HALF_BITS : (uint32_t)C::FrP::BITS, (uint32_t)c);      // GLV: the table of the 130-bit halves
   const uint32_t stride = AW + 8;             // padded entries, as the 128-byte-aligned BLS12-381 table
   std::vector<uint32_t> table((size_t)Wd * n_srs * stride);
   { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data(), stride}; be.launch(b, n_srs); }
   pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_pt_stride = stride; cfg.tbl_min_n = 1;
+  cfg.tbl_glv = glv;
   if (K0) { cfg.K0 = K0; cfg.K1 = K0 == 2 ? 4 : K0; cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3; }
   pc::MsmPlan<C, CpuStepBackend> plan(be, n_srs, cfg);
   plan.run(bases, base_off, scalars, n, from_mont != 0, out);
+}
+extern "C" void emu_msm_table_glv(int curve, const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off,
+                                  int c, int K0, int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: run_table<pc_curve_bls12_381>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out, true); break;
+    case 1: run_table<pc_curve_bn254>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out, true); break;
+    case 2: run_table<pc_curve_pallas>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out, true); break;
+  }
+}
+// the GLV split in 32-bit limbs (the device's) against the 64-bit host version: out = |k1| (5 limbs) | |k2| (5) | neg1 | neg2; returns 1 if they agree
+template <class C> static int glv_split_check(const uint32_t* k, uint32_t* out) {
+  pc::GlvHalves<C> hv; hv.split(k);
+  uint64_t k64[4]; memcpy(k64, k, 32);
+  const pc::GlvSplit ref = pc::glv_decompose<typename pc::GlvOf<C>::T>(k64);
+  memcpy(out, hv.m[0], 20); memcpy(out + 5, hv.m[1], 20); out[10] = hv.neg[0]; out[11] = hv.neg[1];
+  return memcmp(hv.m[0], ref.k1, 20) == 0 && memcmp(hv.m[1], ref.k2, 20) == 0 && hv.neg[0] == ref.neg1 && hv.neg[1] == ref.neg2;
+}
+extern "C" int emu_glv_split(int curve, const uint32_t* k, uint32_t* out) {
+  switch (curve) {
+    case 0: return glv_split_check<pc_curve_bls12_381>(k, out);
+    case 1: return glv_split_check<pc_curve_bn254>(k, out);
+    default: return glv_split_check<pc_curve_pallas>(k, out);
+  }
 }
 extern "C" void emu_msm_table(int curve, const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off,
                               int c, int K0, int from_mont, uint32_t* out) {
@@ -139,6 +163,8 @@ static void run_many(const uint32_t* bases, size_t m, const uint32_t* scalars, s
   pc::MsmPlan<C, CpuStepBackend> plan(be, B * m, cfg, (uint32_t)B);
   plan.run(bases, 0, scalars, B * m, from_mont != 0, out);
 }
+static bool g_many_glv = false;      // emu_msm_many_vectors: the key's table is the GLV (half-scalar) one
+extern "C" void emu_set_many_glv(int on) { g_many_glv = on != 0; }
 // the same with the scalar vectors in separate buffers and fewer vectors than bucket sets (pc_hip_msm_batch's fast path)
 template <class C>
 static void run_many_vectors(const uint32_t* bases, size_t n_srs, size_t base_off, size_t m, const uint32_t* const* vecs, size_t count, size_t B, int c,
@@ -149,6 +175,7 @@ static void run_many_vectors(const uint32_t* bases, size_t n_srs, size_t base_of
   std::vector<uint32_t> table((size_t)Wd * n_srs * AW);
   { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data(), (uint32_t)AW}; be.launch(b, n_srs); }
   pc::MsmConfig cfg; cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_pt_stride = AW; cfg.tbl_min_n = 1;
+  cfg.tbl_glv = g_many_glv;
   cfg.tbl_K0 = 4; cfg.K1 = 16; cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3;
   pc::MsmPlan<C, CpuStepBackend> plan(be, B * m, cfg, (uint32_t)B);
   std::vector<uint64_t> ptrs(count);

@@ -261,6 +261,70 @@ def test_msm_window_table_mode_stepped(curve):
     assert not run_msm_table(curve, b, np.zeros((n, 4), dtype=np.uint64), 5).any()
 
 
+def run_msm_table_glv(curve, b, s, c, K0=0, base_off=0, from_mont=0):
+    out = np.zeros(2 * O.fq_limbs(curve), dtype=np.uint64)
+    emu().emu_msm_table_glv(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(len(b)), p32(s.view(np.uint32)), C.c_size_t(len(s)),
+                            base_off, c, K0, from_mont, p32(out.view(np.uint32)))
+    return out
+
+
+GLV_LAMBDA = {"bls12_381": 0xac45a4010001a40200000000ffffffff,
+              "bn254": 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd,
+              "pallas": 0x06819a58283e528e511db4d81cf70f5a0fed467d47c033af2aa9d2e050aa0e4f}
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_glv_split_32bit_limbs(curve):
+    """GlvHalves::split (what the MSM's digit passes run on the device): k = +-|k1| +- |k2| lambda (mod r) with both magnitudes below
+    2^130 (GLV_HALF_BITS: six windows of 22 bits), identical to the 64-bit host decomposition -- on random, small, and extreme
+    scalars.  lambda from glv_constants.h: lambda^2 + lambda + 1 = 0 (mod r)."""
+    r = R.FIELDS[R.CURVES[curve]["fr"]]["p"]
+    lam = GLV_LAMBDA[curve]
+    assert (lam * lam + lam + 1) % r == 0
+    rnd = random.Random(5)
+    ks = [0, 1, 2, r - 1, r - 2, lam, lam + 1, r - lam, (1 << 128) - 1, 1 << 128, (1 << 200) + 12345, r >> 1] + [rnd.randrange(r) for _ in range(300)]
+    worst = 0
+    for k in ks:
+        kin = O.ints_to_limbs([k], 4)[0]
+        out = np.zeros(12, dtype=np.uint32)
+        same = emu().emu_glv_split(O.CURVES[curve], p32(kin.view(np.uint32)), p32(out))
+        assert same == 1, hex(k)
+        k1 = sum(int(out[i]) << (32 * i) for i in range(5)); k2 = sum(int(out[5 + i]) << (32 * i) for i in range(5))
+        s1 = -1 if out[10] else 1; s2 = -1 if out[11] else 1
+        assert (s1 * k1 + s2 * k2 * lam - k) % r == 0, hex(k)
+        worst = max(worst, k1.bit_length(), k2.bit_length())
+    assert worst <= 129, worst
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_glv_table_mode_stepped(curve):
+    """The GLV form of the window table (MsmGeom::glv): the table holds the windows of the 130-bit halves only, the digits of k1 go to
+    bucket set 0 and those of k2 to set 1 with the SAME table point, phi is applied once to the reduced sum of set 1.  Same point as
+    the naive MSM: offsets, infinity and repeated bases, edge scalars (the halves' signs, zero halves, r - 1), Montgomery input,
+    cooperative and serial reduction plans."""
+    n = 150
+    r = R.FIELDS[curve + "_fr"]["p"]
+    lam = GLV_LAMBDA[curve]
+    b = O.gen_bases(curve, n)
+    b[5] = 0
+    b[11] = b[10]
+    s = O.gen_scalars(curve, 17, n)
+    want = O.msm_naive(curve, b, s)
+    for c, K0 in ((4, 2), (7, 0), (9, 16), (12, 4), (16, 0), (22, 0)):
+        assert (run_msm_table_glv(curve, b, s, c, K0) == want).all(), (c, K0)
+    edge = [0, 1, 2, r - 1, r - 2, lam % r, (lam + 1) % r, (r - lam) % r, (1 << 127), (1 << 128) - 1, (1 << 129) + 7, r >> 1, 3 * lam % r, (lam * lam) % r]
+    sc = O.ints_to_limbs([edge[i % len(edge)] for i in range(n)], 4)
+    assert (run_msm_table_glv(curve, b, sc, 8) == O.msm_naive(curve, b, sc)).all()
+    assert (run_msm_table_glv(curve, b, sc, 13, 4) == O.msm_naive(curve, b, sc)).all()
+    top = O.ints_to_limbs([r - 1] * n, 4)
+    assert (run_msm_table_glv(curve, b, top, 8) == O.msm_naive(curve, b, top)).all()
+    assert (run_msm_table_glv(curve, b, np.ascontiguousarray(s[:100]), 6, 2, base_off=50) == O.msm_naive(curve, b[50:], s[:100])).all()
+    assert (run_msm_table_glv(curve, b, O.f_to_mont(curve, 1, s), 10, 0, from_mont=1) == want).all()
+    assert not run_msm_table_glv(curve, b, np.zeros((n, 4), dtype=np.uint64), 5).any()
+    same = np.ascontiguousarray(np.repeat(s[:1], n, axis=0))
+    assert (run_msm_table_glv(curve, b, same, 6, 2) == O.msm_naive(curve, b, same)).all()
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_msm_many_mode_stepped(curve):
     """pc_hip_msm_many (Hyrax's one-MSM-per-matrix-row, hyrax/mod.rs:233-242): B MSMs over the same m
@@ -546,12 +610,15 @@ def test_pallas_square_root_tonelli_shanks_rejects_non_residues():
         assert px == x and (py * py - x ** 3 - 5) % p == 0 and (py > p - py) == bool(flag)
 
 
+@pytest.mark.parametrize("glv", [0, 1])
 @pytest.mark.parametrize("curve", CURVES)
-def test_msm_batch_over_key_table_stepped(curve):
+def test_msm_batch_over_key_table_stepped(curve, glv):
     """pc_hip_msm_batch's fast path: several polynomials of equal length in SEPARATE buffers go through one many-MSM
     pass over the key's own window table (bucket set k = polynomial k), here with fewer polynomials than bucket sets,
-    a base offset and Montgomery scalars."""
+    a base offset and Montgomery scalars.  glv = 1: the key's table is the GLV one (two bucket sets per polynomial, phi on the
+    second set's sum before the pair is added on the host)."""
     n_srs, off, m, B, count, c = 60, 7, 40, 4, 3, 6
+    emu().emu_set_many_glv(glv)
     b = O.gen_bases(curve, n_srs)
     vecs = [O.gen_scalars(curve, 0x7A0 + k, m) for k in range(count)]
     mont = [O.f_to_mont(curve, 1, v) for v in vecs]
@@ -559,6 +626,7 @@ def test_msm_batch_over_key_table_stepped(curve):
     out = np.zeros((B, 2 * O.fq_limbs(curve)), dtype=np.uint64)
     emu().emu_msm_many_vectors(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(n_srs), C.c_size_t(off), C.c_size_t(m), arr, C.c_size_t(count),
                                C.c_size_t(B), c, 1, p32(out.view(np.uint32)))
+    emu().emu_set_many_glv(0)
     for k in range(count):
         assert (out[k] == O.msm_naive(curve, np.ascontiguousarray(b[off:off + m]), vecs[k])).all(), k
     assert not out[count:].any()
