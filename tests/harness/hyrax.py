@@ -16,8 +16,8 @@ Field elements are Montgomery limbs ((4,) uint64), points x||y; the matrix stays
 """
 import numpy as np
 
-from . import _ffi
-from .sharded import FR_MODULUS, _R, _int_to_limbs, _limbs_to_int
+from poly_commit_amd import _ffi
+from poly_commit_amd.sharded import FR_MODULUS, _R, _int_to_limbs, _limbs_to_int
 
 
 class InvalidNumberOfVariables(ValueError):

@@ -18,7 +18,7 @@ import math
 
 import numpy as np
 
-from .sharded import FR_MODULUS, _R, _limbs_to_int
+from poly_commit_amd.sharded import FR_MODULUS, _R, _limbs_to_int
 
 
 class InvalidCommitment(ValueError):

@@ -1,4 +1,4 @@
-"""GPU parity for HyraxPC (poly-commit/src/hyrax/mod.rs) through poly_commit_amd/hyrax.py: the row commitments (one
+"""GPU parity for HyraxPC (poly-commit/src/hyrax/mod.rs) through tests/harness/hyrax.py: the row commitments (one
 pc_hip_msm_many pass), the opening proof and the verifier against the Python big-int restatement in oracle/pyref.py,
 bit for bit; at the 2^20-evaluation size (1024 rows of 1024 pairs) through the verifier's equations and sampled rows."""
 import numpy as np
@@ -25,7 +25,7 @@ def _inputs(curve, n_vars, seed=0x4A0):
 @pytest.mark.parametrize("curve,n_vars", [("bn254", 8), ("pallas", 10), ("bls12_381", 6), ("bn254", 2)])
 def test_hyrax_commit_open_check_vs_oracle(ctx, curve, n_vars):
     import torch
-    from poly_commit_amd import hyrax
+    from harness import hyrax
     dim, pts, evals, rands, point, rnd, c = _inputs(curve, n_vars)
     key_i, h_i = O.array_to_points(curve, pts[:dim]), O.array_to_points(curve, pts[dim:dim + 1])[0]
     want_rows, mat_i = R.hyrax_commit(curve, key_i, h_i, evals, rands)
@@ -66,7 +66,7 @@ def test_hyrax_2p20_evaluations_bn254(ctx):
     """BASELINE-scale Hyrax: 2^20 evaluations = 1024 row commitments of 1024 pairs (+ the hiding term) in one
     pc_hip_msm_many pass; sampled rows against the oracle's Pippenger, the whole opening through the verifier."""
     import torch
-    from poly_commit_amd import hyrax
+    from harness import hyrax
     curve, n_vars = "bn254", 20
     dim = 1 << (n_vars // 2)
     pts = O.gen_bases(curve, dim + 1)

@@ -1,4 +1,4 @@
-"""GPU parity for LinearCodePCS (univariate Ligero) commit / open / check through poly_commit_amd/ligero.py against the
+"""GPU parity for LinearCodePCS (univariate Ligero) commit / open / check through tests/harness/ligero.py against the
 Python restatement in oracle/pyref.py: commitment (root, shape), opening proof (v, queried columns, Merkle paths,
 well-formedness vector) bit for bit; then both verifiers on honest and altered proofs."""
 import numpy as np
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("curve,poly_len,wf", [("bn254", 300, True), ("bls12_381", 1 << 12, False), ("bls12_381", 5000, True)])
 def test_ligero_commit_open_check_vs_oracle(ctx, curve, poly_len, wf):
     import torch
-    from poly_commit_amd import ligero
+    from harness import ligero
     fr = R.CURVES[curve]["fr"]
     p = R.FIELDS[fr]["p"]
     co = R.gen_scalars(fr, 0x810, poly_len)
@@ -55,7 +55,7 @@ def test_multilinear_ligero_device(ctx):
     """MultilinearLigero through the same device entry points (rho_inv = 2, tensor_vec tensors): opening and both verifiers
     against the restatement and the multilinear extension's value."""
     import torch
-    from poly_commit_amd import ligero
+    from harness import ligero
     curve, n_vars = "bls12_381", 10
     fr = R.CURVES[curve]["fr"]
     evals = R.gen_scalars(fr, 0x830, 1 << n_vars)

@@ -1,4 +1,4 @@
-"""Time HyraxPC commit / open / check through poly_commit_amd/hyrax.py on one GPU (bn254, 2^n evaluations).
+"""Time HyraxPC commit / open / check through tests/harness/hyrax.py on one GPU (bn254, 2^n evaluations).
 Prints one JSON line per size.  Inputs are generated with the oracle's generators; nothing is checked here
 (tests/test_hyrax_gpu.py does that)."""
 import json
@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, ".."))
 sys.path.insert(0, os.path.join(HERE, "..", "tests"))
 import poly_commit_amd as pc  # noqa: E402
-from poly_commit_amd import hyrax  # noqa: E402
+from harness import hyrax  # noqa: E402
 import oracle_lib as O  # noqa: E402  (input generation only)
 
 
