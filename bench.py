@@ -235,7 +235,7 @@ def oracle_scalar_mul(curve, g_xy, k):
 
 
 def pmc_traffic(key, field="accumulate_hbm_bytes_per_launch"):
-    """HBM bytes per launch from the committed PMC summary (profiles/r03_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 note of
+    """HBM bytes per launch from the committed PMC summary (profiles/r04_pmc_traffic.json, else r03: FETCH_SIZE doubled per the gfx950 note of
     MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of the same workload -- NOT a measurement of this run)."""
     for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
@@ -259,7 +259,7 @@ def union_ms(intervals):
 
 
 _MADD_PEAK = None
-_MADD_COMMITTED = {"bls12_381": 6.56e9, "bn254": 14.0e9, "pallas": 15.85e9}      # profiles/r04_microbench.txt
+_MADD_COMMITTED = {"bls12_381": 6.68e9, "bn254": 14.07e9, "pallas": 15.97e9}      # profiles/r04_microbench.txt
 
 
 def madd_peak(curve):
@@ -338,7 +338,7 @@ def cpu_baseline(curve, srs, log_d, budget_s=30.0):
     single-thread rate at 2^20 with ark-ec's own window rule (the per-core figure: ark-ec parallelises over windows only)."""
     import oracle_lib as O
     cores = effective_cores()
-    n0 = 1 << min(16, log_d)
+    n0 = 1 << min(18, log_d)
     b = srs.read(1, n0)
     s = O.gen_scalars(curve, 1, n0)
     t = time.perf_counter()
@@ -348,11 +348,11 @@ def cpu_baseline(curve, srs, log_d, budget_s=30.0):
     O.msm_pippenger(curve, b, s, 1, 2)
     rate1 = n0 / max(time.perf_counter() - t, 1e-6)
     # single thread: 2^20 if that fits a third of the budget (the rate per pair falls slowly with the size: wider windows)
-    lg1 = min(16, log_d)
+    lg1 = min(18, log_d)
     while lg1 < min(20, log_d) and (1 << (lg1 + 1)) / rate1 < budget_s / 3:
         lg1 += 1
-    lg = min(16, log_d)
-    while lg < log_d and (1 << (lg + 1)) / rate * 1.5 < budget_s / 2:
+    lg = min(18, log_d)
+    while lg < log_d and (1 << (lg + 1)) / rate * 1.2 < budget_s / 2:
         lg += 1
     n = 1 << lg
     b = srs.read(1, n)
@@ -576,7 +576,7 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
     #   commit = pc_hip_msm(PC_MEM_HOST, MONTGOMERY)                             (kzg10/mod.rs:157-210)
     #   open   = pc_hip_witness_poly(host -> device) + pc_hip_msm(PC_MEM_DEVICE) (kzg10/mod.rs:287-310)
     trait = None
-    if world == 1:
+    if world == 1 and not args.no_trait:
         hostc = host_u64(host if host is not None else coeffs)
         zm = mont_limbs(curve, S.z)
         reps = 3 if log_degree >= 22 else 10
@@ -668,8 +668,8 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                      "traffic": pmc_traffic(f"{curve}:2^{log_degree}:{'table' if args.precompute else 'table-free'}") if world == 1 else None,
-                     "traffic_source": "profiles/r03_pmc_traffic.json: PMC FETCH_SIZE (doubled per the gfx950 note of the guide) + WRITE_SIZE per launch, "
-                                       "separate rocprofv3 --pmc passes of this workload on an earlier box -- the one figure of this block that is NOT "
+                     "traffic_source": "profiles/r04_pmc_traffic.json: PMC FETCH_SIZE (doubled per the gfx950 note of the guide) + WRITE_SIZE per launch, "
+                                       "separate rocprofv3 --pmc passes of this workload on an earlier box (tools/gpu_full_run.sh) -- the one figure of this block that is NOT "
                                        "measured in this run (null when that size / table mode was not profiled); undoubled FETCH_SIZE is about half: "
                                        "for this kernel's 16-byte gathers the raw figure is the plausible one",
                      "kernel": "pc::k_accumulate (bucket accumulation), launched twice per step (commit MSM, open MSM)",
@@ -1035,7 +1035,7 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS if achieved else None,
                          "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
-                         "traffic_source": "profiles/r03_pmc_traffic.json (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
+                         "traffic_source": "profiles/r04_pmc_traffic.json (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
                          "kernel": "pc::k_ntt_pass_a + pc::k_ntt_pass_b (one batched NTT = both), hipEvent brackets on the context's stream inside the timed region",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "parity": {"horner_spot_checks_ok": bool(ok), "one_row_vs_oracle_ntt_ok": ok_row,
@@ -1133,6 +1133,7 @@ def main():
     ap.add_argument("--curve", default="bls12_381")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-coefficients (H2D-inclusive) leg")
+    ap.add_argument("--no-trait", action="store_true", help="skip the trait-shaped leg (profile runs: its half-size launches would enter the per-kernel averages)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=2,

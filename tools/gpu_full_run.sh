@@ -27,8 +27,8 @@ timeout -k 10 300 python tools/hyrax_timing.py 2>/dev/null | grep workload > gpu
 PC_SWEEP_LOGS=8,10,12,14,16,18,20,22 timeout -k 10 300 python tools/msm_size_sweep.py 2>/dev/null | tail -1 > gpurun_out/d_msm_size_sweep.json
 
 cd /tmp && export TMPDIR=/tmp
-B24="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --inflight 0 --secondary-log-degree 0 --workloads none"
-B20="python $R/bench.py --log-degree 20 --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --inflight 0 --secondary-log-degree 0 --workloads none"
+B24="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-trait --inflight 0 --secondary-log-degree 0 --workloads none"
+B20="python $R/bench.py --log-degree 20 --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-trait --inflight 0 --secondary-log-degree 0 --workloads none"
 NTT="python $R/bench.py --workload ntt --steps 3 --warmup 1"
 BATCH="python $R/bench.py --workload batch --steps 2 --warmup 1"
 PAL="python $R/tools/msm_one.py pallas 22 6"
