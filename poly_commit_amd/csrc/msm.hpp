@@ -60,6 +60,12 @@
 #define PC_ARRIVED_WORD(W) ((void)0)
 #endif
 
+// measurement switch (never set in the product build): PC_ACC_DEBUG_IDX_MASK=m gathers table point (index & m) instead of the entry's --
+// wrong results, but the accumulate kernel then runs with its gathers in cache: the bound on what a deeper prefetch could still buy
+#ifndef PC_ACC_DEBUG_IDX_MASK
+#define PC_ACC_DEBUG_IDX_MASK 0x7fffffffu
+#endif
+
 namespace pc {
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -304,7 +310,7 @@ struct AccumulateBody {
       bool first = true;
       uint32_t val = entries[s];
       uint32_t nval = (s + 1 < e) ? entries[s + 1] : val;
-      AffD<C> pt = AffD<C>::load(bases + (size_t)(val & 0x7fffffffu) * g.pt_stride);
+      AffD<C> pt = AffD<C>::load(bases + (size_t)(val & PC_ACC_DEBUG_IDX_MASK) * g.pt_stride);
       for (uint32_t p = s; p < e; p++) {
         // Everything in flight here (the base, the index and the bucket offset gathered during the previous addition) has had a
         // whole addition to arrive: wait for it NOW, before the boundary block below issues its bucket stores.  The memory counter is
@@ -331,7 +337,7 @@ struct AccumulateBody {
         // the compiler gathered into scratch registers and assembled `npt` from them with copies, i.e. waited for the gather it had
         // just issued -- s_waitcnt vmcnt(3) / vmcnt(2) right behind the four loads of the 8-limb kernels, a memory round trip in
         // EVERY iteration)
-        const AffD<C> npt = AffD<C>::load(bases + (size_t)(nval & 0x7fffffffu) * g.pt_stride);
+        const AffD<C> npt = AffD<C>::load(bases + (size_t)(nval & PC_ACC_DEBUG_IDX_MASK) * g.pt_stride);
         const uint32_t nnval = entries[p + 2 < e ? p + 2 : e - 1];
         next_boundary = offsets[k + 2 <= g.NB ? k + 2 : g.NB];
         if constexpr (LAZY) acc.add_affine_lz(pt, (val >> 31) != 0); else acc.add_affine(pt.neg_if(val >> 31));

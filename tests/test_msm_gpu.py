@@ -487,3 +487,27 @@ def test_msm_randomised_differential():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_fuzz.py"), "10", "20260926"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_msm_equal_partial_sums_meet_in_the_joins(ctx, curve):
+    """ONE base under ONE scalar: every chunk of a bucket's run sums to the same point, so the in-workgroup scan of k_accumulate, the
+    edge kernel, the segmented and the (two-lane) bucket reduction all add EQUAL partial sums -- XyzzD::add / the two-lane half_add take
+    their doubling branch on coordinates that left the accumulation lazily reduced (BLS12-381) or canonical (BN254).  Round-3 advisor
+    finding; tests/test_emu_cpu.py steps the same shape on the CPU."""
+    g = O.gen_bases(curve, 3)
+    for n, chunk in ((64, 0), (4096, 0), (4096, 2), (5000, 5), (1 << 15, 0)):
+        b = np.ascontiguousarray(np.repeat(g[2:3], n, axis=0))
+        for k in (O.gen_scalars(curve, 5, 1), O.ints_to_limbs([1], 4), O.ints_to_limbs([3], 4)):
+            sc = np.ascontiguousarray(np.repeat(k, n, axis=0))
+            want = O.msm_pippenger(curve, b, sc, 8, 2)
+            if chunk:
+                ctx.set_msm_tuning(0, chunk)
+            srs = ctx.upload_srs(curve, b)
+            ctx.set_msm_tuning(0, 0)
+            for table in (False, True):
+                if table:
+                    srs.precompute(min_pairs=1)
+                got, _ = srs.msm(sc)
+                assert (got == want).all(), (curve, n, chunk, table)
+            srs.free()
