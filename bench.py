@@ -1281,6 +1281,8 @@ def main():
                        "srs_window_table": bool(args.precompute), "srs_window_table_form": {-1: "library policy (full unless HBM is tight)", 0: "full", 1: "GLV (half size)"}[args.glv_table],
                        "srs_window_table_build_ms": prim["srs_window_table_build_ms"],    # once per key, outside the timed region
                        "srs_gen_ms": prim["srs_gen_ms"],
+                       "value_is": "inputs resident in HBM when the timed region starts (the bench contract); the PCIe-inclusive rates are "
+                                   "value_h2d_inclusive (pinned host coefficients, copy overlapped) and trait_shaped (pageable, blocking calls)",
                        "coefficients": "device-resident when the timed region starts (value); pinned host memory "
                                        "(value_h2d_inclusive); pageable host memory, blocking calls (trait_shaped)",
                        "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients of ONE polynomial of {world} x 2^{log_degree} coefficients sharded in "
