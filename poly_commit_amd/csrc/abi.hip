@@ -274,6 +274,8 @@ int pc_hip_srs_upload(pc_ctx* ctx, pc_curve curve, const void* bases, size_t n, 
     if (const char* e = getenv("PC_HIP_K0")) srs->cfg.K0 = (uint32_t)atoi(e);
     if (const char* e = getenv("PC_HIP_TBL_K0")) srs->cfg.tbl_K0 = (uint32_t)atoi(e);
     if (const char* e = getenv("PC_HIP_TBL_LANES")) srs->cfg.tbl_target_lanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("PC_HIP_TBL_CHUNK")) srs->cfg.tbl_chunk = (uint32_t)atoi(e);
+    if (const char* e = getenv("PC_HIP_TBL_MAX_LANES")) srs->cfg.tbl_max_lanes = (uint32_t)atoi(e);
     if (const char* e = getenv("PC_HIP_COOP_MAX_LOG2")) srs->cfg.coop_max_points = 1u << (uint32_t)atoi(e);
     if (const char* e = getenv("PC_HIP_COOP2_MAX_LOG2")) { int v = atoi(e); srs->cfg.coop2_max_points = v < 0 ? 0u : 1u << (uint32_t)(v > 30 ? 30 : v); }
     srs_lane(srs, 0);   // allocate the first pipeline now so that OOM surfaces at upload

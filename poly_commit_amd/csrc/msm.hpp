@@ -669,6 +669,14 @@ struct MsmConfig {
   // the in-workgroup neighbour merge cannot repair (seg-reduce 0.37 -> 0.76 ms).  One round of 512
   // workgroups (chunks of 104) keeps every bucket within two chunks at the same accumulate time.
   uint32_t tbl_target_lanes = 1u << 17;
+  // ... doubled (up to tbl_max_lanes) while the chunks stay at least tbl_chunk entries long.  512 workgroups are exactly ONE round of
+  // the chip at two workgroups per CU: a blocking MSM then lasts as long as its slowest workgroup (accumulate 34.5 ms at 2^24); with
+  // 2048 workgroups (chunks of 384) the rounds rebalance: 32.0 ms.  Only whole multiples of a round (768 or 832 workgroups: 1.5 rounds
+  // of work in the time of 2), and not below ~64 entries per chunk: the joins of the cut buckets then cost more than the balance
+  // gains, and the pipelined 2^20 step lost 4 % with chunks of 52.  (BN254 batch pass 94.1 -> 91.0 ms, Pallas 2^22 4.23 -> 4.13 ms;
+  // the pipelined 2^24 step is unchanged: consecutive accumulations already fill each other's tails.)  0: fixed tbl_target_lanes.
+  uint32_t tbl_chunk = 64;
+  uint32_t tbl_max_lanes = 1u << 19;
   uint32_t tbl_K0 = 8;                  // first reduction level of the 2^(c-1)-bucket set (measured 8 < 4 << 16)
 };
 
@@ -763,7 +771,7 @@ class MsmPlan {
     size_t lanes0 = ceil_div_u32(Mmax, min_T_);
     if (!cfg_.T) {
       // T = clamp(floor(M / target_lanes), 16, 4096)  =>  lanes = ceil(M / T) <= max(17/16 target_lanes + 2, M / 4096 + 1)
-      const size_t tl = std::max(cfg_.target_lanes, cfg_.tbl ? cfg_.tbl_target_lanes : 0u);
+      const size_t tl = std::max(cfg_.target_lanes, cfg_.tbl ? (cfg_.tbl_chunk ? std::max(cfg_.tbl_max_lanes, cfg_.tbl_target_lanes) : cfg_.tbl_target_lanes) : 0u);
       size_t bound = std::max<size_t>(tl * 17 / 16 + 2, Mmax / 4096 + 1);
       if (lanes0 > bound) lanes0 = bound;
     }
@@ -824,7 +832,10 @@ class MsmPlan {
     g.m_sub = subs_ ? (uint32_t)(m_sub ? m_sub : n / subs_) : 0u;
     g.scalar_tab = scalar_tab;
     const size_t Mmax = n * g.Wd;
-    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / (g.tbl_stride ? cfg_.tbl_target_lanes : cfg_.target_lanes));
+    uint32_t want_lanes = g.tbl_stride ? cfg_.tbl_target_lanes : cfg_.target_lanes;
+    if (g.tbl_stride && cfg_.tbl_chunk)
+      while ((uint64_t)want_lanes * 2 <= cfg_.tbl_max_lanes && Mmax / ((size_t)want_lanes * 2) >= cfg_.tbl_chunk) want_lanes *= 2;
+    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / want_lanes);
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
     g.T = T; g.T2 = cfg_.T2; g.T2b = cfg_.T2b;
