@@ -258,33 +258,98 @@ def union_ms(intervals):
     return tot
 
 
-_MADD_PEAK = None
+_MICRO = None
 _MADD_COMMITTED = {"bls12_381": 6.68e9, "bn254": 14.07e9, "pallas": 15.97e9}      # profiles/r04_microbench.txt
+# committed figures of the lines tools/microbench prints since round 5 (profiles/r05_microbench.txt), used when the binary is missing
+_MICRO_COMMITTED = {"fmul": {}, "butterfly": {}, "butterfly4": {}, "jac_dbl": {}, "jac_madd": {}}
+
+
+def microbench():
+    """tools/microbench run ONCE on this GPU (rank 0) and parsed: the memory-free loops the kernels are priced against --
+    'madd' (XYZZ += affine per curve, best of 2 / 3 / 4 waves per SIMD), 'fmul' (Montgomery products per field), 'butterfly' /
+    'butterfly4' (the NTT's radix-2 butterfly and the radix-4 register group per scalar field), 'jac_dbl' / 'jac_madd' (the
+    IPA key fold's ladder steps per curve).  Values per second."""
+    global _MICRO
+    if _MICRO is not None:
+        return _MICRO
+    _MICRO = {"madd": {}, "fmul": {}, "butterfly": {}, "butterfly4": {}, "jac_dbl": {}, "jac_madd": {}, "source": None}
+    exe = os.path.join(ROOT, "tools", "microbench")
+    if os.path.exists(exe):
+        try:
+            import subprocess
+            txt = subprocess.run([exe], capture_output=True, text=True, timeout=240).stdout
+            fl = lambda t: [float(x) for x in t if x.replace(".", "", 1).isdigit() and "." in x]      # noqa: E731
+            for line in txt.splitlines():
+                t = line.split()
+                ls = line.strip()
+                if ls.startswith("kernel form") and "M madd/s" in line and fl(t):
+                    _MICRO["madd"][t[2]] = max(fl(t)) * 1e6
+                elif ls.startswith("fmul ") and "G mulmod/s" in line:
+                    _MICRO["fmul"][t[1]] = fl(t)[-1] * 1e9
+                elif ls.startswith("ntt butterfly ") and "G butterflies/s" in line:
+                    _MICRO["butterfly"][t[2]] = fl(t[:6])[-1] * 1e9
+                elif ls.startswith("ntt radix-4 group ") and "G butterflies/s" in line:
+                    _MICRO["butterfly4"][t[3]] = fl(t[:7])[-1] * 1e9
+                elif ls.startswith("jacobian ") and "M ops/s" in line and len(fl(t)) >= 2:
+                    _MICRO["jac_dbl"][t[1]], _MICRO["jac_madd"][t[1]] = fl(t)[0] * 1e6, fl(t)[1] * 1e6
+            _MICRO["source"] = "tools/microbench, this run"
+        except Exception:
+            pass
+    return _MICRO
+
+
+def micro_rate(kind, name):
+    """(rate per second, source) of one microbench line; the committed figure when the binary did not run; (None, None) if neither."""
+    m = microbench()
+    if name in m.get(kind, {}):
+        return m[kind][name], m["source"]
+    if name in _MICRO_COMMITTED.get(kind, {}):
+        return _MICRO_COMMITTED[kind][name], "profiles/r05_microbench.txt"
+    return None, None
 
 
 def madd_peak(curve):
     """Mixed additions per second of a pure-arithmetic loop (no memory traffic) of the same XYZZ += affine addition the accumulate
     kernel runs for this curve (lazily reduced where the field allows it): tools/microbench measured live on this GPU (rank 0,
     once: its 'kernel form <curve> at 2 / 3 / 4 waves per SIMD' line, best of the three), else the committed figure."""
-    global _MADD_PEAK
-    if _MADD_PEAK is None:
-        _MADD_PEAK = {}
-        exe = os.path.join(ROOT, "tools", "microbench")
-        if os.path.exists(exe):
-            try:
-                import subprocess
-                txt = subprocess.run([exe], capture_output=True, text=True, timeout=180).stdout
-                for line in txt.splitlines():
-                    t = line.split()
-                    if line.strip().startswith("kernel form") and "M madd/s" in line:
-                        nums = [float(x) for x in t if x.replace(".", "", 1).isdigit() and "." in x]
-                        if nums:
-                            _MADD_PEAK[t[2]] = {"madd_per_s": max(nums) * 1e6, "source": "tools/microbench, this run"}
-            except Exception:
-                pass
-    if curve not in _MADD_PEAK:
-        _MADD_PEAK[curve] = {"madd_per_s": _MADD_COMMITTED[curve], "source": "profiles/r04_microbench.txt"}
-    return _MADD_PEAK[curve]
+    m = microbench()
+    if curve in m["madd"]:
+        return {"madd_per_s": m["madd"][curve], "source": m["source"]}
+    return {"madd_per_s": _MADD_COMMITTED[curve], "source": "profiles/r04_microbench.txt"}
+
+
+def ntt_products(log_n, in_cols):
+    """Twiddle products and butterflies one row of pc_hip_ntt_batch executes (csrc/ntt.hpp, kept in step with it by
+    tests/test_bench_cpu.py): the four-step split N = 2^lg1 x 2^lg2, the stages pass A skips over the zero padding, the products
+    the kernels skip because the twiddle is 1, and the omega_N^(i2 j1) products between the passes.  Returns (products,
+    butterflies executed, nominal (N/2) log2 N butterflies of SURVEY.md 8d)."""
+    N = 1 << log_n
+    lg1 = (log_n + 1) // 2
+    lg2 = log_n - lg1
+    zskip = 0
+    while zskip < lg1 and in_cols <= (N >> (zskip + 1)):
+        zskip += 1
+
+    def stages(lines, lg, first):
+        prod = bfly = 0
+        length = 1 << lg
+        s = first
+        if (lg - first + 1) & 1 and s <= lg:
+            h = 1 << (s - 1)
+            prod += lines * (length // 2) * (h - 1) // h
+            bfly += lines * (length // 2)
+            s += 1
+        while s + 1 <= lg:
+            h = 1 << (s - 1)
+            groups = lines * (length // 4)
+            prod += groups * 3 * (h - 1) // h + groups        # x1 w1, x3 w1, a2 w2 unless j == 0; a3 w2' always
+            bfly += groups * 4
+            s += 2
+        return prod, bfly
+    pa, ba = stages(1 << lg2, lg1, zskip + 1)
+    pb, bb = stages(1 << lg1, lg2, 1)
+    between = ((1 << lg1) - 1) * ((1 << lg2) - 1)
+    return pa + pb + between, ba + bb, (N // 2) * log_n
 
 
 def msm_roofline(curve, pairs_per_launch, digits, kernel_ms, launches, kernel, traffic_key=None, extra=None):
@@ -377,6 +442,74 @@ def cpu_baseline(curve, srs, log_d, budget_s=30.0):
             "agrees_with_gpu": bool((got == dev).all() and (got1 == dev1).all()),
             "note": "a port of the algorithm, not the reference crate (no Rust toolchain here): ark-ec 0.5 itself parallelises over its "
                     "~16 windows only; its published per-core rates are of the order of 1e5 pairs/s"}
+
+
+def cpu_baseline_batch(curve, srs, vec, n, polys, budget_s=12.0):
+    """configs[2] beside the GPU: the CPU port's MSM of ONE polynomial of the batch (the same resident SRS chunk, the same
+    coefficients) on this box's cores, repeated while the budget lasts -- MarlinKZG10::commit loops its polynomials sequentially
+    (marlin_pc/mod.rs:192), so the batch costs `polys` times that."""
+    import oracle_lib as O
+    cores = effective_cores()
+    b = srs.read(0, n)
+    done, dt, ok = 0, 0.0, True
+    while done < min(polys, 4) and (done == 0 or dt * (done + 1) / done < budget_s):
+        sc = O.f_from_mont(curve, 1, host_u64(vec[done]))
+        t = time.perf_counter()
+        got = O.msm_pippenger(curve, b, sc, cores, 2)
+        dt += time.perf_counter() - t
+        dev, _ = srs.msm(vec[done].data_ptr(), n=n, montgomery=True)
+        ok = ok and bool((got == dev).all())
+        done += 1
+    return {"value": done * n / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
+            "sample": f"{done} of the {polys} polynomials: one MSM of {n} {curve} G1 pairs each over the same resident SRS on {cores} threads, {dt:.2f} s "
+                      f"(oracle/fast_msm.hpp: restated ark-ec signed-digit bucket method, NOT ark-ec itself)",
+            "projected_ms_per_step": polys * n / (done * n / dt) * 1e3, "agrees_with_gpu": ok}
+
+
+def cpu_baseline_ipa(curve, log_n_full, budget_s=12.0):
+    """configs[3] beside the GPU: the oracle's InnerProductArgPC::open halving loop (oracle.cpp orc_ipa_rounds: two MSMs, two inner
+    products, the coefficient / z folds and the key fold k_l += u k_r with batch normalisation per round, ipa_pc/mod.rs:664-711) on
+    this box's cores at the largest n = 2^k that fits the budget; the cost per element of the key fold is size-independent, so the
+    rate (coefficients of the opened polynomial per second) carries to 2^22 up to the MSMs' window widths."""
+    import oracle_lib as O
+    cores = effective_cores()
+    lg, dt, n = 10, None, None
+    while True:
+        n = 1 << lg
+        key = O.gen_bases(curve, n + 1)
+        co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE, n))
+        z = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B, 1))[0]
+        ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, lg))
+        t = time.perf_counter()
+        O.ipa_rounds(curve, np.ascontiguousarray(key[:n]), co, z, key[n], ch, cores)
+        dt = time.perf_counter() - t
+        if lg >= log_n_full or dt * 2.2 > budget_s / 2 or lg >= 18:
+            break
+        lg += 1
+    return {"value": n / dt, "unit": "coefficients/s (one opening of n coefficients)", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
+            "sample": f"one open halving loop at n = 2^{lg} ({lg} rounds, challenges supplied) on {cores} threads, {dt:.2f} s; the oracle's restatement of "
+                      f"ipa_pc/mod.rs:664-711 (full-width double-and-add key fold, Pippenger round MSMs), NOT ark-ec itself",
+            "projected_open_ms_at_full_size": (1 << log_n_full) / (n / dt) * 1e3}
+
+
+def cpu_baseline_ntt(curve, rows, n_cols, log_n, budget_s=10.0):
+    """configs[4] beside the GPU: the oracle's batched radix-2 NTT (oracle.cpp orc_ntt_batch: iterative DIT, precomputed root powers,
+    one thread per row) of a few rows of the same shape on this box's cores."""
+    import oracle_lib as O
+    cores = effective_cores()
+    r = min(rows, max(cores, 1))
+    mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0500, r * n_cols)).reshape(r, n_cols, 4)
+    O.ntt_batch(curve, mat[:1], log_n, 1)                     # (root tables, first-touch)
+    reps, dt = 0, 0.0
+    while reps == 0 or (dt * (reps + 1) / reps < budget_s and reps < 4):
+        t = time.perf_counter()
+        O.ntt_batch(curve, mat, log_n, cores)
+        dt += time.perf_counter() - t
+        reps += 1
+    return {"value": reps * r * n_cols / dt, "unit": "coeffs/s", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
+            "sample": f"{reps} x {r} rows of {n_cols} coefficients -> 2^{log_n} evaluations (the same zero-padded forward NTT, linear_codes/utils.rs:112-127) on "
+                      f"{cores} threads, {dt:.2f} s; the oracle's radix-2 NTT, NOT ark-poly itself",
+            "projected_ms_per_step": rows * n_cols / (reps * r * n_cols / dt) * 1e3}
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -835,6 +968,12 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
                                                            "pipelines overlap with each other's sort and reductions)",
                                    "bracket_ms_mean": ph[3] / passes, "window_bits": shape["window_bits"], "buckets_per_polynomial": shape["buckets"] // max(1, min(8, polys)),
                                    "pass_phase_ms_sum": {k: float(v) for k, v in zip(["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], ph[:6])}})
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_batch(curve, eng.srs, vec, n, polys)
+        except Exception as e:          # the baseline must never cost the measured line
+            cpu = {"error": repr(e)}
     eng.srs.free()
     del vec
     torch.cuda.empty_cache()
@@ -842,7 +981,7 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
     return {"workload": f"{polys} x MarlinKZG10<Bn254> commit, deg 2^{log_degree}, one SRS in {world} contiguous chunk(s) (BASELINE configs[2])",
             "value": pairs * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "ms_per_commitment": dt / steps * 1e3 / polys, "per_rank_ms_per_step": [float(x) / steps * 1e3 for x in per_rank],
-            "srs_window_table_build_ms": eng.precompute_ms, "roofline": roof,
+            "srs_window_table_build_ms": eng.precompute_ms, "roofline": roof, "cpu_baseline": cpu,
             "parity": {"all_commitments_closed_form_ok": bool(ok), "oracle_horner_checked": len(pick), "oracle_horner_ok": bool(ok_eval),
                        "method": "every C_j == p_j(beta) g on the true SRS (p_j(beta) from the device's evaluation kernel, "
                                  f"{len(pick)} of them re-evaluated by the oracle's Horner; scalar multiplication by the oracle)"}}
@@ -851,7 +990,99 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
 # ------------------------------------------------------------------------------------------------------------
 # configs[3]: InnerProductArgPC over Pallas, n = 2^22
 # ------------------------------------------------------------------------------------------------------------
-def ipa_case(ctx, log_n, reps):
+def _naf_weight_and_top(v):
+    """(non-zero digits, index of the top digit) of the non-adjacent form of v >= 0 (ec.hpp NafMasks::from_scalar)."""
+    w, top, i = 0, 0, 0
+    while v:
+        if v & 1:
+            d = 2 - (v & 3)
+            v -= d
+            w += 1
+            top = i
+        v >>= 1
+        i += 1
+    return w, top
+
+
+def glv_header_constants(curve):
+    """The lattice constants of the device's GLV split, read from the generated header the library is compiled with
+    (poly_commit_amd/csrc/glv_constants.h: floor reciprocals G1, G2 and the short basis (A1, B1), (A2, B2) with their signs)."""
+    import re
+    txt = open(os.path.join(ROOT, "poly_commit_amd", "csrc", "glv_constants.h")).read()
+    body = txt[txt.index(f"struct pc_glv_{curve} {{"):]
+    body = body[:body.index("\n};")]
+
+    def arr(name):
+        m = re.search(name + r"\[\d+\] = \{([^}]*)\}", body)
+        return sum(int(x.strip().rstrip("ul"), 16) << (64 * i) for i, x in enumerate(m.group(1).split(",")))
+
+    def flag(name):
+        return int(re.search(name + r" = (\d)", body).group(1))
+    return {k: arr(k) for k in ("G1", "G2", "A1", "B1", "A2", "B2")} | {k: flag(k) for k in ("N1_NEG", "N2_NEG", "A1_NEG", "B1_NEG", "A2_NEG", "B2_NEG")}
+
+
+def glv_split(gc, k):
+    """k = k1 + k2 lambda (mod r) exactly as csrc/glv.hpp glv_decompose computes it (truncated quotients)."""
+    sg = lambda v, neg: -v if neg else v      # noqa: E731
+    c1, c2 = sg((gc["G1"] * k) >> 384, gc["N1_NEG"]), sg((gc["G2"] * k) >> 384, gc["N2_NEG"])
+    a1, b1, a2, b2 = sg(gc["A1"], gc["A1_NEG"]), sg(gc["B1"], gc["B1_NEG"]), sg(gc["A2"], gc["A2_NEG"]), sg(gc["B2"], gc["B2_NEG"])
+    return k - c1 * a1 - c2 * a2, -c1 * b1 - c2 * b2
+
+
+def ipa_open_roofline(curve, log_n, challenges_mont, fold_rounds, per_round_ms, breakdown_ms, open_ms):
+    """Places InnerProductArgPC::open (ipa_pc/mod.rs:664-711) against ceilings.  Its largest part is the key fold k_l += u k_r: the first
+    fold from the committer key's fold table (EcFoldTableBody: one XYZZ mixed addition per non-zero NAF digit of the GLV halves of u,
+    plus one base-field product for the phi half), the next ones by the shared GLV ladder (EcFoldGlvBody: Jacobian doublings and
+    Jacobian += affine).  Each fold's ceiling = elements x (operations / the memory-free loop rate of that operation, tools/microbench);
+    the blocking wall time of the fold call is set against it.  The rounds on the fixed key (n <= 2^17) are latency-bound: their
+    floor is stated, not priced."""
+    try:
+        gc = glv_header_constants(curve)
+    except Exception as e:
+        return {"error": "GLV constants unavailable: " + repr(e)}
+    madd = madd_peak(curve)["madd_per_s"]
+    jd, src = micro_rate("jac_dbl", curve)
+    ja, _ = micro_rate("jac_madd", curve)
+    fm, _ = micro_rate("fmul", f"{curve}_fq")
+    folds, tot_ms, tot_ceiling, madd_eq = [], 0.0, 0.0, 0.0
+    for i, (h, ms) in enumerate(fold_rounds):
+        u = from_mont_limbs(curve, challenges_mont[i])
+        k1, k2 = glv_split(gc, u)
+        (w1, t1), (w2, t2) = _naf_weight_and_top(abs(k1)), _naf_weight_and_top(abs(k2))
+        table = i == 0
+        if table:
+            ceil_s = h * ((w1 + w2) / madd + (w2 / fm if fm else 0.0))
+            ops = {"xyzz_mixed_additions": w1 + w2, "phi_products": w2}
+            kern = "pc::EcFoldTableBody<pallas> + XyzzBatchAffineBody"
+        else:
+            nd, na = max(t1, t2), w1 + w2 + 1
+            ceil_s = h * (nd / jd + na / ja) if jd and ja else None
+            ops = {"jacobian_doublings": nd, "jacobian_mixed_additions": na}
+            kern = "pc::EcFoldGlvBody<pallas> + JacBatchAffineBody"
+        folds.append({"round": i + 1, "elements": h, "kernel": kern, "ops_per_element": ops, "wall_ms": ms,
+                      "ceiling_ms": ceil_s * 1e3 if ceil_s else None, "frac": ceil_s * 1e3 / ms if ceil_s and ms else None})
+        if ceil_s:
+            tot_ms += ms
+            tot_ceiling += ceil_s * 1e3
+            madd_eq += ceil_s * madd
+    n_fold = len(fold_rounds)
+    tail = per_round_ms[n_fold + 1:] if len(per_round_ms) > n_fold + 1 else []
+    return {"bound": "valu", "unit": "ms of memory-free arithmetic per ms measured",
+            "kernels": "the key folds of the first rounds (" + ", ".join(sorted({f['kernel'] for f in folds})) + ")",
+            "achieved": tot_ms, "peak": tot_ceiling, "frac": tot_ceiling / tot_ms if tot_ms else None,
+            "definition": "sum over the folds of [elements x (operations per element / memory-free loop rate of that operation)] / sum of the folds' "
+                          "blocking wall times (kernels + batched normalisation + launch); operations from the NAF of the GLV halves of each round challenge",
+            "madd_equivalents_per_s": madd_eq / (tot_ms * 1e-3) if tot_ms else None, "madd_loop_per_s": madd,
+            "loop_rates_per_s": {"xyzz_madd": madd, "jacobian_dbl": jd, "jacobian_madd": ja, "fq_mul": fm}, "loop_source": src,
+            "folds": folds, "fold_share_of_open": tot_ms / open_ms if open_ms else None,
+            "msm_wait_ms": breakdown_ms.get("msm_wait"), "host_point_mul_ms": breakdown_ms.get("host_point_mul"),
+            "fixed_key_rounds": {"count": len(tail), "ms_each_mean": float(np.mean(tail)) if tail else None, "ms_total": float(np.sum(tail)) if tail else None,
+                                 "note": "rounds with n <= 2^17 keep the key and run two 2^17-pair MSMs over per-base factors: each is one scalar kernel, two "
+                                         "pipelined MSM launches (sort, accumulate, three reduction levels, 64-byte download), two host point multiplications "
+                                         "and the Horner tails -- a launch / latency floor of ~1 ms per round that no kernel rate changes"}}
+
+
+def ipa_case(ctx, log_n, reps, with_cpu=True):
     import torch
     import oracle_lib as O
     from poly_commit_amd import ipa
@@ -897,6 +1128,14 @@ def ipa_case(ctx, log_n, reps):
         if best is None or dt < best:
             best, tm_best = dt, tm
     per_round = tm_best.pop("per_round_ms", [])
+    fold_rounds = tm_best.pop("ec_fold_per_round_ms", [])
+    roof_open = ipa_open_roofline(curve, log_n, ch, fold_rounds, per_round, tm_best, best * 1e3)
+    cpu = None
+    if with_cpu:
+        try:
+            cpu = cpu_baseline_ipa(curve, log_n)
+        except Exception as e:
+            cpu = {"error": repr(e)}
     host = host_u64(cdev)
     pa = from_mont_limbs(curve, O.poly_eval(curve, host, mont_limbs(curve, a)))
     ok_commit = bool((comm == oracle_scalar_mul(curve, g, pa)).all())
@@ -919,6 +1158,7 @@ def ipa_case(ctx, log_n, reps):
                                      extra={"kernel_ms_definition": "hipEvent bracket of the accumulate launch of the last blocking commit MSM",
                                             "commit_msm_phase_ms": {k: float(v) for k, v in zip(["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], ph_c[:6])},
                                             "window_bits": shape_c["window_bits"], "buckets": shape_c["buckets"]}),
+            "roofline_open": roof_open, "cpu_baseline": cpu,
             "key_gen_ms": key_gen_ms, "key_tables_build_ms": key_tables_ms,
             "key_tables_note": "window table + fold table (131 x n/2 points) of the committer key, built once per key outside the timing",
             "parity": {"commit_ok": ok_commit, "final_comm_key_ok": ok_key,
@@ -931,7 +1171,7 @@ def ipa_case(ctx, log_n, reps):
 # ------------------------------------------------------------------------------------------------------------
 # configs[4]: Ligero over BLS12-381 Fr, 2^24 coefficients
 # ------------------------------------------------------------------------------------------------------------
-def ligero_case(ctx, D, curve, log_len, steps, warmup):
+def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True):
     import torch
     import oracle_lib as O
     from poly_commit_amd import sharded
@@ -1026,6 +1266,31 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
     alg_bytes = rows * (n_cols + N) * 32
     kern_ms = float(ph.sum())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+    # the bound that holds (the kernels are VALU-bound on the 255-bit Montgomery product): twiddle products per second against the
+    # memory-free butterfly loops of tools/microbench for this scalar field
+    prod_row, bfly_row, nominal_row = ntt_products(log_n, n_cols)
+    fr = f"{curve}_fr"
+    b2, src2 = micro_rate("butterfly", fr) if rank == 0 else (None, None)
+    b4, _ = micro_rate("butterfly4", fr) if rank == 0 else (None, None)
+    fm, _ = micro_rate("fmul", fr) if rank == 0 else (None, None)
+    ach_p = rows * prod_row / (kern_ms * 1e-3) if kern_ms > 0 else None
+    peak = max([v for v in (b2, b4) if v] or [0]) or None
+    arith = {"bound": "valu", "unit": "twiddle products/s (one 255-bit Montgomery product + one modular add + one modular sub = one butterfly)",
+             "achieved": ach_p, "peak": peak, "frac": ach_p / peak if ach_p and peak else None,
+             "peak_definition": "the faster of tools/microbench's two memory-free butterfly loops for this field: the radix-2 butterfly (x + w y, x - w y) and the "
+                                "radix-4 register group of two stages on four elements (what lds_ntt_stages runs per LDS round trip)",
+             "peak_source": src2, "butterfly_loop_per_s": b2, "radix4_group_loop_per_s": b4, "fmul_per_s": fm,
+             "products_per_launch": rows * prod_row, "butterflies_executed_per_launch": rows * bfly_row,
+             "nominal_butterflies_per_launch": rows * nominal_row,
+             "count_definition": "products the two passes execute per batch: (N/2) log2 N butterflies minus the stages pass A skips over the zero padding "
+                                 "(rho^-1 = 4: two of seventeen) and the products with twiddle 1, plus the omega_N^(i2 j1) products between the passes "
+                                 "(bench.ntt_products mirrors csrc/ntt.hpp)"}
+    cpu = None
+    if rank == 0 and with_cpu:
+        try:
+            cpu = cpu_baseline_ntt(curve, n_rows, n_cols, log_n)
+        except Exception as e:
+            cpu = {"error": repr(e)}
     return {"workload": f"LigeroPCS over {curve} Fr, 2^{log_len} coefficients: {n_rows} x {n_cols} matrix, {n_rows} forward NTTs of size 2^{log_n} "
                         f"(BASELINE configs[4]); rows sharded over {world} GPU(s), no collective",
             "value": world * rows * n_cols * steps / dt, "unit": "coeffs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
@@ -1037,7 +1302,8 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup):
                          "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
                          "traffic_source": "profiles/r04_pmc_traffic.json (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
                          "kernel": "pc::k_ntt_pass_a + pc::k_ntt_pass_b (one batched NTT = both), hipEvent brackets on the context's stream inside the timed region",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes, "arithmetic": arith},
+            "cpu_baseline": cpu,
             "parity": {"horner_spot_checks_ok": bool(ok), "one_row_vs_oracle_ntt_ok": ok_row,
                        "method": "out[r][j] == row_r(omega^j) by the oracle's Horner at 5 (row, column) spots (test_reed_solomon's property, "
                                  "linear_codes/utils.rs:303-331) and one whole row against the oracle's NTT"}}
@@ -1181,7 +1447,7 @@ def main():
     t_start = time.perf_counter()
 
     if args.workload == "ntt":
-        r = ligero_case(ctx, D, curve, 16 if small else 24, args.steps or (5 if small else 100), args.warmup)
+        r = ligero_case(ctx, D, curve, 16 if small else 24, args.steps or (5 if small else 100), args.warmup, with_cpu=not args.no_cpu_baseline)
         if rank == 0:
             emit({"metric": "Ligero Reed-Solomon NTT input coefficients/sec (LigeroPCS over BLS12-381 Fr, 2^24 coeffs)",
                   "value": r["value"], "unit": "coeffs/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
@@ -1238,9 +1504,9 @@ def main():
                 elif name == "batch":
                     workloads[name] = batch_case(ctx, D, args, 14 if small else 20, 8 if small else args.polys, 3, 1)
                 elif name == "ipa":
-                    workloads[name] = ipa_case(ctx, 14 if small else 22, 2)
+                    workloads[name] = ipa_case(ctx, 14 if small else 22, 2, with_cpu=not args.no_cpu_baseline)
                 elif name == "ligero":
-                    workloads[name] = ligero_case(ctx, D, curve, 16 if small else 24, 5 if small else 20, 2)
+                    workloads[name] = ligero_case(ctx, D, curve, 16 if small else 24, 5 if small else 20, 2, with_cpu=not args.no_cpu_baseline)
                 else:
                     workloads[name] = {"error": "unknown workload"}
             except Exception as e:      # one block failing must not lose the driver's line

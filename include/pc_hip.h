@@ -155,7 +155,9 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
 /* Kernel-only timing of the last MSM issued on this ctx, in milliseconds, by phase
  * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py.
  * After pc_hip_msm_batch over a window table (many-MSM passes): [0..5] summed over the passes, [6] the union of the passes'
- * accumulate intervals (passes overlap on two pipelines), [7] the number of passes. */
+ * accumulate intervals (passes overlap on two pipelines), [7] the number of passes.
+ * After a blocking call that ran as two half-size MSMs (pc_hip_msm / pc_hip_kzg_open on host memory from 2^23 pairs): the SUM of the
+ * two halves' phases; pc_hip_last_msm_marks_ms and pc_hip_last_msm_shape then describe the second half. */
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
 /* The same phase boundaries of the last completed MSM as offsets (ms) from the moment pc_hip_set_timing(ctx, 1) was last
  * called: out[0] = the call was queued, out[1..6] = end of digits+hist, scan, scatter, accumulate, seg-reduce,

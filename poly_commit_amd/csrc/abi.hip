@@ -370,18 +370,26 @@ int pc_hip_universal_params_layout(pc_curve curve, const void* bytes, size_t n_b
   return PC_OK;
 }
 
+// Every path mutates shared context state (ctx->keys, the backend's byte ledger, a parent's work cache) and is reached from arbitrary
+// threads (Drop of the last Arc<ResidentKey>, device::release, the LRU eviction of the Rust shim) while other threads may be inside
+// pc_hip_srs_upload / pc_hip_ctx_trim / any alloc: the context lock is held for the whole call (recursive: pc_hip_ctx_trim and the
+// work-cache recursion below re-enter).  The mutex lives in the context, which outlives its keys (pc_hip_shutdown frees them first).
+static void srs_free_locked(pc_srs* srs);
 void pc_hip_srs_free(pc_srs* srs) {
   if (!srs) return;
+  if (srs->ctx) { std::lock_guard<std::recursive_mutex> lk(srs->ctx->mu); srs_free_locked(srs); }
+  else srs_free_locked(srs);
+}
+static void srs_free_locked(pc_srs* srs) {
   if (srs->parent) {                                   // a working key goes back to its committer key (see pc_srs)
     pc_srs* par = srs->parent;
-    std::lock_guard<std::recursive_mutex> lk(srs->ctx->mu);
     for (int i = 0; i < PC_MSM_LANES; i++)             // nothing of it may still be queued
       if (srs->lanes[i] && srs->lanes[i]->inflight) { try { complete_job(srs->ctx, srs->lanes[i]->inflight); } catch (...) {} }
     if (par->work_out == srs) par->work_out = nullptr;
     if (!par->work_cache) { par->work_cache = srs; return; }
     srs->parent = nullptr;                             // the cache is taken: a real free
   }
-  if (srs->work_cache) { srs->work_cache->parent = nullptr; pc_hip_srs_free(srs->work_cache); srs->work_cache = nullptr; }
+  if (srs->work_cache) { srs->work_cache->parent = nullptr; srs_free_locked(srs->work_cache); srs->work_cache = nullptr; }
   if (srs->work_out) { srs->work_out->parent = nullptr; srs->work_out = nullptr; }      // still held by the caller: it frees it
   if (srs->ctx) (void)hipSetDevice(srs->ctx->device);
   for (int i = 0; i < PC_MSM_LANES; i++) {
@@ -469,6 +477,15 @@ static size_t host_split_min() {
   static const size_t v = []() { const char* e = getenv("PC_HIP_HOST_SPLIT_LOG2"); int lg = e ? atoi(e) : 23; return lg <= 0 ? (size_t)-1 : (size_t)1 << (lg > 40 ? 40 : lg); }();
   return v;
 }
+// The two half-size jobs of a split call: pc_hip_last_msm_phases_ms then reports the SUM of both jobs' phase brackets (the halves run
+// one after the other on the device where it matters: two accumulations never share the chip usefully), pc_hip_last_msm_marks_ms and
+// pc_hip_last_msm_shape the second job's (one set of marks cannot describe two pipelines).  A job that an enqueue already completed
+// (lane reuse) contributed its phases then; they are lost to the sum -- with PC_MSM_LANES = 3 pipelines that never happens for two jobs.
+static void complete_two(pc_ctx* ctx, pc_job* a, pc_job* b) {
+  float ph[8] = {0};
+  if (!a->done) { complete_job(ctx, a); for (int i = 0; i < 8; i++) ph[i] = ctx->phases[i]; }
+  if (!b->done) { complete_job(ctx, b); for (int i = 0; i < 8; i++) ctx->phases[i] += ph[i]; }
+}
 // sum of two affine results into out_xy / out_is_infinity
 static void fold_two(pc_srs* srs, const uint32_t* a, const uint32_t* b, void* out_xy, int* out_is_infinity) {
   std::vector<uint32_t> two(2 * (size_t)srs->aw);
@@ -493,8 +510,7 @@ int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void*
       if (rc != PC_OK) return rc;
       rc = enqueue_job(ctx, srs, base_offset + h, (const uint8_t*)scalars + h * 32, form, where, ne - h, r2.data(), nullptr, &j2.job, true);
       if (rc != PC_OK) return rc;
-      if (!j1.job.done) complete_job(ctx, &j1.job);
-      if (!j2.job.done) complete_job(ctx, &j2.job);
+      complete_two(ctx, &j1.job, &j2.job);
       fold_two(srs, r1.data(), r2.data(), out_xy, out_is_infinity);
       return (int)PC_OK;
     }
@@ -676,6 +692,7 @@ int pc_hip_msm_many(pc_ctx* ctx, pc_srs* srs, size_t base_offset, const void* sc
         pc::curve_ops(srs->curve).window_table(ctx->be, b0, (uint32_t)m, c, Wd, table, (uint32_t)srs->aw);
         pc::MsmConfig cfg = srs->cfg;
         cfg.c = 0; cfg.T = 0; cfg.tbl = table; cfg.tbl_c = c; cfg.tbl_stride = (uint32_t)m; cfg.tbl_pt_stride = (uint32_t)srs->aw; cfg.tbl_min_n = 0;
+        cfg.tbl_glv = false;      // this pass's own table is the full one: c, Wd and the capacity checks above are the plain form's, whatever the key's table is
         L = new MsmLane();
         L->be.init();
         L->runner = pc::curve_ops(srs->curve).make_runner(L->be, n_msms * m, cfg, (uint32_t)n_msms);
@@ -936,7 +953,16 @@ int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const 
     const pc::FieldOps& F = pc::field_ops(srs->curve);
     const uint32_t* z = (const uint32_t*)z_host;
     const size_t m = n - 1;                                       // quotient length; x[j] = p[j + 1]
-    uint32_t* q = (uint32_t*)ctx->be.stage(1, m * 32);
+    // the quotient (and, in the split path, the shifted coefficients): the context's grow-only staging up to STAGE_KEEP, transient
+    // buffers above it -- one open of a 2^26-coefficient polynomial would otherwise pin 2 x 2 GiB until pc_hip_ctx_trim.  The transient
+    // ones are freed when the call returns: every job that reads them is complete by then (StackJob / complete_job below).
+    struct CallBuf {
+      pc::HipBackend& be; void* dev; bool owned;
+      CallBuf(pc::HipBackend& b, int slot, size_t bytes) : be(b), owned(bytes > pc::HipBackend::STAGE_KEEP) { dev = owned ? be.alloc(bytes) : be.stage(slot, bytes); }
+      ~CallBuf() { if (owned) { (void)hipStreamSynchronize(be.stream); be.free(dev); } }
+    };
+    CallBuf qbuf(ctx->be, 1, m * 32);
+    uint32_t* q = (uint32_t*)qbuf.dev;
     if (where == PC_MEM_DEVICE || m < host_split_min()) {
       Staged sin(ctx->be, coeffs, where, n * 32, true, 0);
       F.witness(ctx->be, (const uint32_t*)sin.dev, n, z, q, scan_fan());
@@ -946,7 +972,8 @@ int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const 
       complete_job(ctx, &job);
       return (int)PC_OK;
     }
-    uint32_t* x = (uint32_t*)ctx->be.stage(0, m * 32);
+    CallBuf xbuf(ctx->be, 0, m * 32);
+    uint32_t* x = (uint32_t*)xbuf.dev;
     const uint8_t* src = (const uint8_t*)coeffs + 32;
     const size_t h = m / 2;
     std::vector<uint32_t> r1(srs->aw), r2(srs->aw), carry(8);
@@ -960,8 +987,7 @@ int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const 
     F.div_scan(ctx->be, x, h, z, carry.data(), q, scan_fan());
     rc = enqueue_job(ctx, srs, base_offset, q, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, h, r2.data(), nullptr, &j2.job, true);
     if (rc != PC_OK) return rc;
-    if (!j1.job.done) complete_job(ctx, &j1.job);
-    if (!j2.job.done) complete_job(ctx, &j2.job);
+    complete_two(ctx, &j1.job, &j2.job);
     fold_two(srs, r1.data(), r2.data(), out_xy, out_is_infinity);
     return (int)PC_OK;
   });

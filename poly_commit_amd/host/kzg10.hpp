@@ -30,7 +30,7 @@ struct Pallas { typedef pc_curve_pallas C; static constexpr pc_curve ID = PC_CUR
 
 // Error variants of poly-commit/src/error.rs that this path can raise.
 struct Error {
-  enum Kind { None, MissingRng, TooManyCoefficients, HidingBoundIsZero, HidingBoundToolarge, UnsupportedDegreeBound, InvalidParameters, IncorrectInputLength, InvalidNumberOfVariables, IncorrectCommitmentSize, InvalidCommitment, TrimmingDegreeTooLarge, Backend } kind = None;
+  enum Kind { None, MissingRng, TooManyCoefficients, HidingBoundIsZero, HidingBoundToolarge, UnsupportedDegreeBound, InvalidParameters, IncorrectInputLength, InvalidNumberOfVariables, IncorrectCommitmentSize, InvalidCommitment, TrimmingDegreeTooLarge, MissingPolynomial, EquationHasDegreeBounds, Backend } kind = None;
   size_t a = 0, b = 0;      // (num_coefficients, num_powers) / (hiding_poly_degree, num_powers) / bound
   std::string msg;          // Backend: pc_hip_strerror / pc_hip_last_error
   explicit operator bool() const { return kind != None; }

@@ -7,12 +7,18 @@
 //   check_degrees_and_bounds                       kzg10/mod.rs:424-449
 //   MarlinKZG10::commit                            marlin_pc/mod.rs:172-242
 //   MarlinKZG10::open                              marlin_pc/mod.rs:245-336
+//   MarlinKZG10::batch_open                        marlin_pc/mod.rs:457-530
+//   MarlinKZG10::open_combinations                 marlin_pc/mod.rs:407-430 -> Marlin::open_combinations, marlin/mod.rs:224-316
+//     (combine_commitments :52-70, normalize_commitments :72-105)
 // The Fiat-Shamir sponge is the caller's (`ChallengeSource`): the reference squeezes one
 // 128-bit challenge per polynomial (and one more per degree-bounded polynomial) at
 // marlin_pc/mod.rs:282,299.  setup/check stay with the reference (verifier side).
 #pragma once
 #include <algorithm>
+#include <map>
 #include <optional>
+#include <set>
+#include <tuple>
 #include "kzg10.hpp"
 
 namespace pc_host {
@@ -26,6 +32,17 @@ struct LabeledPolynomial {          // data_structures.rs:109-180
 
 template <class E> struct MarlinCommitment { G1Affine<E> comm = G1Affine<E>::zero(); std::optional<G1Affine<E>> shifted_comm; };   // :227-235
 template <class E> struct MarlinRandomness { Randomness<E> rand; std::optional<Randomness<E>> shifted_rand; };                     // :304-311
+
+// LinearCombination<F> (data_structures.rs:248-365): (coefficient, term) pairs; a term without a label is LCTerm::One
+template <class E>
+struct LinearCombination {
+  std::string label;
+  std::vector<std::pair<FrT<E>, std::optional<std::string>>> terms;
+};
+// one element of a QuerySet<T> = BTreeSet<(String, (String, T))> (lib.rs:152): (polynomial / equation label, (point label, point))
+template <class E>
+struct Query { std::string label, point_label; FrT<E> point; };
+template <class E> struct LabeledMarlinCommitment { std::string label; MarlinCommitment<E> commitment; std::optional<size_t> degree_bound; };
 
 template <class E>
 struct ChallengeSource { virtual ~ChallengeSource() {} virtual FrT<E> squeeze_challenge() = 0; };
@@ -171,6 +188,91 @@ struct MarlinKZG10 {
     }
     out.w = w; out.has_random_v = has_v; out.random_v = random_v;
     return Error();
+  }
+
+  // MarlinKZG10::batch_open (marlin_pc/mod.rs:457-530): the queries are grouped by POINT LABEL (BTreeMap order), the polynomials
+  // queried at one point are opened together, in label order (BTreeSet), with one `open` above -- one proof per distinct point label.
+  static Error batch_open(const CommitterKey<E>& ck, const std::vector<LabeledPolynomial<E>>& labeled_polynomials,
+                          const std::vector<Query<E>>& query_set, ChallengeSource<E>& sponge, const std::vector<MarlinRandomness<E>>& states,
+                          std::vector<Proof<E>>& proofs) {
+    proofs.clear();
+    std::map<std::string, size_t> by_label;
+    for (size_t i = 0; i < labeled_polynomials.size(); i++) by_label[labeled_polynomials[i].label] = i;
+    std::vector<Query<E>> qs = query_set;                     // BTreeSet iteration order: (label, (point label, point))
+    std::sort(qs.begin(), qs.end(), [](const Query<E>& a, const Query<E>& b) { return std::tie(a.label, a.point_label) < std::tie(b.label, b.point_label); });
+    std::map<std::string, std::pair<Fr, std::set<std::string>>> query_to_labels_map;
+    for (const auto& q : qs) {
+      auto it = query_to_labels_map.find(q.point_label);
+      if (it == query_to_labels_map.end()) it = query_to_labels_map.emplace(q.point_label, std::make_pair(q.point, std::set<std::string>())).first;
+      it->second.second.insert(q.label);
+    }
+    for (const auto& kv : query_to_labels_map) {
+      std::vector<LabeledPolynomial<E>> query_polys; std::vector<MarlinRandomness<E>> query_states;
+      for (const auto& label : kv.second.second) {
+        auto f = by_label.find(label);
+        if (f == by_label.end()) { Error e; e.kind = Error::MissingPolynomial; e.msg = label; return e; }
+        query_polys.push_back(labeled_polynomials[f->second]); query_states.push_back(states[f->second]);
+      }
+      Proof<E> proof;
+      if (Error e = open(ck, query_polys, kv.second.first, sponge, query_states, proof)) return e;
+      proofs.push_back(proof);
+    }
+    return Error();
+  }
+
+  // Marlin::open_combinations (marlin/mod.rs:224-316): per equation the polynomial, the commitment state and the commitment are
+  // combined (degree-bounded polynomials only alone and with coefficient one, :267-277; the constant term of an equation is not part
+  // of the combined polynomial: the verifier subtracts it from the claimed value, :352-358), then ONE proof per query point is made
+  // over the COMBINED polynomials.  `lc_commitments_out`: the combined commitments (combine_commitments + normalize_commitments) the
+  // verifier rebuilds on its side -- returned so that a caller without pairings can check the proofs against them.
+  // BatchLCProof{proof, evals: None}: `proofs` is the whole proof.
+  static Error open_combinations(const CommitterKey<E>& ck, const std::vector<LinearCombination<E>>& lc_s,
+                                 const std::vector<LabeledPolynomial<E>>& polynomials, const std::vector<MarlinCommitment<E>>& commitments,
+                                 const std::vector<Query<E>>& query_set, ChallengeSource<E>& sponge, const std::vector<MarlinRandomness<E>>& states,
+                                 std::vector<Proof<E>>& proofs, std::vector<LabeledMarlinCommitment<E>>* lc_commitments_out = nullptr) {
+    std::map<std::string, size_t> label_map;
+    for (size_t i = 0; i < polynomials.size(); i++) label_map[polynomials[i].label] = i;
+    std::vector<LabeledPolynomial<E>> lc_polynomials; std::vector<MarlinRandomness<E>> lc_states;
+    std::vector<LabeledMarlinCommitment<E>> lc_commitments;
+    for (const auto& lc : lc_s) {
+      LabeledPolynomial<E> lc_poly; lc_poly.label = lc.label;
+      MarlinRandomness<E> randomness;                          // PCCommitmentState::empty()
+      G1Affine<E> combined_comm = G1Affine<E>::zero(); std::optional<G1Affine<E>> combined_shifted_comm;
+      const size_t num_polys = lc.terms.size();
+      for (const auto& term : lc.terms) {
+        if (!term.second) continue;                            // LCTerm::One
+        const Fr& coeff = term.first;
+        auto f = label_map.find(*term.second);
+        if (f == label_map.end()) { Error e; e.kind = Error::MissingPolynomial; e.msg = *term.second; return e; }
+        const LabeledPolynomial<E>& cur_poly = polynomials[f->second];
+        const MarlinRandomness<E>& cur_state = states[f->second];
+        const MarlinCommitment<E>& cur_comm = commitments[f->second];
+        if (num_polys == 1 && cur_poly.degree_bound) {
+          if (!(coeff == Fr::one())) { Error e; e.kind = Error::InvalidParameters; e.msg = "Coefficient must be one for degree-bounded equations"; return e; }   // an assert! in the reference
+          lc_poly.degree_bound = cur_poly.degree_bound;
+        } else if (cur_poly.degree_bound) { Error e; e.kind = Error::EquationHasDegreeBounds; e.msg = lc.label; return e; }
+        if (cur_poly.hiding_bound && (!lc_poly.hiding_bound || *lc_poly.hiding_bound < *cur_poly.hiding_bound)) lc_poly.hiding_bound = cur_poly.hiding_bound;   // max, Some(_) > None
+        axpy(lc_poly.polynomial, coeff, cur_poly.polynomial);
+        // randomness += (coeff, cur_state)   (marlin_pc/data_structures.rs:322-343)
+        axpy(randomness.rand.blinding_polynomial, coeff, cur_state.rand.blinding_polynomial);
+        if (cur_state.shifted_rand) {
+          if (!randomness.shifted_rand) randomness.shifted_rand = Randomness<E>::empty();
+          axpy(randomness.shifted_rand->blinding_polynomial, coeff, cur_state.shifted_rand->blinding_polynomial);
+        }
+        // combine_commitments (marlin/mod.rs:52-70)
+        combined_comm = combined_comm.add(coeff == Fr::one() ? cur_comm.comm : cur_comm.comm.mul(coeff));
+        if (cur_comm.shifted_comm) {
+          const G1Affine<E> cur = cur_comm.shifted_comm->mul(coeff);
+          combined_shifted_comm = combined_shifted_comm ? combined_shifted_comm->add(cur) : cur;
+        }
+      }
+      lc_polynomials.push_back(lc_poly); lc_states.push_back(randomness);
+      LabeledMarlinCommitment<E> c; c.label = lc.label; c.degree_bound = lc_poly.degree_bound;
+      c.commitment.comm = combined_comm; c.commitment.shifted_comm = combined_shifted_comm;      // (affine already: normalize_commitments is the identity here)
+      lc_commitments.push_back(c);
+    }
+    if (lc_commitments_out) *lc_commitments_out = lc_commitments;
+    return batch_open(ck, lc_polynomials, query_set, sponge, lc_states, proofs);
   }
 };
 

@@ -173,6 +173,7 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
         with _T("fold_dots"):
             # coeffs_l += u^-1 coeffs_r, z_l += u z_r, and the next round's two inner products in the same pass
             dots = ctx.ipa_fold_dots(curve, cptr, zptr, h, u, _int_to_limbs(ui))
+        t_fold = time.perf_counter()
         with _T("ec_fold"):
             if n0:
                 u_prev = u                                                  # applied to the factors at the top of the next round
@@ -180,6 +181,8 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
                 srs.ec_fold(h, u)                                           # key_l += u key_r, normalised
             else:
                 srs, owned = srs.fold_from(h, u), True                      # the same fold, out of place: the committer key stays
+        if timings is not None and not n0:                                  # (blocking calls: wall time = the fold's kernels + launch)
+            timings.setdefault("ec_fold_per_round_ms", []).append((h, round((time.perf_counter() - t_fold) * 1e3, 3)))
         if timings is not None:
             timings.setdefault("per_round_ms", []).append(round((time.perf_counter() - t_round) * 1e3, 3))
         n = h

@@ -1,5 +1,6 @@
 //! `HipIpaPC<G, D, P>`: `PolynomialCommitment` with the associated types of the reference's `InnerProductArgPC`
-//! (`poly-commit/src/ipa_pc/mod.rs:338-345`): `setup` / `trim` / `check` delegate, `commit` (`:403-473`) and `open`
+//! (`poly-commit/src/ipa_pc/mod.rs:338-345`): `setup` / `trim` / `check` / `batch_check` / `check_combinations` delegate,
+//! `open_combinations` (`:858-965`) is restated over the device `open`, `commit` (`:403-473`) and `open`
 //! (`:475-723`) are restated with `cm_commit`'s MSM (`:54-72`) and the body of the halving loop (`:664-711`) on the device.
 //!
 //! Per round of `open` (n -> n/2) the reference does two MSMs of n/2 pairs, two inner products, the folds of the
@@ -22,10 +23,11 @@ use ark_ff::{Field, One, PrimeField, UniformRand, Zero};
 use ark_poly::{DenseUVPolynomial, Polynomial};
 use ark_poly_commit::{
     ipa_pc::{Commitment, CommitterKey, InnerProductArgPC, Proof, Randomness, UniversalParams, VerifierKey},
-    Error, LabeledCommitment, LabeledPolynomial, PCCommitmentState, PCCommitterKey, PolynomialCommitment, CHALLENGE_SIZE,
+    BatchLCProof, Error, Evaluations, LabeledCommitment, LabeledPolynomial, LinearCombination, PCCommitmentState, PCCommitterKey,
+    PolynomialCommitment, QuerySet, CHALLENGE_SIZE,
 };
 use ark_serialize::CanonicalSerialize;
-use ark_std::{marker::PhantomData, rand::RngCore};
+use ark_std::{collections::BTreeMap, convert::TryInto, marker::PhantomData, ops::Mul, rand::RngCore, string::{String, ToString}, vec::Vec};
 use core::ffi::c_void;
 use digest::Digest;
 
@@ -402,4 +404,110 @@ where
         // succinct part (:91-203) is private to the reference, so the drop-in verifier stays the reference's own.
         InnerProductArgPC::<G, D, P>::check(vk, commitments, point, values, proof, sponge, rng)
     }
+
+    // ---- the three methods InnerProductArgPC OVERRIDES beyond the required ones (ipa_pc/mod.rs:775-1048), so that no trait method
+    // of this type resolves to another implementation than the reference type's.  The trait's DEFAULT `open_combinations`
+    // (lib.rs:445-487) opens the individual polynomials and returns `evals: Some(..)`; `InnerProductArgPC::check_combinations`
+    // rebuilds ONE commitment per equation and batch-checks the proofs against those, ignoring `evals` -- it rejects such a proof
+    // for every non-trivial combination (round-4 review).
+
+    fn batch_check<'a, R: RngCore>(vk: &Self::VerifierKey, commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+                                   query_set: &QuerySet<P::Point>, values: &Evaluations<P::Point, G::ScalarField>, proof: &Self::BatchProof,
+                                   sponge: &mut impl CryptographicSponge, rng: &mut R) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        InnerProductArgPC::<G, D, P>::batch_check(vk, commitments, query_set, values, proof, sponge, rng)        // :775-856
+    }
+
+    fn check_combinations<'a, R: RngCore>(vk: &Self::VerifierKey, linear_combinations: impl IntoIterator<Item = &'a LinearCombination<G::ScalarField>>,
+                                          commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>,
+                                          eqn_query_set: &QuerySet<P::Point>, eqn_evaluations: &Evaluations<P::Point, G::ScalarField>,
+                                          proof: &BatchLCProof<G::ScalarField, Self::BatchProof>, sponge: &mut impl CryptographicSponge,
+                                          rng: &mut R) -> Result<bool, Self::Error>
+    where
+        Self::Commitment: 'a,
+    {
+        InnerProductArgPC::<G, D, P>::check_combinations(vk, linear_combinations, commitments, eqn_query_set, eqn_evaluations, proof, sponge, rng)   // :969-1048
+    }
+
+    // `InnerProductArgPC::open_combinations` (ipa_pc/mod.rs:858-965), restated: polynomial, randomness and commitment (with their
+    // shifted twins, `combine_shifted_rand` / `combine_shifted_comm` :241-265) are combined per equation under the reference's
+    // degree-bound rules, the combined commitments go through `construct_labeled_commitments` (:267-300: `comm`, then `shifted_comm`
+    // when the equation carries a degree bound), and `Self::batch_open` -- the trait's provided method, which the reference type
+    // does not override either -- opens the COMBINED polynomials with the `open` above, i.e. on the device.
+    fn open_combinations<'a>(ck: &Self::CommitterKey, linear_combinations: impl IntoIterator<Item = &'a LinearCombination<G::ScalarField>>,
+                             polynomials: impl IntoIterator<Item = &'a LabeledPolynomial<G::ScalarField, P>>,
+                             commitments: impl IntoIterator<Item = &'a LabeledCommitment<Self::Commitment>>, query_set: &QuerySet<P::Point>,
+                             sponge: &mut impl CryptographicSponge, states: impl IntoIterator<Item = &'a Self::CommitmentState>,
+                             rng: Option<&mut dyn RngCore>) -> Result<BatchLCProof<G::ScalarField, Self::BatchProof>, Self::Error>
+    where
+        Self::CommitmentState: 'a,
+        Self::Commitment: 'a,
+        P: 'a,
+    {
+        let label_poly_map = polynomials.into_iter().zip(states).zip(commitments).map(|((p, s), c)| (p.label(), (p, s, c))).collect::<BTreeMap<_, _>>();
+        let mut lc_polynomials = Vec::new();
+        let mut lc_states = Vec::new();
+        let mut lc_commitments: Vec<G::Group> = Vec::new();
+        let mut lc_info = Vec::new();
+        for lc in linear_combinations {
+            let lc_label = lc.label().clone();
+            let mut poly = P::zero();
+            let mut degree_bound = None;
+            let mut hiding_bound = None;
+            let mut combined_comm = G::Group::zero();
+            let mut combined_shifted_comm: Option<G::Group> = None;
+            let mut combined_rand = G::ScalarField::zero();
+            let mut combined_shifted_rand: Option<G::ScalarField> = None;
+            let num_polys = lc.len();
+            for (coeff, label) in lc.iter().filter(|(_, l)| !l.is_one()) {
+                let label: &String = label.try_into().expect("cannot be one!");
+                let &(cur_poly, cur_rand, cur_comm) = label_poly_map.get(label).ok_or(Error::MissingPolynomial { label: label.to_string() })?;
+                if num_polys == 1 && cur_poly.degree_bound().is_some() {                       // :899-909
+                    assert!(coeff.is_one(), "Coefficient must be one for degree-bounded equations");
+                    degree_bound = cur_poly.degree_bound();
+                } else if cur_poly.degree_bound().is_some() {
+                    return Err(Error::EquationHasDegreeBounds(lc_label));
+                }
+                hiding_bound = core::cmp::max(hiding_bound, cur_poly.hiding_bound());          // Some(_) > None, always
+                poly += (*coeff, cur_poly.polynomial());
+                combined_rand += &(cur_rand.rand * coeff);
+                if let Some(new_rand) = cur_rand.shifted_rand {                                // combine_shifted_rand, :241-252
+                    let coeff_new_rand = new_rand * coeff;
+                    combined_shifted_rand = Some(combined_shifted_rand.map_or(coeff_new_rand, |r| r + &coeff_new_rand));
+                }
+                let commitment = cur_comm.commitment();
+                combined_comm += &commitment.comm.mul(*coeff);
+                if let Some(new_comm) = commitment.shifted_comm {                              // combine_shifted_comm, :254-265
+                    let coeff_new_comm = new_comm.mul(*coeff);
+                    combined_shifted_comm = Some(combined_shifted_comm.map_or(coeff_new_comm, |c| c + &coeff_new_comm));
+                }
+            }
+            lc_polynomials.push(LabeledPolynomial::new(lc_label.clone(), poly, degree_bound, hiding_bound));
+            lc_states.push(Randomness { rand: combined_rand, shifted_rand: combined_shifted_rand });
+            lc_commitments.push(combined_comm);
+            if let Some(combined_shifted_comm) = combined_shifted_comm {
+                lc_commitments.push(combined_shifted_comm);
+            }
+            lc_info.push((lc_label, degree_bound));
+        }
+        // construct_labeled_commitments (:267-300)
+        let comms = G::Group::normalize_batch(&lc_commitments);
+        let mut labeled = Vec::new();
+        let mut i = 0;
+        for (label, degree_bound) in lc_info.into_iter() {
+            let commitment = if degree_bound.is_some() {
+                i += 2;
+                Commitment { comm: comms[i - 2].clone(), shifted_comm: Some(comms[i - 1].clone()) }
+            } else {
+                i += 1;
+                Commitment { comm: comms[i - 1].clone(), shifted_comm: None }
+            };
+            labeled.push(LabeledCommitment::new(label, commitment, degree_bound));
+        }
+        let proof = Self::batch_open(ck, lc_polynomials.iter(), labeled.iter(), query_set, sponge, lc_states.iter(), rng)?;
+        Ok(BatchLCProof { proof, evals: None })
+    }
+    // batch_open: the trait's provided method (lib.rs:269-371) -- InnerProductArgPC does not override it -- calling the `open` above.
 }

@@ -184,60 +184,106 @@ fn marlin_kzg10_commit_open_equal_the_reference() {
 
 /// `open_combinations` / `check_combinations` (the shapes of the reference's `single_equation_test`, `two_equation_test` and
 /// `two_equation_degree_bound_test`, `poly-commit/src/lib.rs:1302-1384`, whose templates are private to the reference's own test
-/// module): the proofs `HipSonicKZG10::open_combinations` makes are the reference's, bit for bit, and the reference's verifier
-/// accepts them -- for combinations of several polynomials with coefficients other than one, with a constant term, and for a
-/// degree-bounded polynomial alone in its equation.  (Round-3 advisor finding: the shim used to pair the trait's default prover
-/// with Sonic's verifier, which rejects every honest proof of a real combination.)
-#[test]
-fn sonic_open_combinations_equal_the_reference_and_verify() {
-    use ark_bls12_381::{Bls12_381, Fr};
+/// module), generic over a (reference type, drop-in type) pair with the same associated types: the proofs the drop-in's
+/// `open_combinations` makes are the reference's, bit for bit (`evals: None`, one proof per query point over the COMBINED
+/// polynomials), and the reference's verifier accepts them -- for combinations of several polynomials with coefficients other than
+/// one, with a constant term, and for a degree-bounded polynomial alone in its equation; a wrong evaluation is rejected.
+/// (Round-3 advisor finding for Sonic, round-4 review for Marlin and the IPA: the trait's DEFAULT prover paired with the reference
+/// types' overriding verifiers rejects every honest proof of a real combination.)
+fn combinations_equal_the_reference_and_verify<F, Cpu, Hip>(d: usize, bound: usize, seed_v: u64)
+where
+    F: PrimeField,
+    Cpu: ark_poly_commit::PolynomialCommitment<F, DensePolynomial<F>>,
+    Hip: ark_poly_commit::PolynomialCommitment<F, DensePolynomial<F>, UniversalParams = Cpu::UniversalParams, CommitterKey = Cpu::CommitterKey,
+                                               VerifierKey = Cpu::VerifierKey, Commitment = Cpu::Commitment, CommitmentState = Cpu::CommitmentState,
+                                               Proof = Cpu::Proof, BatchProof = Cpu::BatchProof, Error = Cpu::Error>,
+    Cpu::Commitment: PartialEq + core::fmt::Debug,
+    Cpu::CommitmentState: PartialEq + core::fmt::Debug,
+    Cpu::BatchProof: PartialEq + core::fmt::Debug,
+    Cpu::Error: core::fmt::Debug,
+{
     use ark_pcs_bench_templates::test_sponge;
-    use ark_poly_commit::{sonic_pc::SonicKZG10, Evaluations, LCTerm, LabeledPolynomial, LinearCombination, PolynomialCommitment, QuerySet};
-    use poly_commit_hip::HipSonicKZG10;
-    type Poly = DensePolynomial<Fr>;
-    type Cpu = SonicKZG10<Bls12_381, Poly>;
-    type Hip = HipSonicKZG10<Bls12_381, Poly>;
+    use ark_poly_commit::{Evaluations, LCTerm, LabeledPolynomial, LinearCombination, QuerySet};
+    type Poly<F> = DensePolynomial<F>;
     let rng = &mut test_rng();
-    let d = (1 << 12) - 1;
     let pp = Cpu::setup(d, None, rng).unwrap();
-    let (ck, vk) = Cpu::trim(&pp, d, 1, Some(&[d - 9])).unwrap();
+    let (ck, vk) = Cpu::trim(&pp, d, 1, Some(&[bound])).unwrap();
     let polys = vec![
-        LabeledPolynomial::new("a".into(), Poly::rand(d, rng), None, None),
-        LabeledPolynomial::new("b".into(), Poly::rand(d, rng), None, Some(1)),
-        LabeledPolynomial::new("c".into(), Poly::rand(d - 9, rng), Some(d - 9), None),
+        LabeledPolynomial::new("a".into(), Poly::<F>::rand(d, rng), None, None),
+        LabeledPolynomial::new("b".into(), Poly::<F>::rand(d, rng), None, Some(1)),
+        LabeledPolynomial::new("c".into(), Poly::<F>::rand(bound, rng), Some(bound), None),
     ];
-    let seed = || <rand_chacha::ChaCha20Rng as rand_chacha::rand_core::SeedableRng>::seed_from_u64(11);
+    let seed = || <rand_chacha::ChaCha20Rng as rand_chacha::rand_core::SeedableRng>::seed_from_u64(seed_v);
     let (comms, states) = Hip::commit(&ck, &polys, Some(&mut seed())).unwrap();
     let (comms_cpu, states_cpu) = Cpu::commit(&ck, &polys, Some(&mut seed())).unwrap();
     assert_eq!(comms.iter().map(|c| c.commitment().clone()).collect::<Vec<_>>(), comms_cpu.iter().map(|c| c.commitment().clone()).collect::<Vec<_>>());
     assert_eq!(states, states_cpu);
     // eq0 = 2a + 3b - 5 (two polynomials, coefficients != 1, a constant), eq1 = a - b, eq2 = c alone (degree-bounded: coefficient one)
     let mut eq0 = LinearCombination::empty("eq0");
-    eq0.push((Fr::from(2u64), "a".to_string().into())); eq0.push((Fr::from(3u64), "b".to_string().into())); eq0.push((-Fr::from(5u64), LCTerm::One));
+    eq0.push((F::from(2u64), "a".to_string().into())); eq0.push((F::from(3u64), "b".to_string().into())); eq0.push((-F::from(5u64), LCTerm::One));
     let mut eq1 = LinearCombination::empty("eq1");
-    eq1.push((Fr::from(1u64), "a".to_string().into())); eq1.push((-Fr::from(1u64), "b".to_string().into()));
+    eq1.push((F::from(1u64), "a".to_string().into())); eq1.push((-F::from(1u64), "b".to_string().into()));
     let mut eq2 = LinearCombination::empty("eq2");
-    eq2.push((Fr::from(1u64), "c".to_string().into()));
+    eq2.push((F::from(1u64), "c".to_string().into()));
     let lcs = vec![eq0, eq1, eq2];
-    let (z0, z1) = (Fr::rand(rng), Fr::rand(rng));
+    let (z0, z1) = (F::rand(rng), F::rand(rng));
     let mut query_set = QuerySet::new();
     let mut evals = Evaluations::new();
-    let ev = |l: &str, z: Fr| ark_poly::Polynomial::evaluate(polys.iter().find(|p| p.label() == l).unwrap().polynomial(), &z);
+    let ev = |l: &str, z: F| ark_poly::Polynomial::evaluate(polys.iter().find(|p| p.label() == l).unwrap().polynomial(), &z);
     for (label, pname, z) in [("eq0", "z0", z0), ("eq1", "z0", z0), ("eq1", "z1", z1), ("eq2", "z1", z1)] {
         query_set.insert((label.to_string(), (pname.to_string(), z)));
-        let v = match label { "eq0" => Fr::from(2u64) * ev("a", z) + Fr::from(3u64) * ev("b", z) - Fr::from(5u64), "eq1" => ev("a", z) - ev("b", z), _ => ev("c", z) };
+        let v = match label { "eq0" => F::from(2u64) * ev("a", z) + F::from(3u64) * ev("b", z) - F::from(5u64), "eq1" => ev("a", z) - ev("b", z), _ => ev("c", z) };
         evals.insert((label.to_string(), z), v);
     }
-    let p_hip = Hip::open_combinations(&ck, &lcs, &polys, &comms, &query_set, &mut test_sponge::<Fr>(), &states, Some(&mut seed())).unwrap();
-    let p_cpu = Cpu::open_combinations(&ck, &lcs, &polys, &comms, &query_set, &mut test_sponge::<Fr>(), &states, Some(&mut seed())).unwrap();
+    let p_hip = Hip::open_combinations(&ck, &lcs, &polys, &comms, &query_set, &mut test_sponge::<F>(), &states, Some(&mut seed())).unwrap();
+    let p_cpu = Cpu::open_combinations(&ck, &lcs, &polys, &comms, &query_set, &mut test_sponge::<F>(), &states, Some(&mut seed())).unwrap();
     assert_eq!(p_hip.proof, p_cpu.proof);
-    assert!(p_hip.evals.is_none());
-    assert!(Cpu::check_combinations(&vk, &lcs, &comms, &query_set, &evals, &p_hip, &mut test_sponge::<Fr>(), rng).unwrap());
-    assert!(Hip::check_combinations(&vk, &lcs, &comms, &query_set, &evals, &p_hip, &mut test_sponge::<Fr>(), rng).unwrap());
+    assert!(p_hip.evals.is_none() && p_cpu.evals.is_none());
+    assert!(Cpu::check_combinations(&vk, &lcs, &comms, &query_set, &evals, &p_hip, &mut test_sponge::<F>(), rng).unwrap());
+    assert!(Hip::check_combinations(&vk, &lcs, &comms, &query_set, &evals, &p_hip, &mut test_sponge::<F>(), rng).unwrap());
+    // the batch methods the combinations run through, directly: the drop-in's batch_open equals the reference's, and both batch_checks accept it
+    let mut qs = QuerySet::new();
+    let mut vals = Evaluations::new();
+    for (label, pname, z) in [("a", "z0", z0), ("b", "z0", z0), ("b", "z1", z1), ("c", "z1", z1)] {
+        qs.insert((label.to_string(), (pname.to_string(), z)));
+        vals.insert((label.to_string(), z), ev(label, z));
+    }
+    let b_hip = Hip::batch_open(&ck, &polys, &comms, &qs, &mut test_sponge::<F>(), &states, Some(&mut seed())).unwrap();
+    let b_cpu = Cpu::batch_open(&ck, &polys, &comms, &qs, &mut test_sponge::<F>(), &states, Some(&mut seed())).unwrap();
+    assert_eq!(b_hip, b_cpu);
+    assert!(Cpu::batch_check(&vk, &comms, &qs, &vals, &b_hip, &mut test_sponge::<F>(), rng).unwrap());
+    assert!(Hip::batch_check(&vk, &comms, &qs, &vals, &b_hip, &mut test_sponge::<F>(), rng).unwrap());
     // a wrong evaluation is rejected
     let mut bad = evals.clone();
-    *bad.get_mut(&("eq0".to_string(), z0)).unwrap() += Fr::from(1u64);
-    assert!(!Cpu::check_combinations(&vk, &lcs, &comms, &query_set, &bad, &p_hip, &mut test_sponge::<Fr>(), rng).unwrap());
+    *bad.get_mut(&("eq0".to_string(), z0)).unwrap() += F::from(1u64);
+    assert!(!Cpu::check_combinations(&vk, &lcs, &comms, &query_set, &bad, &p_hip, &mut test_sponge::<F>(), rng).unwrap());
+}
+
+#[test]
+fn sonic_open_combinations_equal_the_reference_and_verify() {
+    use ark_bls12_381::{Bls12_381, Fr};
+    type Poly = DensePolynomial<Fr>;
+    let d = (1 << 12) - 1;
+    combinations_equal_the_reference_and_verify::<Fr, ark_poly_commit::sonic_pc::SonicKZG10<Bls12_381, Poly>, poly_commit_hip::HipSonicKZG10<Bls12_381, Poly>>(d, d - 9, 11);
+}
+
+#[test]
+fn marlin_open_combinations_equal_the_reference_and_verify() {
+    use ark_bls12_381::{Bls12_381, Fr};
+    type Poly = DensePolynomial<Fr>;
+    let d = (1 << 12) - 1;
+    combinations_equal_the_reference_and_verify::<Fr, ark_poly_commit::marlin_pc::MarlinKZG10<Bls12_381, Poly>, poly_commit_hip::HipMarlinKZG10<Bls12_381, Poly>>(d, d - 9, 13);
+}
+
+#[test]
+fn ipa_open_combinations_equal_the_reference_and_verify() {
+    // (the reference's own IPA tests run over JubJub, ipa_pc/mod.rs:1056-1064; Pallas is BASELINE configs[3]'s curve)
+    use ark_pallas::{Affine, Fr};
+    use blake2::Blake2s256;
+    type Poly = DensePolynomial<Fr>;
+    let d = (1 << 10) - 1;           // d + 1 a power of two (ipa_pc/mod.rs:350,375)
+    combinations_equal_the_reference_and_verify::<Fr, ark_poly_commit::ipa_pc::InnerProductArgPC<Affine, Blake2s256, Poly>,
+                                                  poly_commit_hip::HipIpaPC<Affine, Blake2s256, Poly>>(d, d - 9, 17);
 }
 
 /// Residency is bounded and observable: a key that `commit` made resident shows up in `pc_hip_ctx_bytes_resident`, `release`

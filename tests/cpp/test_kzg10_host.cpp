@@ -166,6 +166,67 @@ static void run(pc_ctx* ctx, const char* name) {
       // a degree bound the key does not enforce is rejected (Error::UnsupportedDegreeBound, kzg10/mod.rs:430-434)
       LabeledPolynomial<E> bad = polys[0]; bad.degree_bound = 11;
       CHECK(M::check_degrees_and_bounds(ck, bad).kind == Error::UnsupportedDegreeBound);
+
+      // ---- open_combinations (marlin/mod.rs:224-316; the shapes of single_equation / two_equation / two_equation_degree_bound,
+      // lib.rs:1302-1384): eq0 = 2 p2 + 3 p3 - 5 at z0;  eq1 = p2 - p3 at z0 and z1;  eq2 = p0 alone (degree-bounded, coefficient
+      // one) at z1.  ONE proof per point label over the COMBINED polynomials; checked the way check_combinations does it
+      // (marlin/mod.rs:318-409 -> batch_check -> accumulate_commitments_and_values :109-148), with the trapdoor in place of the
+      // pairing: per point   sum_k xi_k (C_k - v_k g) + sum_{bounded k} xi'_k (shC_k - v_k beta^(max - d_k) g) - random_v gamma_g
+      //                      == (beta - z) w,   C_k the combined commitments, v_k the equation's value MINUS its constant term.
+      {
+        auto L = [](const char* l) { return std::optional<std::string>(l); };
+        std::vector<LinearCombination<E>> lcs(3);
+        lcs[0].label = "eq0"; lcs[0].terms = {{Fr::from_u64(2), L("p2")}, {Fr::from_u64(3), L("p3")}, {Fr::zero() - Fr::from_u64(5), std::nullopt}};
+        lcs[1].label = "eq1"; lcs[1].terms = {{Fr::one(), L("p2")}, {Fr::zero() - Fr::one(), L("p3")}};
+        lcs[2].label = "eq2"; lcs[2].terms = {{Fr::one(), L("p0")}};
+        const Fr z0 = rng.next_fr(), z1 = rng.next_fr();
+        std::vector<Query<E>> qs = {{"eq2", "z1", z1}, {"eq1", "z1", z1}, {"eq0", "z0", z0}, {"eq1", "z0", z0}};     // (any order: a set)
+        Chal sp2;
+        std::vector<Proof<E>> proofs; std::vector<LabeledMarlinCommitment<E>> lcc;
+        CHECK(!M::open_combinations(ck, lcs, polys, comms, qs, sp2, states, proofs, &lcc));
+        CHECK(proofs.size() == 2 && lcc.size() == 3);                       // one proof per point label, BatchLCProof.evals = None
+        // the combined commitments are the combinations of the commitments (what the verifier rebuilds)
+        CHECK(lcc[0].commitment.comm == comms[2].comm.mul(Fr::from_u64(2)).add(comms[3].comm.mul(Fr::from_u64(3))) && !lcc[0].commitment.shifted_comm);
+        CHECK(lcc[1].commitment.comm == comms[2].comm.add(comms[3].comm.neg()));
+        CHECK(lcc[2].commitment.comm == comms[0].comm && lcc[2].commitment.shifted_comm && *lcc[2].commitment.shifted_comm == *comms[0].shifted_comm && lcc[2].degree_bound == polys[0].degree_bound);
+        auto val = [&](int k, const Fr& z) {                                // the combined polynomial's value = equation value - constant
+          const Fr a = polys[2].polynomial.evaluate(z), b = polys[3].polynomial.evaluate(z);
+          return k == 0 ? Fr::from_u64(2) * a + Fr::from_u64(3) * b : k == 1 ? a - b : polys[0].polynomial.evaluate(z);
+        };
+        size_t ci = 0;
+        const std::vector<std::vector<int>> at = {{0, 1}, {1, 2}};           // point "z0": eq0, eq1;  point "z1": eq1, eq2 (label order)
+        for (int pt = 0; pt < 2; pt++) {
+          const Fr z = pt == 0 ? z0 : z1;
+          G1Affine<E> acc = G1Affine<E>::zero();
+          for (int k : at[pt]) {
+            const Fr v = val(k, z), xi = sp2.log[ci++];
+            acc = acc.add(lcc[k].commitment.comm.add(g.mul(v).neg()).mul(xi));
+            if (lcc[k].degree_bound) {
+              const Fr xi1 = sp2.log[ci++];
+              Fr bp = Fr::one(); for (size_t i = 0; i < ck.max_degree - *lcc[k].degree_bound; i++) bp = bp * beta;
+              acc = acc.add(lcc[k].commitment.shifted_comm->add(g.mul(v * bp).neg()).mul(xi1));
+            }
+          }
+          if (hiding) acc = acc.add(gamma_g.mul(proofs[pt].random_v).neg());
+          CHECK(proofs[pt].has_random_v == hiding);
+          CHECK(acc == proofs[pt].w.mul(beta - z));
+        }
+        CHECK(ci == sp2.log.size());
+        // the trait's DEFAULT open_combinations (lib.rs:445-487) would have opened p0, p2, p3 individually: a different number of
+        // challenges and different proofs -- the verifier above could not accept them.  The reference's error paths:
+        std::vector<LinearCombination<E>> bad_lc(1);
+        bad_lc[0].label = "bad"; bad_lc[0].terms = {{Fr::one(), L("p0")}, {Fr::one(), L("p2")}};             // a bounded polynomial inside a real combination
+        Chal sp3;
+        CHECK(M::open_combinations(ck, bad_lc, polys, comms, {{"bad", "z0", z0}}, sp3, states, proofs).kind == Error::EquationHasDegreeBounds);
+        bad_lc[0].terms = {{Fr::one(), L("nope")}};
+        CHECK(M::open_combinations(ck, bad_lc, polys, comms, {{"bad", "z0", z0}}, sp3, states, proofs).kind == Error::MissingPolynomial);
+        // batch_open by itself: two polynomials at one point == one `open` over them in label order
+        Chal sa, sb;
+        std::vector<Proof<E>> bp1; Proof<E> single;
+        CHECK(!M::batch_open(ck, polys, {{"p3", "pt", z0}, {"p2", "pt", z0}}, sa, states, bp1));
+        CHECK(!M::open(ck, {polys[2], polys[3]}, z0, sb, {states[2], states[3]}, single));
+        CHECK(bp1.size() == 1 && bp1[0].w == single.w);
+      }
       ck.release();
     }
   }
@@ -353,7 +414,7 @@ static void run(pc_ctx* ctx, const char* name) {
     std::vector<G1Affine<E>> k3(key.begin(), key.begin() + 3);
     CHECK(InnerProductArgPC<E>::open_rounds(ctx, k3, odd, point, h_prime, ch, proof).kind == Error::Backend);    // not a power of two
   }
-  printf("%s: ipa cm_commit/open rounds, ligero reed_solomon/compute_matrices/commit/row_mul, marlin commit/open with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
+  printf("%s: ipa cm_commit/open rounds, ligero reed_solomon/compute_matrices/commit/row_mul, marlin commit/open/batch_open/open_combinations with degree bounds (hiding on/off), add_commitments, end_to_end (hiding on/off), leading zeros, degree/rng/hiding errors OK\n", name);
 }
 
 // Host arithmetic that needs no device: the reference's own calculate_t tests

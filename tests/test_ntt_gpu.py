@@ -186,3 +186,35 @@ def test_ligero_commit_fused_vs_restatement(ctx, curve):
     nodes3, leaves3 = ctx.ligero_commit(curve, co.reshape(n_rows, n_cols, 4), log_n, col_hash="sha256", tree_hash="blake2s", len_prefix=False)
     wl = _hashlib_columns(curve, want_ext, "sha256")
     assert nodes3.tobytes() == b"".join(R.merkle_tree([wl[j].tobytes() for j in range(1 << log_n)], "blake2s", False))
+
+
+@pytest.mark.parametrize("curve,log_n,in_cols", [("bls12_381", 18, 1 << 16), ("bls12_381", 18, 50000), ("pallas", 18, (1 << 18) - 3),
+                                                 ("bn254", 20, 1 << 18), ("bls12_381", 20, 300001), ("bls12_381", 22, 1 << 20),
+                                                 ("pallas", 22, (1 << 21) + 12345), ("bn254", 22, 1 << 22)])
+def test_ntt_large_sizes_dynamic_lds(ctx, curve, log_n, in_cols):
+    """log_n 18 .. PC_HIP_NTT_MAX_LOG_N = 22: one factor of the four-step split reaches 2^11, the tile (plus the stage twiddles)
+    needs more than the 64 KiB default of dynamic LDS (ntt.hpp: hipFuncAttributeMaxDynamicSharedMemorySize), and the zero-skip
+    covers ragged in_cols.  Whole rows against the oracle's NTT, test_reed_solomon's property (linear_codes/utils.rs:303-331) at a
+    few j, and the DC term."""
+    fr = R.FIELDS[R.CURVES[curve]["fr"]]["p"]
+    rows = 2 if log_n < 22 else 1
+    co = O.gen_scalars(curve, 0x22 + log_n + in_cols, rows * in_cols)
+    mont = O.f_to_mont(curve, 1, co).reshape(rows, in_cols, 4)
+    got = ctx.ntt_batch(curve, mont, log_n)
+    want = O.ntt_batch(curve, mont, log_n, 16)
+    assert (got == want).all()
+    w = O.fr_from_mont_array(curve, O.root_of_unity(curve, log_n).reshape(1, 4))[0]
+    for j in (1, (1 << log_n) // 3, (1 << log_n) - 1):
+        zj = O.fr_mont_array(curve, [pow(w, j, fr)])[0]
+        assert (got[rows - 1, j] == O.poly_eval(curve, np.ascontiguousarray(mont[rows - 1]), zj)).all(), j
+    assert O.fr_from_mont_array(curve, got[0, :1])[0] == sum(O.limbs_to_ints(co[:in_cols])) % fr
+
+
+def test_field_kernels_randomised_differential():
+    """tools/field_fuzz.py for a few seconds: the division scan (with carries and chained pieces), the batched NTT (ragged shapes,
+    the Horner property) and the fused IPA fold + inner products against the oracle / Python big ints on all three fields."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "field_fuzz.py"), "12", "20260927"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout

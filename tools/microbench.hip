@@ -80,6 +80,61 @@ __global__ void __launch_bounds__(256) k_fadd(uint32_t* out, int iters) {
   uint32_t r = 0; for (int i = 0; i < P::N; i++) r ^= x.l[i] ^ y.l[i];
   out[t] = r;
 }
+// memory-free radix-2 butterfly loop of the NTT (csrc/ntt.hpp lds_ntt_stages): (x, y) -> (x + w y, x - w y), one twiddle product, one
+// modular addition, one modular subtraction; the twiddle walks through a short register-resident cycle so that no product is constant
+template <class P>
+__global__ void __launch_bounds__(256) k_butterfly(uint32_t* out, int iters) {
+  typedef pc::Fd<P> F;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  F x = F::one(), y = F::one(), w = F::one();
+  x.l[0] += t; y.l[1] ^= t * 77; w.l[2] += t * 13 + 5;
+  for (int it = 0; it < iters; it++) {
+    const F v = y.mul(w);
+    const F a = x.add(v), b = x.sub(v);
+    x = a; y = b;
+    w.l[0] ^= (uint32_t)it;          // (keeps the compiler from hoisting anything; still a valid limb pattern below 2^255 for every field here)
+  }
+  uint32_t r = 0; for (int i = 0; i < P::N; i++) r ^= x.l[i] ^ y.l[i];
+  out[t] = r;
+}
+// the radix-4 group of two stages the kernel actually runs per LDS round trip: four elements, four twiddle products, eight additions
+template <class P>
+__global__ void __launch_bounds__(256) k_butterfly4(uint32_t* out, int iters) {
+  typedef pc::Fd<P> F;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  F x0 = F::one(), x1 = F::one(), x2 = F::one(), x3 = F::one(), w1 = F::one(), w2 = F::one(), w3 = F::one();
+  x0.l[0] += t; x1.l[1] ^= t * 77; x2.l[2] += t * 3; x3.l[3] ^= t * 5; w1.l[2] += t * 13 + 5; w2.l[1] += t + 9; w3.l[0] += 2 * t + 1;
+  for (int it = 0; it < iters; it++) {
+    x1 = x1.mul(w1); x3 = x3.mul(w1);
+    F a0 = x0.add(x1), a1 = x0.sub(x1), a2 = x2.add(x3), a3 = x2.sub(x3);
+    a2 = a2.mul(w2); a3 = a3.mul(w3);
+    x0 = a0.add(a2); x2 = a0.sub(a2); x1 = a1.add(a3); x3 = a1.sub(a3);
+    w1.l[0] ^= (uint32_t)it;
+  }
+  uint32_t r = 0; for (int i = 0; i < P::N; i++) r ^= x0.l[i] ^ x1.l[i] ^ x2.l[i] ^ x3.l[i];
+  out[t] = r;
+}
+// memory-free loops of the IPA key fold's ladder (csrc/glv.hpp EcFoldGlvBody): Jacobian doublings, Jacobian += affine
+template <class C>
+__global__ void __launch_bounds__(256) k_jac_dbl(uint32_t* out, const uint32_t* pts, int npts, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int AW = 2 * C::FqP::N;
+  pc::JacD<C> acc = pc::JacD<C>::infinity();
+  acc.add_affine(pc::AffD<C>::load(pts + (size_t)(t % npts) * AW));
+  for (int it = 0; it < iters; it++) acc = acc.dbl();
+  uint32_t r = 0; for (int i = 0; i < C::FqP::N; i++) r ^= acc.X.l[i] ^ acc.Z.l[i];
+  out[t] = r;
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_jac_madd(uint32_t* out, const uint32_t* pts, int npts, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int AW = 2 * C::FqP::N;
+  pc::JacD<C> acc = pc::JacD<C>::infinity();
+  for (int it = 0; it < iters; it++) acc.add_affine(pc::AffD<C>::load(pts + (size_t)((t * 31 + it) % npts) * AW));
+  uint32_t r = 0; for (int i = 0; i < C::FqP::N; i++) r ^= acc.X.l[i] ^ acc.Z.l[i];
+  out[t] = r;
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_madd(uint32_t* out, const uint32_t* pts, int npts, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,6 +232,10 @@ static int bench_madd(const char* name, uint32_t* out, int blocks, int threads) 
     float m4 = timeit([&]() { hipLaunchKernelGGL((k_madd_waves<C, 4>), dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
     printf("  kernel form %-12s at 2 / 3 / 4 waves per SIMD: %8.2f / %8.2f / %8.2f M madd/s\n", name,
            (double)lanes * it / m2 * 1e-3, (double)lanes * it / m3 * 1e-3, (double)lanes * it / m4 * 1e-3); }
+  // the ladder of the IPA key fold: Jacobian doubling / Jacobian += affine (bench.py prices EcFoldGlvBody against these two)
+  { float md = timeit([&]() { hipLaunchKernelGGL(k_jac_dbl<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    float ma = timeit([&]() { hipLaunchKernelGGL(k_jac_madd<C>, dim3(blocks), dim3(threads), 0, 0, out, dp, 64, it); });
+    printf("  jacobian %-12s dbl / madd: %8.2f / %8.2f M ops/s\n", name, (double)lanes * it / md * 1e-3, (double)lanes * it / ma * 1e-3); }
   CHECK(hipFree(dp));
   return 0;
 }
@@ -201,6 +260,14 @@ int main() {
     printf("fmul bn254_fq (8 limbs)      %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
     ms = timeit([&]() { hipLaunchKernelGGL(k_fmul<pc_pallas_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
     printf("fmul pallas_fq (8 limbs)     %8.3f ms  %8.2f G mulmod/s\n", ms, (double)lanes * it * 2 / ms * 1e-6);
+    // the scalar fields (the NTT's and the IPA vector kernels' multiplier)
+#define FR_LINE(P, NAME) { ms = timeit([&]() { hipLaunchKernelGGL(k_fmul<P>, dim3(blocks), dim3(threads), 0, 0, out, it); });                 \
+    printf("fmul %-16s (8 limbs) %8.3f ms  %8.2f G mulmod/s\n", NAME, ms, (double)lanes * it * 2 / ms * 1e-6);                              \
+    ms = timeit([&]() { hipLaunchKernelGGL(k_butterfly<P>, dim3(blocks), dim3(threads), 0, 0, out, 2 * it); });                              \
+    printf("  ntt butterfly %-16s      %8.3f ms  %8.2f G butterflies/s   (x + w y, x - w y: 1 product, 1 add, 1 sub)\n", NAME, ms, (double)lanes * it * 2 / ms * 1e-6); \
+    ms = timeit([&]() { hipLaunchKernelGGL(k_butterfly4<P>, dim3(blocks), dim3(threads), 0, 0, out, it / 2); });                             \
+    printf("  ntt radix-4 group %-16s  %8.3f ms  %8.2f G butterflies/s   (two stages on four elements in registers)\n", NAME, ms, (double)lanes * (it / 2) * 4 / ms * 1e-6); }
+    FR_LINE(pc_bls12_381_fr, "bls12_381_fr") FR_LINE(pc_bn254_fr, "bn254_fr") FR_LINE(pc_pallas_fr, "pallas_fr")
     for (int rep = 0; rep < 2; rep++) {
       ms = rep == 0 ? timeit([&]() { hipLaunchKernelGGL(k_fsqr<pc_bls12_381_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); })
                     : timeit([&]() { hipLaunchKernelGGL(k_fsqr<pc_bn254_fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
