@@ -750,8 +750,8 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
                  "note": "blocking pc_hip_msm with PC_MEM_HOST coefficients (pageable numpy memory, the H2D inside the call), then "
                          "pc_hip_kzg_open with the same host coefficients (copy + witness division + MSM in one call): the call "
                          "sequence of the trait's commit(&poly) / open(&poly) with nothing cached between them; from 2^23 "
-                         "coefficients on both calls run as two halves on two pipelines, the second half's PCIe copy under the "
-                         "first half's MSM"}
+                         "coefficients on both calls run as ONE MSM in parts (PC_HIP_HOST_PARTS, default weights 1,2,5,8): the PCIe copy "
+                         "and the sort of a part under the accumulation of the one before, one bucket reduction and one host tail"}
 
     # The kernels without a second pipeline competing for the CUs: strictly serial MSMs after the timed region.
     eng.blocking = False

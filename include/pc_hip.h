@@ -98,11 +98,16 @@ int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t
  * the GLV split k = k1 + k2*lambda (BLS12-381, BN254 and Pallas all have the j = 0 endomorphism phi(x, y) = (beta x, y)): HALF the
  * memory and build time (12.9 instead of 25.8 GB for a 2^24-point BLS12-381 key); every scalar is split on the device, the digits of
  * k2 go to a second bucket set with the SAME table points, and phi is applied once to that set's reduced sum -- the same number of
- * bucket additions, one more bucket set to reduce (+3 % per MSM at 2^24, more below 2^22).  PC_HIP_TABLE_GLV_IF_TIGHT: the GLV form
- * only when the full table would take more than half of the free device memory (what pc_hip_srs_precompute does unless
- * PC_HIP_TABLE_GLV=0/1 is set).  Results are bit-identical in every form. */
+ * bucket additions, one more bucket set to reduce (more below 2^22, where the reduction weighs more).  The split runs once per
+ * scalar in a kernel of its own (40-byte records the sort's two passes read).  PC_HIP_TABLE_GLV_IF_TIGHT: the GLV form only when the
+ * full table would take more than half of the free device memory.  PC_HIP_TABLE_GLV_IF_LARGE: the GLV form when the full table would
+ * exceed 4 GiB (PC_HIP_TABLE_GLV_LARGE_MB overrides), i.e. for keys of 2^22 BLS12-381 points and more -- where the table is what
+ * decides how many keys fit the device -- and the full table for small keys.  pc_hip_srs_precompute = IF_TIGHT (the full table is
+ * 7 % faster at 2^24: blocking MSM 38.4 vs 41.4 ms) unless the environment says PC_HIP_TABLE_GLV=0 / 1 / large.  Results are
+ * bit-identical in every form. */
 #define PC_HIP_TABLE_GLV 1
 #define PC_HIP_TABLE_GLV_IF_TIGHT 2
+#define PC_HIP_TABLE_GLV_IF_LARGE 4
 int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs, unsigned flags);
 size_t pc_hip_srs_len(const pc_srs* srs);
 /* Device pointer of the packed (x||y) resident bases, for callers that build on it. */

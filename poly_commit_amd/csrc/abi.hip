@@ -413,7 +413,7 @@ static uint32_t table_windows(const pc_srs* srs, uint32_t c, bool glv) {
   return pc::msm_num_windows(glv ? pc::GLV_HALF_BITS : pc::curve_ops(srs->curve).scalar_bits, c);
 }
 int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs, unsigned flags) {
-  if (!ctx || !srs || srs->ctx != ctx || window_bits == 1 || window_bits > 23 || (flags & ~(unsigned)(PC_HIP_TABLE_GLV | PC_HIP_TABLE_GLV_IF_TIGHT))) return PC_ERR_INVALID_ARG;
+  if (!ctx || !srs || srs->ctx != ctx || window_bits == 1 || window_bits > 23 || (flags & ~(unsigned)(PC_HIP_TABLE_GLV | PC_HIP_TABLE_GLV_IF_TIGHT | PC_HIP_TABLE_GLV_IF_LARGE))) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
     for (int i = 0; i < PC_MSM_LANES; i++)
@@ -433,6 +433,12 @@ int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, siz
     };
     uint32_t c, Wt; size_t bytes;
     geometry(glv, c, Wt, bytes);
+    if (!glv && (flags & PC_HIP_TABLE_GLV_IF_LARGE)) {
+      // large keys: half the table (a 2^24-point BLS12-381 key: 12.9 instead of 25.8 GB) for one more bucket set to reduce; small keys
+      // keep the full table (at 2^20 the second set's reduction costs 20 % of an MSM, the table only 1.6 GB)
+      static const size_t large = []() { const char* e = getenv("PC_HIP_TABLE_GLV_LARGE_MB"); return (size_t)(e ? atol(e) : 4096) << 20; }();
+      if (bytes > large) { glv = true; geometry(glv, c, Wt, bytes); }
+    }
     if (!glv && (flags & PC_HIP_TABLE_GLV_IF_TIGHT)) {
       // the full table (bits / c + 1 copies of the key: 25.8 GB for 2^24 BLS12-381 points) only when it leaves half of the free
       // memory to everything else; otherwise the GLV form (half the windows: the same additions, one more bucket set to reduce)
@@ -455,8 +461,10 @@ int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, siz
   });
 }
 int pc_hip_srs_precompute(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, size_t min_pairs) {
-  // PC_HIP_TABLE_GLV=1: every table in the GLV form; =0: never; unset: the full table unless device memory is tight
-  static const unsigned flags = []() { const char* e = getenv("PC_HIP_TABLE_GLV"); return !e ? (unsigned)PC_HIP_TABLE_GLV_IF_TIGHT : atoi(e) ? (unsigned)PC_HIP_TABLE_GLV : 0u; }();
+  // PC_HIP_TABLE_GLV=1: every table in the GLV form; =0: never; =large: for keys whose full table exceeds 4 GiB; unset: the full table
+  // unless device memory is tight (round 5: the GLV form costs 7 % of a pipelined 2^24 step -- split 0.6 ms, second bucket set 1.1 ms --
+  // for 12.9 GB less: speed is the default, memory the option)
+  static const unsigned flags = []() { const char* e = getenv("PC_HIP_TABLE_GLV"); return !e ? (unsigned)PC_HIP_TABLE_GLV_IF_TIGHT : !strcmp(e, "large") ? (unsigned)(PC_HIP_TABLE_GLV_IF_TIGHT | PC_HIP_TABLE_GLV_IF_LARGE) : atoi(e) ? (unsigned)PC_HIP_TABLE_GLV : 0u; }();
   return pc_hip_srs_precompute_ex(ctx, srs, window_bits, min_pairs, flags);
 }
 size_t pc_hip_srs_len(const pc_srs* srs) { return srs ? srs->n : 0; }
@@ -486,6 +494,40 @@ static void complete_two(pc_ctx* ctx, pc_job* a, pc_job* b) {
   if (!a->done) { complete_job(ctx, a); for (int i = 0; i < 8; i++) ph[i] = ctx->phases[i]; }
   if (!b->done) { complete_job(ctx, b); for (int i = 0; i < 8; i++) ctx->phases[i] += ph[i]; }
 }
+// Host scalars of at least host_split_min() pairs: ONE MSM in PC_HIP_HOST_PARTS parts (default 4; 0 = the two half-size MSMs on two
+// pipelines of round 4) on one pipeline -- MsmPlan::begin_parts: the copy and sort of part k + 1 run beside the accumulation of part k,
+// all parts share one bucket reduction and one host tail.
+// PC_HIP_HOST_PARTS: a part count (equal parts) or a comma list of relative weights (default "1,2,5,8": a short first part, so that the
+// first copy and sort -- the only ones nothing hides -- are short; measured at 2^24 BLS12-381: commit of host coefficients 40.3 ms against
+// 38.5 resident and 46.8 as two half-size MSMs, open 41.7 against 39.5 / 46.8; four equal parts 44.0 / 45.3, "1,3,4,8" 40.9 / 42.4).
+static const std::vector<double>& host_part_cuts() {      // cumulative fractions: cuts[0] = 0 < ... < cuts[K] = 1; empty = no parts
+  static const std::vector<double> cuts = []() {
+    std::vector<double> w;
+    const char* e = getenv("PC_HIP_HOST_PARTS");
+    std::string spec = e ? e : "1,2,5,8";
+    if (spec.find(',') == std::string::npos) { int k = atoi(spec.c_str()); if (k > 8) k = 8; for (int i = 0; i < k; i++) w.push_back(1.0); }
+    else { size_t at = 0; while (at <= spec.size() && w.size() < 8) { size_t c = spec.find(',', at); if (c == std::string::npos) c = spec.size(); double v = atof(spec.substr(at, c - at).c_str()); if (v > 0) w.push_back(v); at = c + 1; } }
+    std::vector<double> out;
+    if (w.size() < 2) return out;
+    double tot = 0; for (double v : w) tot += v;
+    double acc = 0; out.push_back(0.0);
+    for (double v : w) { acc += v; out.push_back(acc / tot); }
+    out.back() = 1.0;
+    return out;
+  }();
+  return cuts;
+}
+static size_t host_parts() { return host_part_cuts().empty() ? 0 : host_part_cuts().size() - 1; }
+static size_t part_cut(size_t n, size_t k) { const auto& c = host_part_cuts(); return k + 1 >= c.size() ? n : (size_t)((double)n * c[k]); }
+// claim the next pipeline of the key for a job in parts (completing what it still holds)
+static MsmLane* claim_lane(pc_ctx* ctx, pc_srs* srs, void* out_xy, int* out_is_infinity, pc_job* job) {
+  int li = srs->next_lane; srs->next_lane = (srs->next_lane + 1) % PC_MSM_LANES;
+  MsmLane* L = srs_lane(srs, li);
+  if (L->inflight) complete_job(ctx, L->inflight);
+  L->be.timing = ctx->be.timing;
+  job->srs = srs; job->lane = li; job->out_xy = (uint32_t*)out_xy; job->out_inf = out_is_infinity; job->done = false;
+  return L;
+}
 // sum of two affine results into out_xy / out_is_infinity
 static void fold_two(pc_srs* srs, const uint32_t* a, const uint32_t* b, void* out_xy, int* out_is_infinity) {
   std::vector<uint32_t> two(2 * (size_t)srs->aw);
@@ -502,6 +544,20 @@ int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void*
   return guarded(ctx, [&]() {
     const size_t avail = base_offset <= srs->n ? srs->n - base_offset : 0;
     const size_t ne = n < avail ? n : avail;
+    if (where == PC_MEM_HOST && scalars && ne >= host_split_min() && base_offset <= srs->n && host_parts() >= 2) {
+      const size_t K = host_parts();
+      StackJob j(ctx);
+      MsmLane* L = claim_lane(ctx, srs, out_xy, out_is_infinity, &j.job);
+      L->runner->begin_parts(ne);
+      L->inflight = &j.job;                      // from here on the pipeline holds work of this job (StackJob completes it on any exit)
+      std::vector<std::pair<size_t, size_t>> parts;        // (first, count), empty parts dropped
+      for (size_t k = 0; k < K; k++) { const size_t first = part_cut(ne, k), cnt = part_cut(ne, k + 1) - first; if (cnt) parts.push_back({first, cnt}); }
+      for (size_t k = 0; k < parts.size(); k++)
+        L->runner->add_part(srs->bases, (uint32_t)base_offset, parts[k].first, (const uint8_t*)scalars + parts[k].first * 32, PC_MEM_HOST, parts[k].second,
+                            form == PC_SCALARS_MONTGOMERY, k + 1 == parts.size());
+      complete_job(ctx, &j.job);
+      return (int)PC_OK;
+    }
     if (where == PC_MEM_HOST && scalars && ne >= host_split_min() && base_offset <= srs->n) {
       const size_t h = ne / 2;
       std::vector<uint32_t> r1(srs->aw), r2(srs->aw);
@@ -975,6 +1031,27 @@ int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const 
     CallBuf xbuf(ctx->be, 0, m * 32);
     uint32_t* x = (uint32_t*)xbuf.dev;
     const uint8_t* src = (const uint8_t*)coeffs + 32;
+    if (host_parts() >= 2) {
+      // the quotient in parts, TOP part first (its scan needs nothing from below; every further part takes the carry q[hi] of the one
+      // above): copy + division of part t + 1 on the context's queue beside the accumulation of part t on the key's pipeline; one MSM
+      const size_t K = host_parts();
+      std::vector<uint32_t> carry(8);
+      StackJob j(ctx);
+      MsmLane* L = claim_lane(ctx, srs, out_xy, out_is_infinity, &j.job);
+      L->runner->begin_parts(m);
+      L->inflight = &j.job;
+      std::vector<std::pair<size_t, size_t>> parts;        // (lo, hi) from the top; part t of the weights counted from the top
+      for (size_t t = 0; t < K; t++) { const size_t hi = m - part_cut(m, t), lo = m - part_cut(m, t + 1); if (hi > lo) parts.push_back({lo, hi}); }
+      for (size_t t = 0; t < parts.size(); t++) {
+        const size_t lo = parts[t].first, hi = parts[t].second, len = hi - lo;
+        ctx->be.copy_h2d(x + lo * 8, src + lo * 32, len * 32);
+        if (t) ctx->be.copy_d2h(carry.data(), q + hi * 8, 32);
+        F.div_scan(ctx->be, x + lo * 8, len, z, t ? carry.data() : nullptr, q + lo * 8, scan_fan());      // (returns with the stream drained)
+        L->runner->add_part(srs->bases, (uint32_t)base_offset, lo, q + lo * 8, PC_MEM_DEVICE, len, true, t + 1 == parts.size());
+      }
+      complete_job(ctx, &j.job);
+      return (int)PC_OK;
+    }
     const size_t h = m / 2;
     std::vector<uint32_t> r1(srs->aw), r2(srs->aw), carry(8);
     StackJob j1(ctx), j2(ctx);

@@ -94,6 +94,19 @@ struct MsmRunnerT : MsmRunner {
     }
     plan.enqueue(bases, base_off, sdev, n, from_mont);
   }
+  void begin_parts(size_t n_total) override { be.n_ev = 0; be.mark(); plan.begin_parts(n_total); }
+  void add_part(const uint32_t* bases, uint32_t base_off, size_t first, const void* scalars_part, pc_mem where, size_t n, bool from_mont, bool last) override {
+    const uint32_t* sdev = (const uint32_t*)scalars_part;
+    int tok = -1;
+    if (where == PC_MEM_HOST && n) {      // the copy rides on the auxiliary queue (in order before this part's sort), beside the previous part's accumulation
+      uint32_t* dst = plan.scalar_staging() + first * (size_t)C::FrP::N;
+      be.aux_begin(-1, -1);
+      be.copy_h2d(dst, scalars_part, n * (size_t)C::FrP::N * 4);
+      tok = be.aux_end();
+      sdev = dst;
+    }
+    plan.add_part(bases, base_off + (uint32_t)first, sdev, n, from_mont, tok, last);
+  }
   void enqueue_vectors(const uint32_t* bases, uint32_t base_off, const uint64_t* ptrs_host, size_t count, size_t m, bool from_mont) override {
     be.n_ev = 0; be.mark();
     plan.enqueue_vectors(bases, base_off, ptrs_host, count, m, from_mont);

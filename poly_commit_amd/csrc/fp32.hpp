@@ -17,6 +17,12 @@
 #ifndef PC_LAZY_N8
 #define PC_LAZY_N8 1
 #endif
+// tuning experiment switch: 1 closes a Montgomery column with four simple instructions where p = 1 (mod 2^32) (close_column below).
+// Measured slower (round 5, profiles/EXPERIMENTS.md): the pair v_mul_lo_u32 + v_mad_u64_u32 it replaces costs less than the five
+// instructions the compiler makes of it (BLS12-381 Fr NTT 5.20 -> 5.31 ms, Pallas Fq product 157 -> 154 G/s): off.
+#ifndef PC_P0_ONE
+#define PC_P0_ONE 0
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -168,6 +174,22 @@ struct Fd {
     const uint32_t p0 = P::MOD[0];
     macs1(acc, hi, mk, &p0);
   }
+  // Moduli with p = 1 (mod 2^32) -- BLS12-381 Fr, both Pasta fields -- have INV = -p^-1 = -1 (mod 2^32): the Montgomery factor of a
+  // column is m = -acc_lo, and m * p_0 = m only clears the low word of the accumulator and carries iff that word was not zero.
+  // Closes a column (m, the term m * p_0 and the shift to the next column) in four simple instructions instead of v_mul_lo_u32 +
+  // v_mad_u64_u32 + v_addc (the two multiplier instructions are several times the issue cost of an addition on this part).
+  static constexpr bool P0_ONE = PC_P0_ONE && P::MOD[0] == 1u && P::INV == 0xffffffffu;
+  static __device__ __forceinline__ void close_column(uint32_t& mk, uint64_t& acc, uint32_t& hi) {
+    if constexpr (P0_ONE) {
+      const uint32_t lo = (uint32_t)acc;
+      mk = 0u - lo;
+      acc = ((acc >> 32) | ((uint64_t)hi << 32)) + (uint64_t)(lo != 0u);      // < 2^64: the 96-bit column sum carries at most into its own top words
+    } else {
+      mk = (uint32_t)acc * P::INV;
+      red_last(&mk, acc, hi);
+      acc = (acc >> 32) | ((uint64_t)hi << 32);
+    }
+  }
 
   // UNIT: the second operand is the raw integer 1 (Montgomery -> canonical conversion): the only
   // a_i * b_j left in column K is a_K * 1, so a column is one product plus the reduction terms.
@@ -181,9 +203,7 @@ struct Fd {
     else { PC_UNROLL for (int i = 0; i <= K; i++) { x[c] = l[i]; y[c] = o.l[K - i]; c++; } }
     mac_n<CNT, true>(acc, hi, x, y);
     red_terms<K, 0, K - 1, false>(m, acc, hi);
-    m[K] = (uint32_t)acc * P::INV;
-    red_last(&m[K], acc, hi);
-    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    close_column(m[K], acc, hi);
     if constexpr (K + 1 < N) column_lo<K + 1, UNIT>(o, m, mod, acc, hi);
   }
   template <int K, bool UNIT>
@@ -235,9 +255,7 @@ struct Fd {
     PC_UNROLL for (int i = 0; i <= K; i++) { x[n] = c.l[i]; y[n] = d.l[K - i]; n++; }
     mac_n<CNT, true>(acc, hi, x, y);
     red_terms<K, 0, K - 1, false>(m, acc, hi);
-    m[K] = (uint32_t)acc * P::INV;
-    red_last(&m[K], acc, hi);
-    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    close_column(m[K], acc, hi);
     if constexpr (K + 1 < N) dual_column_lo<K + 1>(b, c, d, m, mod, acc, hi);
   }
   template <int K>
@@ -282,9 +300,7 @@ struct Fd {
     if constexpr ((K & 1) == 0) { x[c] = l[K / 2]; y[c] = l[K / 2]; c++; }
     mac_n<CNT, true>(acc, hi, x, y);
     red_terms<K, 0, K - 1, CNT == 0>(m, acc, hi);
-    m[K] = (uint32_t)acc * P::INV;
-    red_last(&m[K], acc, hi);
-    acc = (acc >> 32) | ((uint64_t)hi << 32);
+    close_column(m[K], acc, hi);
     if constexpr (K + 1 < N) sq_column_lo<K + 1>(d, dm, m, mod, acc, hi);
   }
   template <int K>

@@ -173,6 +173,9 @@ struct HipBackend {
     if (main_stream) stream = main_stream;
     if (tail_stream) (void)hipStreamDestroy(tail_stream);
     if (tail_ev) (void)hipEventDestroy(tail_ev);
+    if (aux_saved) { stream = aux_saved; aux_saved = nullptr; }
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    for (int i = 0; i < N_TOK; i++) if (tok_ev[i]) (void)hipEventDestroy(tok_ev[i]);
     if (stream) (void)hipStreamDestroy(stream);
   }
   // release every grow-only scratch buffer (they come back on demand); the stream must be idle
@@ -183,7 +186,31 @@ struct HipBackend {
     for (int i = 0; i < 2; i++) { free(stage_ws[i]); stage_ws[i] = nullptr; stage_bytes[i] = 0; }
   }
   size_t scratch_bytes() const { return scan_tmp_bytes + sort_ws_bytes + work_ws_bytes + stage_bytes[0] + stage_bytes[1]; }
-  void mark() { if (timing && n_ev < MAX_EV) PC_HIP_CHECK(hipEventRecord(ev[n_ev++], stream)); }
+  void mark() { if (timing && marks_on && n_ev < MAX_EV) PC_HIP_CHECK(hipEventRecord(ev[n_ev++], stream)); }
+  bool marks_on = true;
+  bool timing_marks(bool on) { const bool was = marks_on; marks_on = on; return was; }      // suppress the phase marks of inner steps (an MSM in parts)
+
+  // ---- auxiliary queue of a pipeline (MsmPlan::add_part): the sort of the next part of an MSM, and the copy of its scalars, run here
+  // beside the accumulation of the current part on the main queue.  Tokens are events from a small ring; -1 = nothing to wait for.
+  static constexpr int N_TOK = 16;
+  hipStream_t aux_stream = nullptr, aux_saved = nullptr;
+  hipEvent_t tok_ev[N_TOK] = {};
+  int tok_next = 0;
+  int new_token(hipStream_t s) {
+    const int t = tok_next; tok_next = (tok_next + 1) % N_TOK;
+    if (!tok_ev[t]) PC_HIP_CHECK(hipEventCreateWithFlags(&tok_ev[t], hipEventDisableTiming));
+    PC_HIP_CHECK(hipEventRecord(tok_ev[t], s));
+    return t;
+  }
+  void aux_begin(int wait_a, int wait_b) {      // everything queued until aux_end() goes to the auxiliary queue, after the two tokens
+    if (!aux_stream) PC_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    aux_saved = stream; stream = aux_stream;
+    if (wait_a >= 0) PC_HIP_CHECK(hipStreamWaitEvent(aux_stream, tok_ev[wait_a], 0));
+    if (wait_b >= 0) PC_HIP_CHECK(hipStreamWaitEvent(aux_stream, tok_ev[wait_b], 0));
+  }
+  int aux_end() { const int t = new_token(aux_stream); stream = aux_saved; aux_saved = nullptr; return t; }
+  void wait_token(int t) { if (t >= 0) PC_HIP_CHECK(hipStreamWaitEvent(stream, tok_ev[t], 0)); }
+  int main_token() { return new_token(stream); }
 
   size_t bytes_live = 0;      // device bytes currently allocated through THIS backend (a pipeline's workspace, a context's buffers)
   void* alloc(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(dev_malloc(&p, bytes ? bytes : 4)); bytes_live += bytes ? bytes : 4; return p; }

@@ -21,7 +21,8 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   // workspace: G[nblocks][NC] | bintotal[NC+1] | binbase[NC+1] | records[n*W] (8 B each)
   const size_t gw = (size_t)sg.nblocks * sg.NC, nb1 = (size_t)sg.NC + 1;
   const size_t rec_off = ((gw + 2 * nb1) * 4 + 15) & ~(size_t)15;
-  const size_t need = rec_off + (size_t)g.n * g.Wd * 8;
+  const size_t split_off = rec_off + (size_t)g.n * g.Wd * 8;                       // GLV table mode: the pre-split scalars behind the records
+  const size_t need = split_off + (g.glv ? (size_t)g.n * GLV_SPLIT_WORDS * 4 : 0);
   if (need > sort_ws_bytes) {
     if (sort_ws) { PC_HIP_CHECK(hipStreamSynchronize(stream)); free(sort_ws); sort_ws = nullptr; sort_ws_bytes = 0; }
     sort_ws = alloc(need); sort_ws_bytes = need;
@@ -29,21 +30,25 @@ void HipBackend::sort_entries(const MsmGeom& g, const uint32_t* scalars, uint32_
   uint32_t* G = (uint32_t*)sort_ws; uint32_t* bintotal = G + gw; uint32_t* binbase = bintotal + nb1;
   uint2* records = (uint2*)((char*)sort_ws + rec_off);
   const size_t lds = (size_t)sg.NC * 4;
+  uint32_t* split = (uint32_t*)((char*)sort_ws + split_off);
+  if (g.glv) {      // k = k1 + k2 lambda once per scalar (Montgomery -> canonical fused): both passes below read the 40-byte records
+    GlvPresplitBody<C> b{g, scalars, split};
+    launch(b, g.n);
+  }
   auto pass = [&](auto scatter_tag, const uint32_t* bb, uint2* rec, int threads) {
     constexpr bool SC = decltype(scatter_tag)::value;
     if (g.glv) {
-      if (lds > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, SC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_sort_pass<C, SC, true>), dim3(sg.nblocks), dim3(threads), lds, stream, sg, scalars, G, bb, rec);
+      if (lds > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, SC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_sort_pass<C, SC, 2>), dim3(sg.nblocks), dim3(threads), lds, stream, sg, (const uint32_t*)split, G, bb, rec);
     } else {
-      if (lds > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, SC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_sort_pass<C, SC, false>), dim3(sg.nblocks), dim3(threads), lds, stream, sg, scalars, G, bb, rec);
+      if (lds > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_pass<C, SC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_sort_pass<C, SC, 0>), dim3(sg.nblocks), dim3(threads), lds, stream, sg, scalars, G, bb, rec);
     }
     PC_HIP_CHECK(hipGetLastError());
   };
   // 512 workgroups cover the chip twice at most: with 256 lanes each that is 2 waves per SIMD for two passes that are bound
   // by DRAM latency (a scalar load, ~13 LDS atomics and as many 8-byte stores per lane and iteration).  16 waves per workgroup
   // give 8 per SIMD; the LDS histogram (<= 64 KiB) still allows two workgroups per CU.  PC_HIP_SORT_THREADS overrides (tuning).
-  // (the GLV passes hold the scalar split's temporaries: ~94 VGPRs, one 1024-lane workgroup per CU)
   static const int threads_env = []() { const char* e = getenv("PC_HIP_SORT_THREADS"); return e ? atoi(e) : 0; }();
   const int sort_threads = threads_env ? threads_env : (lds > 32 * 1024 || g.n >= 65536) ? 1024 : 256;
   pass(std::false_type{}, (const uint32_t*)nullptr, (uint2*)nullptr, sort_threads);

@@ -169,12 +169,15 @@ PC_HD void for_each_window_limbs(const uint32_t* s, uint32_t c, uint32_t Wd, F f
 // Every non-zero signed digit of one scalar: f(half, window, magnitude in [1, 2^(c-1)], negative).  Plain mode: half = 0, the
 // scalar's Wd windows.  GLV table mode (Geo::glv): the scalar is split into k1, k2 (GlvHalves), each half is recoded over
 // Wd / 2 windows and a half's own sign flips its digits' signs.  Geo: MsmGeom or SortGeom.
-template <class C, bool GLV, class Geo, class F>
+// GLV: 0 plain, 1 the split done here, 2 `scalar` points at a PRE-SPLIT record (GlvPresplit below: the halves' magnitudes, canonical,
+// their signs in the top bits) -- the form the LDS sort's two passes read after k_glv_presplit ran once.
+static constexpr int GLV_SPLIT_WORDS = 10;            // 2 x 5 limbs per pre-split scalar (40 bytes)
+template <class C, int GLV, class Geo, class F>
 PC_HD void for_each_signed_digit_t(const Geo& g, const uint32_t* scalar, F f) {
   typedef typename C::FrP FrP;
-  ScalarDigits<FrP> sd; sd.load(scalar, g.from_mont);
   const uint32_t half = 1u << (g.c - 1);
-  if constexpr (!GLV) {
+  if constexpr (GLV == 0) {
+    ScalarDigits<FrP> sd; sd.load(scalar, g.from_mont);
     uint32_t carry = 0;
     sd.for_each_window(g.c, g.Wd, [&](uint32_t w, uint32_t bits) {
       const uint32_t raw = bits + carry;
@@ -183,11 +186,21 @@ PC_HD void for_each_signed_digit_t(const Geo& g, const uint32_t* scalar, F f) {
       if (mag) f(0u, w, mag, carry);
     });
   } else {
-    GlvHalves<C> hv; hv.split(sd.s);
+    uint32_t m[2][5], neg[2];
+    if constexpr (GLV == 1) {
+      ScalarDigits<FrP> sd; sd.load(scalar, g.from_mont);
+      GlvHalves<C> hv; hv.split(sd.s);
+      PC_UNROLL for (int h = 0; h < 2; h++) { neg[h] = hv.neg[h]; PC_UNROLL for (int k = 0; k < 5; k++) m[h][k] = hv.m[h][k]; }
+    } else {
+      PC_UNROLL for (int h = 0; h < 2; h++) {
+        PC_UNROLL for (int k = 0; k < 5; k++) m[h][k] = scalar[5 * h + k];
+        neg[h] = m[h][4] >> 31; m[h][4] &= 0x7fffffffu;
+      }
+    }
     PC_UNROLL for (int h = 0; h < 2; h++) {
       uint32_t carry = 0;
-      const uint32_t ng = hv.neg[h];
-      for_each_window_limbs<5>(hv.m[h], g.c, g.Wd / 2, [&](uint32_t w, uint32_t bits) {
+      const uint32_t ng = neg[h];
+      for_each_window_limbs<5>(m[h], g.c, g.Wd / 2, [&](uint32_t w, uint32_t bits) {
         const uint32_t raw = bits + carry;
         carry = raw > half;
         const uint32_t mag = carry ? (2 * half - raw) : raw;
@@ -196,11 +209,30 @@ PC_HD void for_each_signed_digit_t(const Geo& g, const uint32_t* scalar, F f) {
     }
   }
 }
+// One scalar -> its pre-split record (the sort's GLV passes then cost what the plain ones do: the split's temporaries tripled
+// their registers, 33 -> 83-94 VGPRs, which kept them from running beside an accumulation -- round 4: pipelined step 76.8 vs 69.3 ms)
+template <class C>
+struct GlvPresplitBody {
+  typedef typename C::FrP FrP;
+  MsmGeom g;
+  const uint32_t* scalars;
+  uint32_t* split;          // n x GLV_SPLIT_WORDS
+  PC_HD void operator()(uint32_t i) const {
+    uint32_t sub, j; g.split(i, sub, j);
+    ScalarDigits<FrP> sd; sd.load(g.scalar_at(scalars, i, sub, j, FrP::N), g.from_mont);
+    GlvHalves<C> hv; hv.split(sd.s);
+    uint32_t* o = split + (size_t)i * GLV_SPLIT_WORDS;
+    PC_UNROLL for (int h = 0; h < 2; h++) {
+      PC_UNROLL for (int k = 0; k < 4; k++) o[5 * h + k] = hv.m[h][k];
+      o[5 * h + 4] = hv.m[h][4] | (hv.neg[h] << 31);          // |k_h| < 2^130: limb 4 holds two bits
+    }
+  }
+};
 // (the mode as a run-time flag: the CPU-stepped bodies and the atomic reference sort; the LDS sort's kernels take it as a template
 // parameter -- the split's temporaries would triple the registers of the plain passes, 33 -> 94 VGPRs, and halve their occupancy)
 template <class C, class Geo, class F>
 PC_HD void for_each_signed_digit(const Geo& g, const uint32_t* scalar, F f) {
-  if (g.glv) for_each_signed_digit_t<C, true>(g, scalar, f); else for_each_signed_digit_t<C, false>(g, scalar, f);
+  if (g.glv) for_each_signed_digit_t<C, 1>(g, scalar, f); else for_each_signed_digit_t<C, 0>(g, scalar, f);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -632,6 +664,21 @@ struct SubFoldBody {
   }
 };
 
+// A[k] += B[k] over two bucket arrays (an MSM run in parts: every part after the first accumulates into a second bucket array,
+// which is folded into the first before the one bucket reduction; MsmPlan::add_part)
+template <class C>
+struct BucketMergeBody {
+  typedef XyzzD<C> Pt;
+  uint32_t* a; const uint32_t* b;
+  PC_HD void operator()(uint32_t k) const {
+    const Pt y = Pt::load(b + (size_t)k * Pt::WORDS);
+    if (y.is_inf()) return;
+    Pt x = Pt::load(a + (size_t)k * Pt::WORDS);
+    x.add(y);
+    x.store(a + (size_t)k * Pt::WORDS);
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 // Orchestration
 // ---------------------------------------------------------------------------------------
@@ -790,7 +837,8 @@ class MsmPlan {
   }
   ~MsmPlan() { release(); }
   void release() {
-    void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_};
+    void* ps[] = {hist_, offsets_, cursor_, entries_, buckets_, scalars_, pk_[0], pk_[1], pp_[0], pp_[1], red_, entries2_, offsets2_, buckets2_, hist2_, cursor2_};
+    entries2_ = offsets2_ = buckets2_ = hist2_ = cursor2_ = nullptr;
     for (void* p : ps) be_.free(p);
     be_.free_host(result_host_);
     be_.free(tab_); be_.free_host(tab_host_); tab_ = nullptr; tab_host_ = nullptr;
@@ -827,6 +875,47 @@ class MsmPlan {
     pending_empty_ = (n == 0);
     if (n == 0) return;
     plan_geometry(n);
+    parts_k_ = 0; in_parts_ = false;
+    part_body(bases_dev, base_off, scalars_dev, n, from_mont, m_sub, scalar_tab, /*first=*/true, /*last=*/true);
+    reduce_and_download();
+  }
+
+  // ---- one MSM in PARTS (host scalars: a blocking call cannot hide the PCIe copy of its scalars behind anything but its own work) ----
+  // The MSM is a sum over index ranges: part k sorts and accumulates scalars [first_k, first_k + n_k) against bases base_off + first_k ..
+  // with the geometry (window width, buckets, reduction plan) of the WHOLE call; every part after the first accumulates into a second
+  // bucket array that is folded into the first one (BucketMergeBody: 2^(c-1) additions), and ONE bucket reduction + host tail close
+  // the call.  The sort of part k + 1 (and, in the runner, the copy of its scalars) runs on the backend's auxiliary queue beside the
+  // accumulation of part k (sort outputs are double-buffered), so what a blocking call adds to the resident MSM is the copy and sort
+  // of its FIRST part and the merges -- not the whole copy (round 4: two half-size MSMs on two pipelines, each with its own bucket
+  // reduction and tail: the second half's copy hidden, 47.8 ms for a commit of 2^24 host coefficients against 38.3 ms resident).
+  void begin_parts(size_t n_total) {
+    if (subs_) throw std::runtime_error("MsmPlan: parts are for single MSMs");
+    pending_empty_ = (n_total == 0);
+    if (n_total == 0) return;
+    if (n_total > n_max_) throw MsmCapacityError("MsmPlan: call exceeds the workspace this plan was sized for");
+    plan_geometry(n_total);
+    parts_k_ = 0; in_parts_ = true; parts_n_ = 0;
+    if (!entries2_) {        // second sort output + second bucket array, on first use (freed with the plan)
+      entries2_ = (uint32_t*)be_.alloc((entries_cap_ / 2 + 64) * 4);
+      offsets2_ = (uint32_t*)be_.alloc((nb_cap_ + 1) * 4);
+      buckets2_ = (uint32_t*)be_.alloc(nb_cap_ * Pt::WORDS * 4);
+      hist2_ = (uint32_t*)be_.alloc((nb_cap_ + 1) * 4);
+      cursor2_ = (uint32_t*)be_.alloc((nb_cap_ + 1) * 4);
+    }
+    set_tok_[0] = set_tok_[1] = -1;
+  }
+  // scalars_dev: the part's n scalars on the device; ready_tok: a backend token (aux_token / -1) after which they may be read
+  void add_part(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont, int ready_tok, bool last) {
+    if (pending_empty_ || n == 0) { if (last && !pending_empty_) { if (parts_k_ == 0) { pending_empty_ = true; return; } reduce_and_download(); } return; }
+    if (parts_k_ > 0 && n * (size_t)g_.Wd > entries_cap_ / 2 + 64) throw MsmCapacityError("MsmPlan: a part exceeds half of the plan's entry capacity");
+    part_body(bases_dev, base_off, scalars_dev, n, from_mont, 0, nullptr, parts_k_ == 0, last, ready_tok);
+    parts_n_ += n;
+    if (last) reduce_and_download();
+  }
+
+ private:
+  void part_body(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont, size_t m_sub,
+                 const uint64_t* scalar_tab, bool first, bool last, int ready_tok = -1) {
     MsmGeom g = g_;
     g.n = (uint32_t)n; g.base_off = base_off; g.from_mont = from_mont ? 1 : 0;
     g.m_sub = subs_ ? (uint32_t)(m_sub ? m_sub : n / subs_) : 0u;
@@ -835,7 +924,9 @@ class MsmPlan {
     uint32_t want_lanes = g.tbl_stride ? cfg_.tbl_target_lanes : cfg_.target_lanes;
     if (g.tbl_stride && cfg_.tbl_chunk)
       while ((uint64_t)want_lanes * 2 <= cfg_.tbl_max_lanes && Mmax / ((size_t)want_lanes * 2) >= cfg_.tbl_chunk) want_lanes *= 2;
-    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)(Mmax / want_lanes);
+    // ceil: at most want_lanes lanes, i.e. whole rounds of the chip.  (The floor of round 4 gave a call of 2^24 - 1 pairs -- every KZG open --
+    // chunks of 383 instead of 384 entries and 2054 workgroups instead of 2048: a fifth, nearly empty round, accumulate 36.0 instead of 32.0 ms)
+    uint32_t T = cfg_.T ? cfg_.T : (uint32_t)((Mmax + want_lanes - 1) / want_lanes);
     if (T < min_T_) T = min_T_;
     if (T > 4096) T = 4096;
     g.T = T; g.T2 = cfg_.T2; g.T2b = cfg_.T2b;
@@ -843,31 +934,57 @@ class MsmPlan {
     const size_t lanes = ceil_div_u32(Mmax, T);
     if (n > n_max_ || Mmax > entries_cap_ || g.NB > nb_cap_ || 2 * lanes > part_slots_)
       throw MsmCapacityError("MsmPlan: call exceeds the workspace this plan was sized for");
+    // sort outputs: part k of a call in parts uses set k & 1, and sorts on the auxiliary queue once the accumulation that last read
+    // that set is through; the accumulation then waits for the sort
+    const int set = in_parts_ ? (int)(parts_k_ & 1u) : 0;
+    uint32_t* entries = set ? entries2_ : entries_; uint32_t* offsets = set ? offsets2_ : offsets_;
+    uint32_t* hist = set ? hist2_ : hist_; uint32_t* cursor = set ? cursor2_ : cursor_;
+    uint32_t* buckets = (in_parts_ && !first) ? buckets2_ : buckets_;
+    const bool marks = !in_parts_ || first;              // phase marks: the sort of the first part; accumulate / seg-reduce marks of the last
+    be_.memset(buckets, 0, (size_t)g.NB * Pt::WORDS * 4);
+    if (in_parts_) {
+      be_.aux_begin(set_tok_[set], ready_tok);
+      const bool t = be_.timing_marks(marks);
+      be_.template sort_entries<C>(g, scalars_dev, hist, offsets, cursor, entries);
+      be_.timing_marks(t);
+      be_.wait_token(be_.aux_end());
+    } else {
+      // steps 1-3: entries grouped by bucket + CSR offsets (backend chooses the sort)
+      be_.template sort_entries<C>(g, scalars_dev, hist, offsets, cursor, entries);
+    }
 
-    be_.memset(buckets_, 0, (size_t)g.NB * Pt::WORDS * 4);
-    // steps 1-3: entries grouped by bucket + CSR offsets (backend chooses the sort)
-    be_.template sort_entries<C>(g, scalars_dev, hist_, offsets_, cursor_, entries_);
-
-    { AccumulateBody<C> b{g, g.tbl_stride ? cfg_.tbl : bases_dev, entries_, offsets_, buckets_, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
-    be_.mark();   // 4: accumulate
+    { AccumulateBody<C> b{g, g.tbl_stride ? cfg_.tbl : bases_dev, entries, offsets, buckets, pk_[0], pp_[0]}; be_.template accumulate<C>(b, lanes); }
+    if (!in_parts_ || last) be_.mark();   // 4: accumulate
     // the reductions below are latency-bound: they go to the pipeline's low-priority queue (HIP backend)
     // (only while the reductions are a sizeable share of the MSM: 20-30 % faster steps up to 2^18, 10-15 % at
     // 2^20, but 8 % slower at 2^21 and beyond, where a delayed reduction stalls the caller's pipeline)
-    if (n <= ((size_t)3 << 19)) be_.begin_tail();
-    struct TailScope { Backend& b; ~TailScope() { b.end_tail(); } } tail_scope{be_};
+    const bool tail_queue = !in_parts_ && n <= ((size_t)3 << 19);
+    if (tail_queue) be_.begin_tail();
+    tail_open_ = tail_queue;
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
       size_t lanes2 = ceil_div_u32(slots, level == 1 ? g.T2 : g.T2b);
       if (lanes2 <= (cfg_.seg_tail_lanes ? cfg_.seg_tail_lanes : 1u)) {   // lanes2 == 1 always ends the walk
         // the remaining levels are tiny: one workgroup walks them all in a single launch
-        be_.template seg_reduce_tail<C>(g, level, (uint32_t)slots, pk_, pp_, cur, offsets_, buckets_);
+        be_.template seg_reduce_tail<C>(g, level, (uint32_t)slots, pk_, pp_, cur, offsets, buckets);
         break;
       }
-      SegReduceBody<C> b{g, level, (uint32_t)slots, pk_[cur], pp_[cur], offsets_, buckets_, pk_[cur ^ 1], pp_[cur ^ 1]};
+      SegReduceBody<C> b{g, level, (uint32_t)slots, pk_[cur], pp_[cur], offsets, buckets, pk_[cur ^ 1], pp_[cur ^ 1]};
       be_.launch(b, lanes2);
       slots = 2 * lanes2; level++; cur ^= 1;
     }
+    if (in_parts_) {
+      if (!first) { BucketMergeBody<C> m{buckets_, buckets2_}; be_.launch(m, g.NB); }
+      set_tok_[set] = be_.main_token();
+      parts_k_++;
+    }
+    last_g_ = g;
+  }
 
+  void reduce_and_download() {
+    const MsmGeom& g = last_g_;
+    struct TailScope { Backend& b; bool on; ~TailScope() { if (on) b.end_tail(); } } tail_scope{be_, tail_open_};
+    tail_open_ = false;
     be_.mark();   // 5: segmented reduction of partials
     // bucket reduction
     // layout of red_: per level l: [S_l][this level's weighted arrays][older arrays, folded], each W * lvl_m_[l] points
@@ -900,8 +1017,10 @@ class MsmPlan {
     else if (n_levels_ == 0) be_.copy_d2h_async(result_host_, buckets_, (size_t)g.W * Pt::WORDS * 4);
     else be_.copy_d2h_async(result_host_, prev_base + (size_t)g.W * Pt::WORDS, (size_t)g.W * lvl_narr_[n_levels_ - 1] * Pt::WORDS * 4);
     be_.record_done();
+    in_parts_ = false;
   }
 
+ public:
   // Host-side state of enqueue() for a call whose device work is replayed from a captured graph (same n as the captured
   // call): what finish() and its Horner fold read.
   void prepare_replay(size_t n) { pending_empty_ = (n == 0); if (n) plan_geometry(n); }
@@ -1023,6 +1142,12 @@ class MsmPlan {
   uint32_t* result_host_ = nullptr;   // pinned
   uint64_t* tab_ = nullptr; uint64_t* tab_host_ = nullptr;   // scalar-vector addresses of enqueue_vectors (device / pinned)
   bool pending_empty_ = true;
+  // a call in parts (begin_parts / add_part): second sort outputs and bucket array, the part counter, backend tokens of the last
+  // accumulation that read each sort-output set
+  uint32_t *entries2_ = nullptr, *offsets2_ = nullptr, *buckets2_ = nullptr, *hist2_ = nullptr, *cursor2_ = nullptr;
+  uint32_t parts_k_ = 0; size_t parts_n_ = 0; bool in_parts_ = false, tail_open_ = false;
+  int set_tok_[2] = {-1, -1};
+  MsmGeom last_g_;
 };
 
 }  // namespace pc

@@ -37,7 +37,10 @@ inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   // make the runs a workgroup appends to a bin longer (its 8-byte records then complete 32-byte sectors while they are
   // still in L2); PC_HIP_FINE_BITS overrides (tuning).
   static const uint32_t fine_target = []() { const char* e = getenv("PC_HIP_FINE_BITS"); int v = e ? atoi(e) : 8; return (uint32_t)(v < 4 ? 4 : v > 11 ? 11 : v); }();
-  uint32_t cb = bbits > fine_target ? bbits - fine_target : 0;
+  // (two bucket sets -- the GLV table -- with the common fine width would double the coarse bins: 16384 instead of 8192 at c = 22, i.e.
+  // half-length runs of 8-byte records per (block, bin) in the scatter pass: one more fine bit keeps the bin count of the plain form)
+  const uint32_t ft = fine_target + ((g.glv && !g.m_sub && fine_target < 11) ? 1u : 0u);
+  uint32_t cb = bbits > ft ? bbits - ft : 0;
   if (cb > cb_max) cb = cb_max;
   s.cb = cb; s.fine_bits = bbits - cb; s.ncw = 1u << cb; s.NC = g.W * s.ncw;
   // fine_bits can exceed 11 (k_sort_fine's LDS histogram holds 2^11 buckets) when cb clamps to cb_max with many bucket sets
@@ -59,7 +62,9 @@ inline SortGeom make_sort_geom(const MsmGeom& g, uint32_t scalar_bits) {
   return s;
 }
 
-template <class C, bool SCATTER, bool GLV = false>
+// GLV: 0 plain scalars; 2 `scalars` is the pre-split array of k_glv_presplit (GLV_SPLIT_WORDS words per scalar, in call order:
+// sub-MSM addressing already resolved)
+template <class C, bool SCATTER, int GLV = 0>
 __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t* scalars, uint32_t* G, const uint32_t* binbase,
                                                   uint2* records) {
   typedef typename C::FrP FrP;
@@ -70,10 +75,12 @@ __global__ void __launch_bounds__(1024) k_sort_pass(SortGeom sg, const uint32_t*
   const uint32_t lo = blockIdx.x * sg.S;
   const uint32_t hi = (sg.n - lo > sg.S) ? lo + sg.S : sg.n;
   constexpr uint32_t sets = GLV ? 2u : 1u;
+  static_assert(GLV == 0 || GLV == 2, "the LDS sort reads plain or pre-split scalars");
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     uint32_t sub = 0, j = i;
     if (sg.m_sub) { sub = i / sg.m_sub; j = i - sub * sg.m_sub; }      // many-MSM mode: bucket set(s) of `sub`
-    const uint32_t* sp = sg.scalar_tab ? reinterpret_cast<const uint32_t*>(sg.scalar_tab[sub]) + (size_t)j * FrP::N : scalars + (size_t)i * FrP::N;
+    const uint32_t* sp = GLV == 2 ? scalars + (size_t)i * GLV_SPLIT_WORDS
+                                  : sg.scalar_tab ? reinterpret_cast<const uint32_t*>(sg.scalar_tab[sub]) + (size_t)j * FrP::N : scalars + (size_t)i * FrP::N;
     for_each_signed_digit_t<C, GLV>(sg, sp, [&](uint32_t h, uint32_t w, uint32_t mag, uint32_t neg) {
       const uint32_t fb = (w == sg.top_w) ? sg.top_fine_bits : sg.fine_bits;
       uint32_t b = mag - 1, cbin = b >> fb;

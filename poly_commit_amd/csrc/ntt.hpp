@@ -7,8 +7,8 @@
 //   omega = TWO_ADIC_ROOT_OF_UNITY^(2^(s - log_n))   (arkworks' FftField constants).
 // Each row is zero-padded from in_cols to N = 2^log_n (the padding is never read).
 //
-// Four-step decomposition N = N1 * N2, two kernels, both staging a tile in LDS (limb-major /
-// SoA so that consecutive lanes hit consecutive banks):
+// Four-step decomposition N = N1 * N2, two kernels, both staging a tile in LDS (limb-pair-major with a
+// bank swizzle, LdsTile below: 8-byte accesses, conflict-free in every phase):
 //   pass A  tile = C adjacent columns i2 of the N1 x N2 view; N1-point NTT down each column
 //           (bit-reversed on the way into LDS, DIT butterflies), then * omega_N^(i2*j1)
 //   pass B  tile = R adjacent rows j1; N2-point NTT along each row; transposed store
@@ -32,7 +32,10 @@ namespace pc {
 #define PC_NTT_THREADS 512
 #endif
 static constexpr int NTT_THREADS = PC_NTT_THREADS;
-static constexpr uint32_t NTT_TILE_MAX = 2048;   // elements per LDS tile (64 KiB of 32-byte elements)
+#ifndef PC_NTT_TILE
+#define PC_NTT_TILE 2048
+#endif
+static constexpr uint32_t NTT_TILE_MAX = PC_NTT_TILE;   // elements per LDS tile (64 KiB of 32-byte elements)
 
 template <class FrP>
 struct PowTable { uint32_t w[32][FrP::N]; };   // w[k] = omega_N^(2^k)
@@ -54,30 +57,62 @@ PC_HD uint32_t bitrev(uint32_t v, uint32_t bits) {
   return r;
 }
 
-template <class FrP>
+// An LDS tile of field elements, limb-PAIR-major: element `pos` keeps limbs (2m, 2m + 1) at base[m * stride + phys(pos)], so an
+// element is N / 2 ds_read_b64 / ds_write_b64 (half the LDS instructions and, for reads, half the LDS cycles of dword accesses).
+//
+// phys() permutes the low five bits of a position as a function of its higher bits -- a bijection, so any position may be used
+// anywhere -- chosen so that each 32-lane group of every access pattern of the two passes lands in 32 distinct 8-byte slots (the LDS
+// services 32 lanes per cycle and serialises lanes that share a bank; round 4 ran the butterfly stages 1 .. 5 of a tile with 2- to
+// 4-way conflicts on every data access and up to 8-way on the twiddles):
+//   DATA   the positions of a radix-4 group of stage s are p | {0, 1, 2, 3} << (s - 1): consecutive lanes vary bits 0 .. s-2 and
+//          s+1 .. 6 of p, bits s-1 and s (both below 5 for s <= 4) are zero in every lane.  bank = low5 ^ T(bit 5, bit 6) with
+//          T(1, 0) = 10101b, T(0, 1) = 11010b: over GF(2) the two vectors project onto every pair of adjacent bank bits (0,1), (1,2),
+//          (2,3), (3,4) as a basis, so bits 5, 6 fill whichever two bank bits the stage leaves empty; stages >= 6 vary bits 0 .. 4.
+//          Bits 7 .. 10 (constant inside a group of a stage) are folded in as well, onto bank bits 0, 2, 3, 4: they are what varies in
+//          the bit-reversed fill and in the transposed read-out of the tile.  Lines start at multiples of the line length (no padding
+//          word: an added offset would carry into the bits the argument is about).
+//   TWID   a stage reads omega^(j << sh) for consecutive j: five consecutive bits sh .. sh+4 vary.  bank = XOR of the 5-bit digits of
+//          the position: every window of five consecutive bits hits each bank bit exactly once.
+// tuning experiment switch: 0 keeps the positions as they are (the conflicts of round 4, with 8-byte accesses)
+#ifndef PC_NTT_SWIZZLE
+#define PC_NTT_SWIZZLE 1
+#endif
+enum { LDS_PLAIN = 0, LDS_DATA = PC_NTT_SWIZZLE ? 1 : 0, LDS_TWID = PC_NTT_SWIZZLE ? 2 : 3 };
+template <class FrP, int MODE>
 struct LdsTile {
   typedef Fd<FrP> F;
-  uint32_t* base; uint32_t stride;   // word stride between limbs (= padded tile elements)
+  static_assert(FrP::N % 2 == 0, "limb pairs");
+  uint2* base; uint32_t stride;   // 8-byte stride between limb pairs (= tile elements)
+  static __device__ __forceinline__ uint32_t phys(uint32_t pos) {
+    if constexpr (MODE == 1) {
+      const uint32_t x = pos >> 5;
+      return pos ^ ((0u - (x & 1u)) & 21u) ^ ((0u - ((x >> 1) & 1u)) & 26u) ^ ((x >> 2) & 1u) ^ (((x >> 3) & 7u) << 2);
+    } else if constexpr (MODE == 2) {
+      return pos ^ (((pos >> 5) ^ (pos >> 10)) & 31u);
+    } else return pos;
+  }
   __device__ __forceinline__ F get(uint32_t pos) const {
     F r;
+    const uint32_t p = phys(pos);
 #pragma unroll
-    for (int k = 0; k < FrP::N; k++) r.l[k] = base[k * stride + pos];
+    for (int m = 0; m < FrP::N / 2; m++) { const uint2 v = base[m * stride + p]; r.l[2 * m] = v.x; r.l[2 * m + 1] = v.y; }
     return r;
   }
   __device__ __forceinline__ void put(uint32_t pos, const F& v) const {
+    const uint32_t p = phys(pos);
 #pragma unroll
-    for (int k = 0; k < FrP::N; k++) base[k * stride + pos] = v.l[k];
+    for (int m = 0; m < FrP::N / 2; m++) base[m * stride + p] = make_uint2(v.l[2 * m], v.l[2 * m + 1]);
   }
 };
 
 // DIT butterfly stages over `lines` independent length-2^lg sequences laid out in LDS at
-// pos = line * (len + 1) + p (bit-reversed input, natural output).
+// pos = line * len + p (bit-reversed input, natural output).
 // The 2^(lg-1) twiddles omega_{2^lg}^j of these stages are staged in LDS first (`tw`, limb-major like
 // the tile): every butterfly then reads its twiddle from LDS instead of gathering 32 bytes from the
 // global table (5.7e8 L2 gathers per 2^24-coefficient batch).
 template <class FrP>
-__device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t lines, uint32_t lg, const uint32_t* W,
-                                               uint32_t log_n_total, const LdsTile<FrP>& tw, uint32_t first_stage = 1) {
+__device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, uint32_t lines, uint32_t lg, const uint32_t* W,
+                                               uint32_t log_n_total, const LdsTile<FrP, LDS_TWID>& tw, uint32_t first_stage = 1) {
   typedef Fd<FrP> F;
   const uint32_t len = 1u << lg, halfs = len >> 1;
   for (uint32_t j = threadIdx.x; j < halfs; j += NTT_THREADS)
@@ -92,7 +127,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t l
     for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
       uint32_t line = b >> (lg - 1), k = b & (halfs - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
-      uint32_t p0 = line * (len + 1) + (g << s) + j, p1 = p0 + h;
+      uint32_t p0 = line * len + (g << s) + j, p1 = p0 + h;
       F u = t.get(p0), v = t.get(p1);
       if (j) v = v.mul(tw.get(j << tw_shift));
       t.put(p0, u.add(v)); t.put(p1, u.sub(v));
@@ -111,7 +146,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP>& t, uint32_t l
     for (uint32_t b = threadIdx.x; b < lines * quarters; b += NTT_THREADS) {
       uint32_t line = b >> (lg - 2), k = b & (quarters - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
-      uint32_t p0 = line * (len + 1) + (g << (s + 1)) + j;
+      uint32_t p0 = line * len + (g << (s + 1)) + j;
       F x0 = t.get(p0), x1 = t.get(p0 + h), x2 = t.get(p0 + 2 * h), x3 = t.get(p0 + 3 * h);
       if (j) { F w1 = tw.get(j << sh1); x1 = x1.mul(w1); x3 = x3.mul(w1); }
       F a0 = x0.add(x1), a1 = x0.sub(x1), a2 = x2.add(x3), a3 = x2.sub(x3);
@@ -132,8 +167,8 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
   const uint32_t lgC = 31 - __builtin_clz(C), tile_bits = lg2 - lgC;
   const uint32_t row = blockIdx.x >> tile_bits, tile = blockIdx.x & ((1u << tile_bits) - 1);
-  LdsTile<FrP> t{smem, C * (N1 + 1)};
-  LdsTile<FrP> tw{smem + (size_t)FrP::N * C * (N1 + 1), N1 / 2 + 1};
+  LdsTile<FrP, LDS_DATA> t{(uint2*)smem, C * N1};
+  LdsTile<FrP, LDS_TWID> tw{(uint2*)(smem + (size_t)FrP::N * C * N1), N1 / 2 > 1 ? N1 / 2 : 1};
   const uint32_t* rin = in + (size_t)row * in_cols * FrP::N;
   // Zero padding: if only the first N >> z coefficients can be non-zero (rho_inv = 4 -> z = 2), a
   // column holds data only at i1 < N1 >> z, i.e. (bit-reversed) at LDS positions = 0 mod 2^z, and
@@ -143,7 +178,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
     uint32_t c = idx & (C - 1), i1 = idx >> lgC;
     uint32_t i = i1 * N2 + tile * C + c;
     F v = (i < in_cols) ? F::load(rin + (size_t)i * FrP::N) : F::zero();
-    uint32_t pos = c * (N1 + 1) + bitrev(i1, lg1);
+    uint32_t pos = c * N1 + bitrev(i1, lg1);
     for (uint32_t r = 0; r < zpow; r++) t.put(pos + r, v);
   }
   __syncthreads();
@@ -152,7 +187,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
     uint32_t c = idx & (C - 1), j1 = idx >> lgC;
     uint32_t i2 = tile * C + c;
-    F v = t.get(c * (N1 + 1) + j1);
+    F v = t.get(c * N1 + j1);
     uint32_t e = i2 * j1;                       // < N
     if (e) v = v.mul(F::load(W + (size_t)e * FrP::N));
     v.store(rout + ((size_t)j1 * N2 + i2) * FrP::N);
@@ -167,19 +202,19 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const uint32_t* tmp,
   const uint32_t lg2 = log_n - lg1, N1 = 1u << lg1, N2 = 1u << lg2, N = 1u << log_n;
   const uint32_t lgR = 31 - __builtin_clz(R), tile_bits = lg1 - lgR;
   const uint32_t row = blockIdx.x >> tile_bits, tile = blockIdx.x & ((1u << tile_bits) - 1);
-  LdsTile<FrP> t{smem, R * (N2 + 1)};
-  LdsTile<FrP> tw{smem + (size_t)FrP::N * R * (N2 + 1), N2 / 2 + 1};
+  LdsTile<FrP, LDS_DATA> t{(uint2*)smem, R * N2};
+  LdsTile<FrP, LDS_TWID> tw{(uint2*)(smem + (size_t)FrP::N * R * N2), N2 / 2 > 1 ? N2 / 2 : 1};
   const uint32_t* rin = tmp + ((size_t)row * N + (size_t)tile * R * N2) * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
     uint32_t r = idx >> lg2, i2 = idx & (N2 - 1);
-    t.put(r * (N2 + 1) + bitrev(i2, lg2), F::load(rin + (size_t)idx * FrP::N));
+    t.put(r * N2 + bitrev(i2, lg2), F::load(rin + (size_t)idx * FrP::N));
   }
   __syncthreads();
   lds_ntt_stages<FrP>(t, R, lg2, W, log_n, tw);
   uint32_t* rout = out + (size_t)row * N * FrP::N;
   for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
     uint32_t r = idx & (R - 1), j2 = idx >> lgR;
-    F v = t.get(r * (N2 + 1) + j2);
+    F v = t.get(r * N2 + j2);
     v.store(rout + ((size_t)(tile * R + r) + (size_t)N1 * j2) * FrP::N);
   }
 }
@@ -212,7 +247,7 @@ class NttPlan {
     uint32_t C = 8; while (C > N2) C >>= 1; while (C > 1 && C * N1 > NTT_TILE_MAX) C >>= 1;
     uint32_t R = 8; while (R > N1) R >>= 1; while (R > 1 && R * N2 > NTT_TILE_MAX) R >>= 1;
     // tile + the stage twiddles of the pass (N1/2 resp. N2/2 elements)
-    size_t lds_a = ((size_t)C * (N1 + 1) + N1 / 2 + 1) * FrP::N * 4, lds_b = ((size_t)R * (N2 + 1) + N2 / 2 + 1) * FrP::N * 4;
+    size_t lds_a = ((size_t)C * N1 + (N1 / 2 > 1 ? N1 / 2 : 1)) * FrP::N * 4, lds_b = ((size_t)R * N2 + (N2 / 2 > 1 ? N2 / 2 : 1)) * FrP::N * 4;
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) throw std::runtime_error("NTT size exceeds the LDS tile");
     if (lds_a > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_a<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     if (lds_b > 64 * 1024) PC_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass_b<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));

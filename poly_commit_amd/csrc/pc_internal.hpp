@@ -21,6 +21,10 @@ struct MsmRunner {
   virtual void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) = 0;
   // many-MSM runners only: `count` scalar vectors of m elements each in separate device buffers (a batch of polynomials)
   virtual void enqueue_vectors(const uint32_t* bases, uint32_t base_off, const uint64_t* ptrs_host, size_t count, size_t m, bool from_mont) = 0;
+  // ONE MSM of n_total pairs in parts (MsmPlan::begin_parts): part k covers scalars [first, first + n) of the call -- host memory: copied on
+  // the pipeline's auxiliary queue; device memory: readable now -- against bases base_off + first ..; `last` closes the call
+  virtual void begin_parts(size_t n_total) = 0;
+  virtual void add_part(const uint32_t* bases, uint32_t base_off, size_t first, const void* scalars_part, pc_mem where, size_t n, bool from_mont, bool last) = 0;
   virtual void finish(uint32_t* out_host) = 0;
   // geometry of the last enqueue: {window bits c, signed digits per scalar, buckets, 1 if the window table was used}
   virtual void shape(uint32_t out[4]) const = 0;

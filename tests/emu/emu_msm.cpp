@@ -20,6 +20,11 @@ struct CpuStepBackend {
   void* workspace(size_t bytes) { if (ws.size() < bytes) ws.assign(bytes, 0); return ws.data(); }
   void memset(void* p, int v, size_t bytes) { ::memset(p, v, bytes); }
   void mark() {}
+  bool timing_marks(bool) { return true; }
+  void aux_begin(int, int) {}
+  int aux_end() { return -1; }
+  void wait_token(int) {}
+  int main_token() { return -1; }
   void record_done() {}
   void begin_tail() {}
   void end_tail() {}
@@ -124,6 +129,44 @@ extern "C" void emu_msm_table_glv(int curve, const uint32_t* bases, size_t n_srs
     case 0: run_table<pc_curve_bls12_381>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out, true); break;
     case 1: run_table<pc_curve_bn254>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out, true); break;
     case 2: run_table<pc_curve_pallas>(bases, n_srs, scalars, n, base_off, c, K0, from_mont, out, true); break;
+  }
+}
+// ONE MSM in `parts` parts (MsmPlan::begin_parts / add_part: pc_hip_msm and pc_hip_kzg_open on host memory): with the window table (c > 0:
+// plain or GLV form) or table-free (c == 0); parts of unequal lengths, the last one possibly a single scalar.
+template <class C>
+static int run_parts(const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int glv, int parts,
+                     int from_mont, uint32_t* out) {
+  CpuStepBackend be;
+  constexpr int AW = 2 * pc::Fd<typename C::FqP>::N;
+  pc::MsmConfig cfg;
+  std::vector<uint32_t> table;
+  if (c > 0) {
+    const uint32_t Wd = pc::msm_num_windows(glv ? pc::GLV_HALF_BITS : (uint32_t)C::FrP::BITS, (uint32_t)c);
+    const uint32_t stride = AW;
+    table.resize((size_t)Wd * n_srs * stride);
+    { pc::WindowTableBody<C> b{bases, (uint32_t)n_srs, (uint32_t)c, Wd, table.data(), stride}; be.launch(b, n_srs); }
+    cfg.tbl = table.data(); cfg.tbl_c = (uint32_t)c; cfg.tbl_stride = (uint32_t)n_srs; cfg.tbl_pt_stride = stride; cfg.tbl_min_n = 1; cfg.tbl_glv = glv != 0;
+  }
+  cfg.coop_max_points = 64; cfg.seg_tail_lanes = 3;
+  pc::MsmPlan<C, CpuStepBackend> plan(be, n_srs, cfg);
+  try {
+    plan.begin_parts(n);
+    for (int k = 0; k < parts; k++) {
+      // unequal cuts: thirds of what is left, the last part takes the rest
+      const size_t first = n * (size_t)k / (size_t)parts + (k ? 1 : 0) * (k < parts ? 0 : 0);
+      const size_t end = k + 1 == parts ? n : n * (size_t)(k + 1) / (size_t)parts;
+      plan.add_part(bases, base_off + (uint32_t)first, scalars + first * (size_t)C::FrP::N, end - first, from_mont != 0, -1, k + 1 == parts);
+    }
+    plan.finish(out);
+  } catch (const pc::MsmCapacityError&) { return 1; }
+  return 0;
+}
+extern "C" int emu_msm_parts(int curve, const uint32_t* bases, size_t n_srs, const uint32_t* scalars, size_t n, uint32_t base_off, int c, int glv,
+                             int parts, int from_mont, uint32_t* out) {
+  switch (curve) {
+    case 0: return run_parts<pc_curve_bls12_381>(bases, n_srs, scalars, n, base_off, c, glv, parts, from_mont, out);
+    case 1: return run_parts<pc_curve_bn254>(bases, n_srs, scalars, n, base_off, c, glv, parts, from_mont, out);
+    default: return run_parts<pc_curve_pallas>(bases, n_srs, scalars, n, base_off, c, glv, parts, from_mont, out);
   }
 }
 // the GLV split in 32-bit limbs (the device's) against the 64-bit host version: out = |k1| (5 limbs) | |k2| (5) | neg1 | neg2; returns 1 if they agree

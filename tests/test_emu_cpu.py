@@ -661,3 +661,33 @@ def test_window_table_batched_build_equals_serial_build(curve):
     aw = b.shape[1] * 2
     for c, stride, K in ((13, aw, 4), (22, aw + 8, 16)):
         assert emu().emu_table_builds_agree(O.CURVES[curve], p32(b.view(np.uint32)), n, c, stride, K) == 1, (c, stride)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_in_parts_stepped(curve):
+    """MsmPlan::begin_parts / add_part (pc_hip_msm and pc_hip_kzg_open on host memory: ONE MSM in parts -- every part after the first
+    accumulates into a second bucket array that BucketMergeBody folds into the first, one bucket reduction closes the call): the point
+    of the undivided MSM for 1 .. 5 parts, with the window table (plain and GLV form) and table-free, a base offset, Montgomery input,
+    buckets that only one part touches (sparse scalars) and buckets every part touches (five-valued scalars)."""
+    n = 240
+    b = O.gen_bases(curve, n)
+    b[7] = 0
+    uni = O.gen_scalars(curve, 23, n)
+    few = np.ascontiguousarray(uni[np.arange(n) % 5])
+    sparse = np.where((np.arange(n) % 9 == 0)[:, None], uni, 0).astype(np.uint64)
+
+    def run(s, c, glv, parts, base_off=0, from_mont=0):
+        out = np.zeros(2 * O.fq_limbs(curve), dtype=np.uint64)
+        rc = emu().emu_msm_parts(O.CURVES[curve], p32(b.view(np.uint32)), C.c_size_t(len(b)), p32(s.view(np.uint32)), C.c_size_t(len(s)),
+                                 base_off, c, glv, parts, from_mont, p32(out.view(np.uint32)))
+        assert rc == 0
+        return out
+    for s in (uni, few, sparse):
+        want = O.msm_naive(curve, b, s)
+        for c, glv in ((7, 0), (9, 1), (0, 0)):
+            for parts in (1, 2, 3, 5):
+                assert (run(s, c, glv, parts) == want).all(), (c, glv, parts)
+    part = np.ascontiguousarray(uni[:150])
+    assert (run(part, 8, 0, 4, base_off=60) == O.msm_naive(curve, b[60:], part)).all()
+    assert (run(O.f_to_mont(curve, 1, uni), 6, 1, 3, from_mont=1) == O.msm_naive(curve, b, uni)).all()
+    assert not run(np.zeros((n, 4), dtype=np.uint64), 7, 0, 3).any()

@@ -1,5 +1,5 @@
-"""pc_hip_msm with HOST scalars and pc_hip_kzg_open with HOST coefficients run large inputs as two halves on two pipelines (the second
-half's PCIe copy under the first half's MSM; abi.hip host_split_min, default 2^23 pairs).  The split is forced down to 2^10 here
+"""pc_hip_msm with HOST scalars and pc_hip_kzg_open with HOST coefficients run large inputs in parts (the PCIe copy and the sort of a part
+under the accumulation of the one before; abi.hip host_split_min, default 2^23 pairs; host_parts, default 4).  The split is forced down to 2^10 here
 (PC_HIP_HOST_SPLIT_LOG2, read once per process: hence the subprocess) and compared with the oracle's kzg_commit / kzg_open
 (kzg10/mod.rs:157-210, :287-310) bit for bit; the unsplit paths of the same calls run in the same child."""
 import os
@@ -61,8 +61,12 @@ print("host-split ok")
 '''
 
 
-def test_host_inputs_split_in_two_halves_against_the_oracle():
-    env = dict(os.environ, PC_HIP_HOST_SPLIT_LOG2="10")
+@pytest.mark.parametrize("parts", ["4", "0", "2", "7"])
+def test_host_inputs_in_parts_against_the_oracle(parts):
+    """PC_HIP_HOST_PARTS: 4 (the default) / 2 / 7 = ONE MSM in that many parts on one pipeline (MsmPlan::begin_parts: copy and sort of part
+    k + 1 beside the accumulation of part k, second bucket array merged into the first, one reduction); 0 = round 4's two half-size MSMs
+    on two pipelines."""
+    env = dict(os.environ, PC_HIP_HOST_SPLIT_LOG2="10", PC_HIP_HOST_PARTS=parts)
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "host-split ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

@@ -18,6 +18,7 @@
 #               tests         pytest -m gpu (TESTS="-k expr" narrows it)
 #   PROF      runs (same names) to repeat under rocprofv3 --kernel-trace --stats for the FIRST variant; SQ: the same with the SQ counters;
 #             PMC: FETCH_SIZE and WRITE_SIZE passes
+#   LDSC      runs to repeat with the LDS bank-conflict counters
 #   ENVS      extra "NAME=value" pairs exported for every run (tuning environment variables of the library)
 set -x
 TAG=${1:-probe}
@@ -52,6 +53,8 @@ SQC="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INS
 prof() { name=$1; shift; PC_HIP_LIB=$lib0 NTT_STEPS=3 BATCH_STEPS=2 PC_IPA_REPS=2 timeout -k 10 600 rocprofv3 "$@" > $R/gpurun_out/$name.log 2>&1; }
 for r in $PROF; do NTT_STEPS=3 BATCH_STEPS=2 prof ${TAG}_prof_$r --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_$r -o bench -- $(NTT_STEPS=3 BATCH_STEPS=2 cmd_of $r); done
 for r in $SQ; do prof ${TAG}_sq_$r --kernel-trace --pmc $SQC --output-format csv -d $R/gpurun_out/${TAG}_sq_$r -o bench -- $(NTT_STEPS=3 BATCH_STEPS=2 cmd_of $r); done
+# LDS: bank-conflict cycles against all LDS-array cycles (MI355X_MICROARCH.md, LDS section)
+for r in $LDSC; do prof ${TAG}_lds_$r --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/${TAG}_lds_$r -o bench -- $(NTT_STEPS=3 BATCH_STEPS=2 cmd_of $r); done
 for r in $PMC; do
   prof ${TAG}_fetch_$r --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_fetch_$r -o bench -- $(NTT_STEPS=3 BATCH_STEPS=2 cmd_of $r)
   prof ${TAG}_write_$r --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_write_$r -o bench -- $(NTT_STEPS=3 BATCH_STEPS=2 cmd_of $r)

@@ -51,3 +51,13 @@ for f in sorted(glob.glob(f"{G}/{tag}_sq_*/**/*counter_collection.csv", recursiv
     for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:6]:
         wc = c.get("SQ_WAVE_CYCLES", 0) or 1
         print("  ", k, "valu_share", round(c.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3), "issue_stall_share", round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3), "wait_share", round(c.get("SQ_WAIT_ANY", 0) / wc, 3))
+for f in sorted(glob.glob(f"{G}/{tag}_lds_*/**/*counter_collection.csv", recursive=True)):
+    agg = {}
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"][:70]
+        agg.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+    print("==", f)
+    for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_LDS_IDX_ACTIVE", 0))[:4]:
+        act = c.get("SQ_LDS_IDX_ACTIVE", 0) or 1
+        print("  ", k, "lds_active", c.get("SQ_LDS_IDX_ACTIVE"), "bank_conflict", c.get("SQ_LDS_BANK_CONFLICT"), "conflict_share", round(c.get("SQ_LDS_BANK_CONFLICT", 0) / act, 3), "insts_lds", c.get("SQ_INSTS_LDS"))
