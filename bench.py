@@ -234,16 +234,27 @@ def oracle_scalar_mul(curve, g_xy, k):
     return O.msm_naive(curve, np.ascontiguousarray(g_xy).reshape(1, -1), np.ascontiguousarray(sc))
 
 
+_PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
+
+
 def pmc_traffic(key, field="accumulate_hbm_bytes_per_launch"):
-    """HBM bytes per launch from the committed PMC summary (profiles/r04_pmc_traffic.json, else r03: FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of the same workload -- NOT a measurement of this run)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    """HBM bytes per launch from the newest committed PMC summary that has the key (profiles/r05_pmc_traffic.json, else r04, r03: FETCH_SIZE
+    doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of the same workload -- NOT a
+    measurement of this run)."""
+    for name in _PMC_FILES:
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name))).get(field, {}).get(key)
             if v is not None:
                 return v
         except Exception:
             pass
+    return None
+
+
+def pmc_source():
+    for name in _PMC_FILES:
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            return "profiles/" + name
     return None
 
 
@@ -259,9 +270,12 @@ def union_ms(intervals):
 
 
 _MICRO = None
-_MADD_COMMITTED = {"bls12_381": 6.68e9, "bn254": 14.07e9, "pallas": 15.97e9}      # profiles/r04_microbench.txt
+_MADD_COMMITTED = {"bls12_381": 6.67e9, "bn254": 14.04e9, "pallas": 15.9e9}      # profiles/r05_microbench.txt
 # committed figures of the lines tools/microbench prints since round 5 (profiles/r05_microbench.txt), used when the binary is missing
-_MICRO_COMMITTED = {"fmul": {}, "butterfly": {}, "butterfly4": {}, "jac_dbl": {}, "jac_madd": {}}
+_MICRO_COMMITTED = {"fmul": {"bls12_381_fq": 57.4e9, "bn254_fq": 129.3e9, "pallas_fq": 157.0e9, "bls12_381_fr": 129.9e9, "bn254_fr": 130.6e9, "pallas_fr": 157.0e9},
+                    "butterfly": {"bls12_381_fr": 111.1e9, "bn254_fr": 112.5e9, "pallas_fr": 128.0e9},
+                    "butterfly4": {"bls12_381_fr": 110.3e9, "bn254_fr": 113.3e9, "pallas_fr": 129.7e9},
+                    "jac_dbl": {"bls12_381": 8.80e9, "bn254": 17.55e9, "pallas": 20.5e9}, "jac_madd": {"bls12_381": 5.76e9, "bn254": 11.89e9, "pallas": 13.79e9}}
 
 
 def microbench():
@@ -315,7 +329,7 @@ def madd_peak(curve):
     m = microbench()
     if curve in m["madd"]:
         return {"madd_per_s": m["madd"][curve], "source": m["source"]}
-    return {"madd_per_s": _MADD_COMMITTED[curve], "source": "profiles/r04_microbench.txt"}
+    return {"madd_per_s": _MADD_COMMITTED[curve], "source": "profiles/r05_microbench.txt"}
 
 
 def ntt_products(log_n, in_cols):
@@ -361,7 +375,7 @@ def msm_roofline(curve, pairs_per_launch, digits, kernel_ms, launches, kernel, t
     adds = pairs_per_launch * digits
     r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS if ach else None,
          "traffic": pmc_traffic(traffic_key) if traffic_key else None,
-         "traffic_source": "profiles/r04_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE doubled per "
+         "traffic_source": f"{pmc_source()} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE doubled per "
                            "the guide's gfx950 note; not measured in this run)",
          "kernel": kernel, "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
          "arithmetic": {"bound": "valu", "unit": "mixed additions/s (XYZZ += affine, 8M + 2S in Fq)",
@@ -801,7 +815,7 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                      "traffic": pmc_traffic(f"{curve}:2^{log_degree}:{'table' if args.precompute else 'table-free'}") if world == 1 else None,
-                     "traffic_source": "profiles/r04_pmc_traffic.json: PMC FETCH_SIZE (doubled per the gfx950 note of the guide) + WRITE_SIZE per launch, "
+                     "traffic_source": f"{pmc_source()}: PMC FETCH_SIZE (doubled per the gfx950 note of the guide) + WRITE_SIZE per launch, "
                                        "separate rocprofv3 --pmc passes of this workload on an earlier box (tools/gpu_full_run.sh) -- the one figure of this block that is NOT "
                                        "measured in this run (null when that size / table mode was not profiled); undoubled FETCH_SIZE is about half: "
                                        "for this kernel's 16-byte gathers the raw figure is the plausible one",
@@ -1300,7 +1314,7 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS if achieved else None,
                          "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
-                         "traffic_source": "profiles/r04_pmc_traffic.json (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
+                         "traffic_source": f"{pmc_source()} (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
                          "kernel": "pc::k_ntt_pass_a + pc::k_ntt_pass_b (one batched NTT = both), hipEvent brackets on the context's stream inside the timed region",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes, "arithmetic": arith},
             "cpu_baseline": cpu,

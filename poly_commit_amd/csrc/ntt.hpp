@@ -25,17 +25,26 @@
 
 namespace pc {
 
-// Lanes per tile.  The 64 KiB LDS tile, not the VGPRs, bounds the workgroups per CU (two), so the occupancy is set here:
-// 512 lanes = 4 waves per SIMD at 104 VGPRs; 256 lanes left 2 waves per SIMD and 22-28 % of the wave cycles waiting on LDS
-// and global loads (measured: 6.01 -> 5.48 ms for the 2^24-coefficient batch).
+// Lanes and elements per tile, per pass.  The LDS tile, not the VGPRs (85), bounds the workgroups per CU, so the occupancy is set here.
+// Pass A: 512 lanes on 2048 elements (64 KiB): 2 workgroups = 4 waves per SIMD; its tile is C = 4 adjacent columns, i.e. 128-byte runs in
+// global memory (256 lanes left 2 waves per SIMD: 6.01 -> 5.48 ms for the 2^24-coefficient batch in round 3; half tiles with 256 lanes
+// would keep 4 waves per SIMD but read 64-byte runs).  Pass B: 256 lanes on 1024 elements: 4 independent workgroups per CU instead of 2
+// (a barrier then spans 4 waves, and a workgroup's load / store phases overlap three others' butterflies); its R = 4 rows still store
+// 128-byte runs (round 5: pass B 2.33 -> 2.23 ms).  The kernels take their lane count from blockDim.
 #ifndef PC_NTT_THREADS
 #define PC_NTT_THREADS 512
 #endif
-static constexpr int NTT_THREADS = PC_NTT_THREADS;
 #ifndef PC_NTT_TILE
 #define PC_NTT_TILE 2048
 #endif
-static constexpr uint32_t NTT_TILE_MAX = PC_NTT_TILE;   // elements per LDS tile (64 KiB of 32-byte elements)
+#ifndef PC_NTT_THREADS_B
+#define PC_NTT_THREADS_B 256
+#endif
+#ifndef PC_NTT_TILE_B
+#define PC_NTT_TILE_B 1024
+#endif
+static constexpr int NTT_THREADS_MAX = 512;
+static constexpr uint32_t NTT_TILE_MAX = PC_NTT_TILE;   // elements per LDS tile of pass A (64 KiB of 32-byte elements)
 
 template <class FrP>
 struct PowTable { uint32_t w[32][FrP::N]; };   // w[k] = omega_N^(2^k)
@@ -115,7 +124,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, 
                                                uint32_t log_n_total, const LdsTile<FrP, LDS_TWID>& tw, uint32_t first_stage = 1) {
   typedef Fd<FrP> F;
   const uint32_t len = 1u << lg, halfs = len >> 1;
-  for (uint32_t j = threadIdx.x; j < halfs; j += NTT_THREADS)
+  for (uint32_t j = threadIdx.x; j < halfs; j += blockDim.x)
     tw.put(j, F::load(W + ((size_t)j << (log_n_total - lg)) * FrP::N));      // omega_{2^lg}^j = W[j << (log_n - lg)]
   __syncthreads();
   // every size is a power of two: index arithmetic is shifts and masks (an integer divide by a
@@ -124,7 +133,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, 
   if (((lg - first_stage + 1) & 1) && s <= lg) {     // odd number of stages: one radix-2 stage first
     const uint32_t h = 1u << (s - 1);
     const uint32_t tw_shift = lg - s;                // omega_{2^s}^j = tw[j << (lg - s)]
-    for (uint32_t b = threadIdx.x; b < lines * halfs; b += NTT_THREADS) {
+    for (uint32_t b = threadIdx.x; b < lines * halfs; b += blockDim.x) {
       uint32_t line = b >> (lg - 1), k = b & (halfs - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
       uint32_t p0 = line * len + (g << s) + j, p1 = p0 + h;
@@ -143,7 +152,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, 
   for (; s + 1 <= lg; s += 2) {
     const uint32_t h = 1u << (s - 1);
     const uint32_t sh1 = lg - s, sh2 = lg - s - 1;
-    for (uint32_t b = threadIdx.x; b < lines * quarters; b += NTT_THREADS) {
+    for (uint32_t b = threadIdx.x; b < lines * quarters; b += blockDim.x) {
       uint32_t line = b >> (lg - 2), k = b & (quarters - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
       uint32_t p0 = line * len + (g << (s + 1)) + j;
@@ -160,7 +169,7 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, 
 }
 
 template <class FrP>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, uint32_t in_cols, uint32_t* tmp, const uint32_t* W,
+__global__ void __launch_bounds__(NTT_THREADS_MAX) k_ntt_pass_a(const uint32_t* in, uint32_t in_cols, uint32_t* tmp, const uint32_t* W,
                                                            uint32_t log_n, uint32_t lg1, uint32_t C, uint32_t zskip) {
   typedef Fd<FrP> F;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -174,7 +183,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   // column holds data only at i1 < N1 >> z, i.e. (bit-reversed) at LDS positions = 0 mod 2^z, and
   // the first z DIT stages just replicate each value over its group of 2^z: skip them.
   const uint32_t zpow = 1u << zskip, n1nz = N1 >> zskip;
-  for (uint32_t idx = threadIdx.x; idx < C * n1nz; idx += NTT_THREADS) {
+  for (uint32_t idx = threadIdx.x; idx < C * n1nz; idx += blockDim.x) {
     uint32_t c = idx & (C - 1), i1 = idx >> lgC;
     uint32_t i = i1 * N2 + tile * C + c;
     F v = (i < in_cols) ? F::load(rin + (size_t)i * FrP::N) : F::zero();
@@ -184,7 +193,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
   __syncthreads();
   lds_ntt_stages<FrP>(t, C, lg1, W, log_n, tw, zskip + 1);
   uint32_t* rout = tmp + (size_t)row * N * FrP::N;
-  for (uint32_t idx = threadIdx.x; idx < C * N1; idx += NTT_THREADS) {
+  for (uint32_t idx = threadIdx.x; idx < C * N1; idx += blockDim.x) {
     uint32_t c = idx & (C - 1), j1 = idx >> lgC;
     uint32_t i2 = tile * C + c;
     F v = t.get(c * N1 + j1);
@@ -195,7 +204,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(const uint32_t* in, 
 }
 
 template <class FrP>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const uint32_t* tmp, uint32_t* out, const uint32_t* W, uint32_t log_n,
+__global__ void __launch_bounds__(NTT_THREADS_MAX) k_ntt_pass_b(const uint32_t* tmp, uint32_t* out, const uint32_t* W, uint32_t log_n,
                                                            uint32_t lg1, uint32_t R) {
   typedef Fd<FrP> F;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -205,14 +214,14 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const uint32_t* tmp,
   LdsTile<FrP, LDS_DATA> t{(uint2*)smem, R * N2};
   LdsTile<FrP, LDS_TWID> tw{(uint2*)(smem + (size_t)FrP::N * R * N2), N2 / 2 > 1 ? N2 / 2 : 1};
   const uint32_t* rin = tmp + ((size_t)row * N + (size_t)tile * R * N2) * FrP::N;
-  for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
+  for (uint32_t idx = threadIdx.x; idx < R * N2; idx += blockDim.x) {
     uint32_t r = idx >> lg2, i2 = idx & (N2 - 1);
     t.put(r * N2 + bitrev(i2, lg2), F::load(rin + (size_t)idx * FrP::N));
   }
   __syncthreads();
   lds_ntt_stages<FrP>(t, R, lg2, W, log_n, tw);
   uint32_t* rout = out + (size_t)row * N * FrP::N;
-  for (uint32_t idx = threadIdx.x; idx < R * N2; idx += NTT_THREADS) {
+  for (uint32_t idx = threadIdx.x; idx < R * N2; idx += blockDim.x) {
     uint32_t r = idx & (R - 1), j2 = idx >> lgR;
     F v = t.get(r * N2 + j2);
     v.store(rout + ((size_t)(tile * R + r) + (size_t)N1 * j2) * FrP::N);
@@ -245,7 +254,7 @@ class NttPlan {
     size_t need = rows * (size_t)N * FrP::N * 4;
     if (need > tmp_bytes_) { be_.sync(); be_.free(tmp_); tmp_ = (uint32_t*)be_.alloc(need); tmp_bytes_ = need; }
     uint32_t C = 8; while (C > N2) C >>= 1; while (C > 1 && C * N1 > NTT_TILE_MAX) C >>= 1;
-    uint32_t R = 8; while (R > N1) R >>= 1; while (R > 1 && R * N2 > NTT_TILE_MAX) R >>= 1;
+    uint32_t R = 8; while (R > N1) R >>= 1; while (R > 1 && R * N2 > (uint32_t)PC_NTT_TILE_B) R >>= 1;
     // tile + the stage twiddles of the pass (N1/2 resp. N2/2 elements)
     size_t lds_a = ((size_t)C * N1 + (N1 / 2 > 1 ? N1 / 2 : 1)) * FrP::N * 4, lds_b = ((size_t)R * N2 + (N2 / 2 > 1 ? N2 / 2 : 1)) * FrP::N * 4;
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) throw std::runtime_error("NTT size exceeds the LDS tile");
@@ -266,11 +275,11 @@ class NttPlan {
       const uint32_t* gin = in + r0 * in_cols * FrP::N;
       uint32_t* gtmp = tmp_ + r0 * (size_t)N * FrP::N;
       uint32_t* gout = out + r0 * (size_t)N * FrP::N;
-      hipLaunchKernelGGL(k_ntt_pass_a<FrP>, dim3((unsigned)(nr * (N2 / C))), dim3(NTT_THREADS), lds_a, be_.stream, gin,
+      hipLaunchKernelGGL(k_ntt_pass_a<FrP>, dim3((unsigned)(nr * (N2 / C))), dim3(PC_NTT_THREADS), lds_a, be_.stream, gin,
                          (uint32_t)in_cols, gtmp, W_, log_n_, lg1_, C, zskip);
       PC_HIP_CHECK(hipGetLastError());
       if (single) be_.mark();
-      hipLaunchKernelGGL(k_ntt_pass_b<FrP>, dim3((unsigned)(nr * (N1 / R))), dim3(NTT_THREADS), lds_b, be_.stream, gtmp, gout, W_,
+      hipLaunchKernelGGL(k_ntt_pass_b<FrP>, dim3((unsigned)(nr * (N1 / R))), dim3(PC_NTT_THREADS_B), lds_b, be_.stream, gtmp, gout, W_,
                          log_n_, lg1_, R);
       PC_HIP_CHECK(hipGetLastError());
     }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Copies the summaries of one tools/gpu_full_run.sh call (gpurun_out/d_*) into profiles/<round>_* (tracked).  usage: collect_profiles.sh r04
+# Copies the summaries of one tools/gpu_full_run.sh call (gpurun_out/d_*) into profiles/<round>_* (tracked).  usage: collect_profiles.sh r05
 set -e
 cd "$(dirname "$0")/.."
-P=${1:-r04}
+P=${1:-r05}
 G=gpurun_out
 cp $G/d_microbench.txt profiles/${P}_microbench.txt
 for f in bench_n1 bench_n1_inflight0 bench_n1_notable bench_n1_glv bench_ntt bench_rccl_1rank bench_2ranks_dev0 bench_8ranks_dev0 group_host group_device; do [ -f $G/d_$f.json ] && cp $G/d_$f.json profiles/${P}_$f.json; done
@@ -11,6 +11,8 @@ cp $G/d_ipa_2p22.json profiles/${P}_ipa_pallas_2p22.json
 cp $G/d_lincomb.json profiles/${P}_lincomb_bn254.json
 [ -f $G/d_hyrax.jsonl ] && cp $G/d_hyrax.jsonl profiles/${P}_hyrax_bn254.jsonl
 [ -f $G/d_msm_size_sweep.json ] && cp $G/d_msm_size_sweep.json profiles/${P}_msm_size_sweep.json
+[ -f $G/d_host_parts.jsonl ] && cp $G/d_host_parts.jsonl profiles/${P}_host_parts.jsonl
+[ -f $G/d_ldsntt/bench_counter_collection.csv ] && python tools/lds_summary.py $G/d_ldsntt/bench_counter_collection.csv profiles/${P}_ntt_lds_conflicts.json
 cp $G/d_prof24/bench_kernel_stats.csv profiles/${P}_bench_2p24_kernel_stats.csv
 cp $G/d_prof20/bench_kernel_stats.csv profiles/${P}_bench_2p20_kernel_stats.csv
 cp $G/d_profntt/bench_kernel_stats.csv profiles/${P}_ntt_kernel_stats.csv

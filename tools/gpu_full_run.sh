@@ -25,6 +25,9 @@ timeout -k 10 300 python tools/ipa_timing.py 22 2>/dev/null | tail -1 > gpurun_o
 timeout -k 10 200 python tools/lincomb_timing.py 2>/dev/null | tail -1 > gpurun_out/d_lincomb.json
 timeout -k 10 300 python tools/hyrax_timing.py 2>/dev/null | grep workload > gpurun_out/d_hyrax.jsonl
 PC_SWEEP_LOGS=8,10,12,14,16,18,20,22 timeout -k 10 300 python tools/msm_size_sweep.py 2>/dev/null | tail -1 > gpurun_out/d_msm_size_sweep.json
+# blocking calls on host memory (the trait-shaped calls): ONE MSM in parts (default weights), four equal parts, and round 4's two half-size MSMs
+rm -f gpurun_out/d_host_parts.jsonl
+for P in "1,2,5,8" "4" "0"; do PC_HIP_HOST_PARTS=$P timeout -k 10 300 python tools/host_parts_probe.py 24 2>/dev/null | tail -1 >> gpurun_out/d_host_parts.jsonl; done
 
 cd /tmp && export TMPDIR=/tmp
 B24="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-trait --inflight 0 --secondary-log-degree 0 --workloads none"
@@ -42,6 +45,8 @@ for w in 24:"$B24" 20:"$B20" ntt:"$NTT" batch:"$BATCH" pallas:"$PAL"; do
   prof d_sq$k --kernel-trace --pmc $SQ --output-format csv -d $R/gpurun_out/d_sq$k -o bench -- $cmd
 done
 PC_IPA_REPS=2 prof d_profipa --kernel-trace --stats --output-format csv -d $R/gpurun_out/d_profipa -o bench -- python $R/tools/ipa_timing.py 22
+# LDS bank conflicts of the NTT passes (conflict cycles against all LDS-array cycles)
+prof d_ldsntt --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/d_ldsntt -o bench -- $NTT
 cd $R
 find gpurun_out -name "*.csv" -size +30M -delete 2>/dev/null
 python - <<'PY'
@@ -58,4 +63,5 @@ for f in ("d_group_host", "d_group_device"):
 for f in ("d_bench_ntt", "d_bench_batch"):
     d = json.load(open(f"gpurun_out/{f}.json")); print(f, d["ms_per_step"], d.get("ntt_phase_ms"), d.get("column_hash_blake2s_ms"))
 print(open("gpurun_out/d_ipa_2p22.json").read()[:600])
+print(open("gpurun_out/d_host_parts.jsonl").read()[:2500])
 PY
