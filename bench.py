@@ -763,7 +763,7 @@ def kzg_case(ctx, D, args, curve, log_degree, steps, warmup, with_h2d, seed=0x5E
                  "parity_ok": bool((c == want_c).all() and (w == want_w).all()),
                  "note": "blocking pc_hip_msm with PC_MEM_HOST coefficients (pageable numpy memory, the H2D inside the call), then "
                          "pc_hip_kzg_open with the same host coefficients (copy + witness division + MSM in one call): the call "
-                         "sequence of the trait's commit(&poly) / open(&poly) with nothing cached between them; from 2^23 "
+                         "sequence of the trait's commit(&poly) / open(&poly) with nothing cached between them; from 2^21 "
                          "coefficients on both calls run as ONE MSM in parts (PC_HIP_HOST_PARTS, default weights 1,2,5,8): the PCIe copy "
                          "and the sort of a part under the accumulation of the one before, one bucket reduction and one host tail"}
 

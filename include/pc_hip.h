@@ -119,7 +119,10 @@ void* pc_hip_srs_device_ptr(const pc_srs* srs);
  * form = PC_SCALARS_MONTGOMERY accepts the polynomial's coefficient slice as it lies in
  * memory and fuses convert_to_bigints (kzg10/mod.rs:463-470) into the digit kernel.
  * out_xy: 2*sizeof(Fq) bytes on the host, affine, Montgomery; *out_is_infinity set if the
- * sum is the identity (out_xy is then all zero). */
+ * sum is the identity (out_xy is then all zero).
+ * HOST scalars of 2^21 pairs and more (PC_HIP_HOST_SPLIT_LOG2) run as ONE MSM in parts (PC_HIP_HOST_PARTS: a count, or relative
+ * weights; default "1,2,5,8"; 0 = two half-size MSMs on two pipelines): the PCIe copy and the sort of a part on an auxiliary queue
+ * beside the accumulation of the part before, one bucket reduction and one host tail -- the same point, bit for bit. */
 int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* scalars,
                pc_scalar_form form, pc_mem where, size_t n, void* out_xy, int* out_is_infinity);
 
@@ -161,8 +164,10 @@ int pc_hip_set_msm_tuning(pc_ctx* ctx, unsigned window_bits, unsigned chunk);
  * (digits+hist, scan, scatter, accumulate, seg-reduce, bucket-reduce, tail).  For bench.py.
  * After pc_hip_msm_batch over a window table (many-MSM passes): [0..5] summed over the passes, [6] the union of the passes'
  * accumulate intervals (passes overlap on two pipelines), [7] the number of passes.
- * After a blocking call that ran as two half-size MSMs (pc_hip_msm / pc_hip_kzg_open on host memory from 2^23 pairs): the SUM of the
- * two halves' phases; pc_hip_last_msm_marks_ms and pc_hip_last_msm_shape then describe the second half. */
+ * After a blocking call on host memory that ran in parts (pc_hip_msm / pc_hip_kzg_open from 2^21 pairs): [0..2] the sort of the FIRST
+ * part, [3] from there to the end of the last part's accumulation (the later parts' sorts and the bucket merges run inside it),
+ * [4] the last part's segmented reduction, [5] the one bucket reduction.  (PC_HIP_HOST_PARTS=0, two half-size MSMs: the SUM of the
+ * two halves' phases; marks and shape then describe the second half.) */
 int pc_hip_last_msm_phases_ms(const pc_ctx* ctx, float out[8]);
 /* The same phase boundaries of the last completed MSM as offsets (ms) from the moment pc_hip_set_timing(ctx, 1) was last
  * called: out[0] = the call was queued, out[1..6] = end of digits+hist, scan, scatter, accumulate, seg-reduce,
@@ -291,8 +296,9 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
                         const void* z_host, void* out, pc_mem where_out);
 /* KZG10::open without hiding as ONE call (poly-commit/src/kzg10/mod.rs:287-310 = compute_witness_polynomial :217-240 +
  * the MSM of open_with_witness_polynomial :255-258):  out = sum_j q[j] * bases[base_offset + j],  q = p / (x - z), n - 1 pairs.
- * coeffs: n Fr (Montgomery), host or device; the quotient never leaves the device.  Large HOST polynomials are processed as
- * two halves so that the second half's PCIe copy runs under the first half's MSM (see pc_hip_msm: the same split).  The
+ * coeffs: n Fr (Montgomery), host or device; the quotient never leaves the device.  Large HOST polynomials are processed in
+ * parts, top part first (its quotient needs nothing from below; every further part takes the carry of the one above), so that the
+ * copy + division of a part run under the accumulation of the part before (see pc_hip_msm: the same parts, one MSM).  The
  * reference's degree checks (kzg10/mod.rs:393-407) stay with the caller; n - 1 > srs length - base_offset is PC_ERR_INVALID_ARG. */
 int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* coeffs, pc_mem where, size_t n,
                     const void* z_host, void* out_xy, int* out_is_infinity);

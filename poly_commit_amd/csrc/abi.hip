@@ -472,8 +472,8 @@ void* pc_hip_srs_device_ptr(const pc_srs* srs) { return srs ? srs->bases : nullp
 
 // Scalars that arrive in HOST memory are copied inside the call (the trait hands over &[F]: 512 MB at degree 2^24, ~9 ms of PCIe).
 // Every step of one MSM needs all of its scalars, so nothing of that MSM can hide the copy -- but the MSM is a sum: from
-// host_split_min() pairs on, the call runs as TWO half-size MSMs on two pipelines, the second half's copy under the first half's
-// sort and accumulation, and adds the two points on the host (the fold of per-GPU partial results, pc_hip_points_sum).
+// host_split_min() pairs on (2^21: measured gains 8 % / 17 % / 17 % / 14 % of a commit at 2^21 / 2^22 / 2^23 / 2^24, a loss at 2^20),
+// the call runs in parts over index ranges (host_part_cuts below).
 // a job on this call's stack must not outlive it inside a pipeline (an exception between two enqueues would leave the lane with a
 // dangling pointer): completed on scope exit if it still is in flight
 struct StackJob {
@@ -482,7 +482,7 @@ struct StackJob {
   ~StackJob() { if (job.srs && !job.done) { try { complete_job(ctx, &job); } catch (...) {} } }
 };
 static size_t host_split_min() {
-  static const size_t v = []() { const char* e = getenv("PC_HIP_HOST_SPLIT_LOG2"); int lg = e ? atoi(e) : 23; return lg <= 0 ? (size_t)-1 : (size_t)1 << (lg > 40 ? 40 : lg); }();
+  static const size_t v = []() { const char* e = getenv("PC_HIP_HOST_SPLIT_LOG2"); int lg = e ? atoi(e) : 21; return lg <= 0 ? (size_t)-1 : (size_t)1 << (lg > 40 ? 40 : lg); }();
   return v;
 }
 // The two half-size jobs of a split call: pc_hip_last_msm_phases_ms then reports the SUM of both jobs' phase brackets (the halves run
@@ -994,9 +994,9 @@ int pc_hip_witness_poly(pc_ctx* ctx, pc_curve field_of, const void* coeffs, pc_m
 
 // KZG10::open without hiding (poly-commit/src/kzg10/mod.rs:287-310: compute_witness_polynomial :217-240, then
 // open_with_witness_polynomial's MSM :255-258) as ONE call: W = sum_j q[j] * powers[base_offset + j], q = p / (x - z).
-// The quotient never leaves the device.  Host coefficients of at least host_split_min() elements run as two halves, top half
-// first (its quotient needs nothing from below): copy + division + MSM of the top half, the bottom half's copy under that MSM,
-// its division with the carry q[h], its MSM on a second pipeline, and the two points added.
+// The quotient never leaves the device.  Host coefficients of at least host_split_min() elements run in parts, top part first (its
+// quotient needs nothing from below): copy + division of a part on the context's queue beside the accumulation of the part above on
+// the key's pipeline, every further division with the carry q[hi] of the part above; ONE MSM over all parts (MsmPlan::begin_parts).
 int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const void* coeffs, pc_mem where, size_t n, const void* z_host,
                     void* out_xy, int* out_is_infinity) {
   pc_srs* srs = const_cast<pc_srs*>(srs_c);
@@ -1019,7 +1019,7 @@ int pc_hip_kzg_open(pc_ctx* ctx, const pc_srs* srs_c, size_t base_offset, const 
     };
     CallBuf qbuf(ctx->be, 1, m * 32);
     uint32_t* q = (uint32_t*)qbuf.dev;
-    if (where == PC_MEM_DEVICE || m < host_split_min()) {
+    if (where == PC_MEM_DEVICE || n < host_split_min()) {
       Staged sin(ctx->be, coeffs, where, n * 32, true, 0);
       F.witness(ctx->be, (const uint32_t*)sin.dev, n, z, q, scan_fan());
       pc_job job;

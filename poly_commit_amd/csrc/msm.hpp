@@ -896,7 +896,7 @@ class MsmPlan {
     plan_geometry(n_total);
     parts_k_ = 0; in_parts_ = true; parts_n_ = 0;
     if (!entries2_) {        // second sort output + second bucket array, on first use (freed with the plan)
-      entries2_ = (uint32_t*)be_.alloc((entries_cap_ / 2 + 64) * 4);
+      entries2_ = (uint32_t*)be_.alloc(entries_cap_ * 4);          // (full size: any weights of the parts)
       offsets2_ = (uint32_t*)be_.alloc((nb_cap_ + 1) * 4);
       buckets2_ = (uint32_t*)be_.alloc(nb_cap_ * Pt::WORDS * 4);
       hist2_ = (uint32_t*)be_.alloc((nb_cap_ + 1) * 4);
@@ -907,7 +907,6 @@ class MsmPlan {
   // scalars_dev: the part's n scalars on the device; ready_tok: a backend token (aux_token / -1) after which they may be read
   void add_part(const uint32_t* bases_dev, uint32_t base_off, const uint32_t* scalars_dev, size_t n, bool from_mont, int ready_tok, bool last) {
     if (pending_empty_ || n == 0) { if (last && !pending_empty_) { if (parts_k_ == 0) { pending_empty_ = true; return; } reduce_and_download(); } return; }
-    if (parts_k_ > 0 && n * (size_t)g_.Wd > entries_cap_ / 2 + 64) throw MsmCapacityError("MsmPlan: a part exceeds half of the plan's entry capacity");
     part_body(bases_dev, base_off, scalars_dev, n, from_mont, 0, nullptr, parts_k_ == 0, last, ready_tok);
     parts_n_ += n;
     if (last) reduce_and_download();

@@ -100,18 +100,20 @@ struct LdsTile {
       return pos ^ (((pos >> 5) ^ (pos >> 10)) & 31u);
     } else return pos;
   }
-  __device__ __forceinline__ F get(uint32_t pos) const {
+  // (phys is linear over GF(2) with phys(0) = 0: phys(a ^ b) = phys(a) ^ phys(b).  The four positions of a radix-4 group differ in two
+  // bits that are zero in the first one, p + k h = p ^ k h, so a group costs ONE phys() and three XORs with wave-uniform constants)
+  __device__ __forceinline__ F get_at(uint32_t p) const {      // p: a physical position
     F r;
-    const uint32_t p = phys(pos);
 #pragma unroll
     for (int m = 0; m < FrP::N / 2; m++) { const uint2 v = base[m * stride + p]; r.l[2 * m] = v.x; r.l[2 * m + 1] = v.y; }
     return r;
   }
-  __device__ __forceinline__ void put(uint32_t pos, const F& v) const {
-    const uint32_t p = phys(pos);
+  __device__ __forceinline__ void put_at(uint32_t p, const F& v) const {
 #pragma unroll
     for (int m = 0; m < FrP::N / 2; m++) base[m * stride + p] = make_uint2(v.l[2 * m], v.l[2 * m + 1]);
   }
+  __device__ __forceinline__ F get(uint32_t pos) const { return get_at(phys(pos)); }
+  __device__ __forceinline__ void put(uint32_t pos, const F& v) const { put_at(phys(pos), v); }
 };
 
 // DIT butterfly stages over `lines` independent length-2^lg sequences laid out in LDS at
@@ -133,13 +135,14 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, 
   if (((lg - first_stage + 1) & 1) && s <= lg) {     // odd number of stages: one radix-2 stage first
     const uint32_t h = 1u << (s - 1);
     const uint32_t tw_shift = lg - s;                // omega_{2^s}^j = tw[j << (lg - s)]
+    const uint32_t dh = t.phys(h);
     for (uint32_t b = threadIdx.x; b < lines * halfs; b += blockDim.x) {
       uint32_t line = b >> (lg - 1), k = b & (halfs - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
-      uint32_t p0 = line * len + (g << s) + j, p1 = p0 + h;
-      F u = t.get(p0), v = t.get(p1);
+      const uint32_t q0 = t.phys(line * len + (g << s) + j), q1 = q0 ^ dh;
+      F u = t.get_at(q0), v = t.get_at(q1);
       if (j) v = v.mul(tw.get(j << tw_shift));
-      t.put(p0, u.add(v)); t.put(p1, u.sub(v));
+      t.put_at(q0, u.add(v)); t.put_at(q1, u.sub(v));
     }
     __syncthreads();
     s++;
@@ -152,17 +155,19 @@ __device__ __forceinline__ void lds_ntt_stages(const LdsTile<FrP, LDS_DATA>& t, 
   for (; s + 1 <= lg; s += 2) {
     const uint32_t h = 1u << (s - 1);
     const uint32_t sh1 = lg - s, sh2 = lg - s - 1;
+    const uint32_t d1 = t.phys(h), d2 = t.phys(2 * h), d3 = d1 ^ d2, dw = tw.phys(h << sh2);      // wave-uniform
     for (uint32_t b = threadIdx.x; b < lines * quarters; b += blockDim.x) {
       uint32_t line = b >> (lg - 2), k = b & (quarters - 1);
       uint32_t g = k >> (s - 1), j = k & (h - 1);
-      uint32_t p0 = line * len + (g << (s + 1)) + j;
-      F x0 = t.get(p0), x1 = t.get(p0 + h), x2 = t.get(p0 + 2 * h), x3 = t.get(p0 + 3 * h);
+      const uint32_t q0 = t.phys(line * len + (g << (s + 1)) + j);      // bits s-1 and s of the position are zero: + k h = ^ k h
+      F x0 = t.get_at(q0), x1 = t.get_at(q0 ^ d1), x2 = t.get_at(q0 ^ d2), x3 = t.get_at(q0 ^ d3);
+      const uint32_t qw = tw.phys(j << sh2);                             // (j + h) << sh2 = (j << sh2) ^ (h << sh2) for j < h
       if (j) { F w1 = tw.get(j << sh1); x1 = x1.mul(w1); x3 = x3.mul(w1); }
       F a0 = x0.add(x1), a1 = x0.sub(x1), a2 = x2.add(x3), a3 = x2.sub(x3);
-      if (j) a2 = a2.mul(tw.get(j << sh2));
-      a3 = a3.mul(tw.get((j + h) << sh2));
-      t.put(p0, a0.add(a2)); t.put(p0 + 2 * h, a0.sub(a2));
-      t.put(p0 + h, a1.add(a3)); t.put(p0 + 3 * h, a1.sub(a3));
+      if (j) a2 = a2.mul(tw.get_at(qw));
+      a3 = a3.mul(tw.get_at(qw ^ dw));
+      t.put_at(q0, a0.add(a2)); t.put_at(q0 ^ d2, a0.sub(a2));
+      t.put_at(q0 ^ d1, a1.add(a3)); t.put_at(q0 ^ d3, a1.sub(a3));
     }
     __syncthreads();
   }
