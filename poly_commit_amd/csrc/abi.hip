@@ -519,9 +519,10 @@ static const std::vector<double>& host_part_cuts() {      // cumulative fraction
 }
 static size_t host_parts() { return host_part_cuts().empty() ? 0 : host_part_cuts().size() - 1; }
 static size_t part_cut(size_t n, size_t k) { const auto& c = host_part_cuts(); return k + 1 >= c.size() ? n : (size_t)((double)n * c[k]); }
-// claim the next pipeline of the key for a job in parts (completing what it still holds)
+// claim a pipeline of the key for a job in parts (completing what it still holds).  Always the first one: a blocking call gains nothing from
+// rotating, and only the pipeline that runs parts grows the second sort output and bucket array (1.2 GB at 2^24 BLS12-381 points).
 static MsmLane* claim_lane(pc_ctx* ctx, pc_srs* srs, void* out_xy, int* out_is_infinity, pc_job* job) {
-  int li = srs->next_lane; srs->next_lane = (srs->next_lane + 1) % PC_MSM_LANES;
+  const int li = 0;
   MsmLane* L = srs_lane(srs, li);
   if (L->inflight) complete_job(ctx, L->inflight);
   L->be.timing = ctx->be.timing;

@@ -100,9 +100,12 @@ struct MsmRunnerT : MsmRunner {
     int tok = -1;
     if (where == PC_MEM_HOST && n) {      // the copy rides on the auxiliary queue (in order before this part's sort), beside the previous part's accumulation
       uint32_t* dst = plan.scalar_staging() + first * (size_t)C::FrP::N;
-      be.aux_begin(-1, -1);
-      be.copy_h2d(dst, scalars_part, n * (size_t)C::FrP::N * 4);
-      tok = be.aux_end();
+      {
+        struct AuxScope { HipBackend& b; int* tok; ~AuxScope() { try { *tok = b.aux_end(); } catch (...) { *tok = -1; } } };
+        be.aux_begin(-1, -1);
+        AuxScope scope{be, &tok};
+        be.copy_h2d(dst, scalars_part, n * (size_t)C::FrP::N * 4);
+      }
       sdev = dst;
     }
     plan.add_part(bases, base_off + (uint32_t)first, sdev, n, from_mont, tok, last);

@@ -208,7 +208,7 @@ struct HipBackend {
     if (wait_a >= 0) PC_HIP_CHECK(hipStreamWaitEvent(aux_stream, tok_ev[wait_a], 0));
     if (wait_b >= 0) PC_HIP_CHECK(hipStreamWaitEvent(aux_stream, tok_ev[wait_b], 0));
   }
-  int aux_end() { const int t = new_token(aux_stream); stream = aux_saved; aux_saved = nullptr; return t; }
+  int aux_end() { stream = aux_saved; aux_saved = nullptr; return new_token(aux_stream); }      // (the main queue is back before anything can throw)
   void wait_token(int t) { if (t >= 0) PC_HIP_CHECK(hipStreamWaitEvent(stream, tok_ev[t], 0)); }
   int main_token() { return new_token(stream); }
 

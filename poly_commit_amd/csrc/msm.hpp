@@ -942,11 +942,15 @@ class MsmPlan {
     const bool marks = !in_parts_ || first;              // phase marks: the sort of the first part; accumulate / seg-reduce marks of the last
     be_.memset(buckets, 0, (size_t)g.NB * Pt::WORDS * 4);
     if (in_parts_) {
-      be_.aux_begin(set_tok_[set], ready_tok);
-      const bool t = be_.timing_marks(marks);
-      be_.template sort_entries<C>(g, scalars_dev, hist, offsets, cursor, entries);
-      be_.timing_marks(t);
-      be_.wait_token(be_.aux_end());
+      int tok = -1;
+      {
+        // (a throw inside -- a failed workspace allocation -- must not leave the backend on its auxiliary queue)
+        struct AuxScope { Backend& b; bool marks_was; int* tok; ~AuxScope() { b.timing_marks(marks_was); try { *tok = b.aux_end(); } catch (...) { *tok = -1; } } };
+        be_.aux_begin(set_tok_[set], ready_tok);
+        AuxScope scope{be_, be_.timing_marks(marks), &tok};
+        be_.template sort_entries<C>(g, scalars_dev, hist, offsets, cursor, entries);
+      }
+      be_.wait_token(tok);
     } else {
       // steps 1-3: entries grouped by bucket + CSR offsets (backend chooses the sort)
       be_.template sort_entries<C>(g, scalars_dev, hist, offsets, cursor, entries);
