@@ -22,9 +22,9 @@ for curve in ("bls12_381", "bn254", "pallas"):
     nmax = 5000
     powers = O.gen_bases(curve, nmax)
     srs = ctx.upload_srs(curve, powers)
-    for table in (False, True):
+    for table in (False, True, "glv"):
         if table:
-            srs.precompute(min_pairs=1)
+            srs.precompute(min_pairs=1, glv=(table == "glv"))      # the full window table, then its GLV form (pre-split scalars, two bucket sets)
         for n in (1, 2, 3, 1023, 1024, 1025, 2049, 4097, 5000):
             coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x5EED0001 + n, n))
             if n >= 1025:
