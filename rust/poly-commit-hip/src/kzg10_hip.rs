@@ -280,8 +280,8 @@ where
         let dev = device::device_poly(p.coeffs())?;
         return open_device::<E, P>(powers, &dev, n, point, rand);
     }
-    // host coefficients: copy + witness division + MSM as ONE call (pc_hip_kzg_open; large polynomials as two halves, the
-    // second half's copy under the first half's MSM)
+    // host coefficients: copy + witness division + MSM as ONE call (pc_hip_kzg_open; large polynomials in parts, top part first: the
+    // copy + division of a part under the accumulation of the part above)
     let hiding_witness = if rand.is_hiding() {
         let divisor = P::from_coefficients_vec(vec![-point, E::ScalarField::from(1u64)]);
         Some(&rand.blinding_polynomial / &divisor)                                   // :228-236
