@@ -1,0 +1,44 @@
+"""The drop-in types override what the reference types override (round-4 review: `HipMarlinKZG10` / `HipIpaPC` inherited the trait's DEFAULT
+`open_combinations`, whose proofs the reference types' `check_combinations` rejects).  No Rust toolchain exists here, so this is a textual
+check: the set of methods inside `impl PolynomialCommitment ... for <ReferenceType>` (poly-commit/src/{marlin/marlin_pc,sonic_pc,ipa_pc}/mod.rs)
+must be a subset of the methods inside the shim's `impl PolynomialCommitment ... for Hip<Type>`.  Skipped where the reference checkout is absent."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/poly-commit/src"
+PAIRS = [("marlin/marlin_pc/mod.rs", "MarlinKZG10", "marlin_kzg10.rs", "HipMarlinKZG10"),
+         ("sonic_pc/mod.rs", "SonicKZG10", "sonic_kzg10.rs", "HipSonicKZG10"),
+         ("ipa_pc/mod.rs", "InnerProductArgPC", "ipa_pc.rs", "HipIpaPC")]
+
+
+def trait_impl_methods(text, type_name):
+    """names of the `fn`s directly inside `impl<..> PolynomialCommitment<..> for <type_name><..> { ... }`"""
+    m = re.search(r"impl\s*<[^{;]*?>\s*PolynomialCommitment\s*<[^{;]*?>\s*for\s+" + type_name + r"\b", text, re.S)
+    assert m, type_name
+    i = text.index("{", m.end())
+    depth, j, names = 0, i, []
+    while j < len(text):
+        ch = text[j]
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+            if depth == 0:
+                break
+        elif depth == 1 and text.startswith("fn ", j) and not text[j - 1].isalnum() and text[j - 1] != "_":
+            names.append(re.match(r"fn\s+(\w+)", text[j:]).group(1))
+        j += 1
+    return names
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("ref_file,ref_type,shim_file,shim_type", PAIRS)
+def test_shim_overrides_every_method_the_reference_type_overrides(ref_file, ref_type, shim_file, shim_type):
+    ref = set(trait_impl_methods(open(os.path.join(REF, ref_file)).read(), ref_type))
+    shim = set(trait_impl_methods(open(os.path.join(ROOT, "rust", "poly-commit-hip", "src", shim_file)).read(), shim_type))
+    assert {"setup", "trim", "commit", "open", "check"} <= ref, ref          # the parser found the impl block
+    missing = ref - shim
+    assert not missing, f"{shim_type} inherits the trait's default for {sorted(missing)}; {ref_type} overrides them"
