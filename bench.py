@@ -982,6 +982,23 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
                                                            "pipelines overlap with each other's sort and reductions)",
                                    "bracket_ms_mean": ph[3] / passes, "window_bits": shape["window_bits"], "buckets_per_polynomial": shape["buckets"] // max(1, min(8, polys)),
                                    "pass_phase_ms_sum": {k: float(v) for k, v in zip(["digits_hist", "scan", "scatter_fine_sort", "accumulate", "seg_reduce", "bucket_reduce"], ph[:6])}})
+    # trait-shaped: MarlinKZG10::commit hands the polynomials over in HOST memory (marlin_pc/mod.rs:172-242): one blocking
+    # pc_hip_msm_batch(PC_MEM_HOST) over pageable arrays, every pass's polynomials staged beside the other pipeline's pass
+    trait = None
+    if world == 1 and not args.no_trait:
+        hostv = [host_u64(v) for v in vec]
+        got = eng.srs.msm_batch(hostv, lens, host=True)
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            got = eng.srs.msm_batch(hostv, lens, host=True)
+        dt_t = (time.perf_counter() - t0) / reps
+        trait = {"ms_per_step": dt_t * 1e3, "value": polys * n / dt_t, "unit": "pairs/s",
+                 "parity_ok": bool(all((got[j] == out[j]).all() for j in range(polys))),
+                 "note": f"one blocking pc_hip_msm_batch over {polys} polynomials in pageable HOST memory ({polys * n * 32 / 2**20:.0f} MiB of PCIe "
+                         "inside the call): the polynomials of a pass are copied to the pipeline that will run it while the other "
+                         "pipeline runs the pass before"}
+        del hostv
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         try:
@@ -995,7 +1012,7 @@ def batch_case(ctx, D, args, log_degree, polys, steps, warmup):
     return {"workload": f"{polys} x MarlinKZG10<Bn254> commit, deg 2^{log_degree}, one SRS in {world} contiguous chunk(s) (BASELINE configs[2])",
             "value": pairs * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "ms_per_commitment": dt / steps * 1e3 / polys, "per_rank_ms_per_step": [float(x) / steps * 1e3 for x in per_rank],
-            "srs_window_table_build_ms": eng.precompute_ms, "roofline": roof, "cpu_baseline": cpu,
+            "srs_window_table_build_ms": eng.precompute_ms, "roofline": roof, "trait_shaped": trait, "cpu_baseline": cpu,
             "parity": {"all_commitments_closed_form_ok": bool(ok), "oracle_horner_checked": len(pick), "oracle_horner_ok": bool(ok_eval),
                        "method": "every C_j == p_j(beta) g on the true SRS (p_j(beta) from the device's evaluation kernel, "
                                  f"{len(pick)} of them re-evaluated by the oracle's Horner; scalar multiplication by the oracle)"}}

@@ -127,7 +127,10 @@ int pc_hip_msm(pc_ctx* ctx, const pc_srs* srs, size_t base_offset, const void* s
                pc_scalar_form form, pc_mem where, size_t n, void* out_xy, int* out_is_infinity);
 
 /* Batched MSM over one SRS (MarlinKZG10::commit's sequential loop over polynomials,
- * marlin_pc/mod.rs:192-237): n_polys independent scalar vectors, out_xy holds n_polys points. */
+ * marlin_pc/mod.rs:192-237): n_polys independent scalar vectors, out_xy holds n_polys points.
+ * Equal-length vectors against a key with a window table run 8 per pass (one sort / accumulate / reduce pipeline with a bucket set
+ * each, two such pipelines alternating); HOST vectors are copied pass by pass to the pipeline that will run them, beside the other
+ * pipeline's pass (64 x 2^20 BN254 scalars from pageable memory: 100 ms, device-resident: 92 ms). */
 int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs, const size_t* base_offsets,
                      const void* const* scalars, const size_t* n, size_t n_polys,
                      pc_scalar_form form, pc_mem where, void* out_xy, int* out_is_infinity);

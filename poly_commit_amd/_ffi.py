@@ -476,9 +476,12 @@ class Srs:
                                                     C.c_void_p(out.ctypes.data), inf))
         return out, np.array(list(inf)[:n_msms], dtype=bool)
 
-    def msm_batch(self, scalar_ptrs, lens, base_offsets=None, montgomery=True):
-        """pc_hip_msm_batch over device pointers: k scalar vectors against this SRS -> (k, 2*Fq) points."""
+    def msm_batch(self, scalar_ptrs, lens, base_offsets=None, montgomery=True, host=False):
+        """pc_hip_msm_batch: k scalar vectors against this SRS -> (k, 2*Fq) points.  scalar_ptrs: device pointers, or (host=True) host
+        numpy arrays / addresses (what MarlinKZG10::commit hands over: the library stages them pass by pass)."""
         k = len(scalar_ptrs)
+        if host:
+            scalar_ptrs = [p.ctypes.data if isinstance(p, np.ndarray) else p for p in scalar_ptrs]
         ptrs = (C.c_void_p * k)(*scalar_ptrs)
         ns = (C.c_size_t * k)(*lens)
         offs = (C.c_size_t * k)(*base_offsets) if base_offsets is not None else None
@@ -486,7 +489,7 @@ class Srs:
         infs = (C.c_int * k)()
         self.ctx.check(self.ctx.lib.pc_hip_msm_batch(self.ctx.h, self.h, offs, ptrs, ns, k,
                                                      PC_SCALARS_MONTGOMERY if montgomery else PC_SCALARS_CANONICAL,
-                                                     PC_MEM_DEVICE, C.c_void_p(out.ctypes.data), infs))
+                                                     PC_MEM_HOST if host else PC_MEM_DEVICE, C.c_void_p(out.ctypes.data), infs))
         return out
 
     def ec_fold(self, n_half, u):

@@ -68,7 +68,7 @@ struct pc_srs {
   // pc_hip_msm_many: window table of bases[base_offset .. base_offset + m) and the pipeline sized for B x m
   struct Many { size_t base_offset = 0, m = 0, B = 0; uint32_t* table = nullptr; MsmLane* lane = nullptr; } many;
   // pc_hip_msm_batch over the window table: G polynomials of m coefficients per pass, one bucket set each (two pipelines)
-  struct BatchMany { size_t m = 0, G = 0; MsmLane* lanes[2] = {nullptr, nullptr}; } bm;
+  struct BatchMany { size_t m = 0, G = 0; MsmLane* lanes[2] = {nullptr, nullptr}; uint32_t* stage[2] = {nullptr, nullptr}; } bm;      // stage: device copies of one pass's HOST polynomials
 };
 struct pc_job {
   pc_srs* srs = nullptr; int lane = 0;
@@ -167,7 +167,11 @@ static void drop_many(pc_srs* srs) {
 }
 
 static void drop_batch_many(pc_srs* srs) {
-  for (int i = 0; i < 2; i++) { delete srs->bm.lanes[i]; srs->bm.lanes[i] = nullptr; }
+  for (int i = 0; i < 2; i++) {
+    if (srs->bm.stage[i] && srs->bm.lanes[i]) srs->bm.lanes[i]->be.free(srs->bm.stage[i]);
+    srs->bm.stage[i] = nullptr;
+    delete srs->bm.lanes[i]; srs->bm.lanes[i] = nullptr;
+  }
   srs->bm.m = srs->bm.G = 0;
 }
 
@@ -624,7 +628,10 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
     // pc_hip_msm_many, over the key's own table).  The latency-bound reductions and the host tail are then paid once per G
     // polynomials and are wide enough to be throughput-bound; two such pipelines alternate.
     {
-      bool same = n_polys >= 2 && srs->table && where == PC_MEM_DEVICE && n[0] >= ((size_t)1 << 14) && n[0] >= srs->cfg.tbl_min_n;
+      // (HOST polynomials -- what MarlinKZG10::commit hands over -- take the same passes: the G polynomials of a pass are copied to a
+      // staging buffer on the pipeline that will run the pass, i.e. beside the other pipeline's pass: 64 x 2^20 host polynomials cost
+      // one exposed copy of 8, not 2 GiB of PCIe in front of the batch)
+      bool same = n_polys >= 2 && srs->table && n[0] >= ((size_t)1 << 14) && n[0] >= srs->cfg.tbl_min_n;
       const size_t b0 = base_offsets ? base_offsets[0] : 0;
       for (size_t k = 0; same && k < n_polys; k++) same = n[k] == n[0] && (base_offsets ? base_offsets[k] : 0) == b0 && scalars[k];
       if (same && b0 <= srs->n && n[0] <= srs->n - b0) {
@@ -675,7 +682,16 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
             drain(li);
             const size_t cnt = std::min(G, n_polys - first);
             std::vector<uint64_t> ptrs(cnt);
-            for (size_t k = 0; k < cnt; k++) ptrs[k] = (uint64_t)(uintptr_t)scalars[first + k];
+            if (where == PC_MEM_HOST) {
+              pc::HipBackend& lbe = B.lanes[li]->be;
+              if (!B.stage[li]) B.stage[li] = (uint32_t*)lbe.alloc(G * m * 32);
+              for (size_t k = 0; k < cnt; k++) {
+                uint32_t* dst = B.stage[li] + k * m * 8;
+                lbe.copy_h2d(dst, scalars[first + k], m * 32);
+                ptrs[k] = (uint64_t)(uintptr_t)dst;
+              }
+            } else
+              for (size_t k = 0; k < cnt; k++) ptrs[k] = (uint64_t)(uintptr_t)scalars[first + k];
             B.lanes[li]->be.timing = ctx->be.timing;
             B.lanes[li]->runner->enqueue_vectors(srs->bases, (uint32_t)b0, ptrs.data(), cnt, m, form == PC_SCALARS_MONTGOMERY);
             pending_first[li] = first; pending_cnt[li] = cnt;

@@ -120,8 +120,16 @@ where
         let batchable = all_valid && polys.len() >= 2 && len0 >= device::min_pairs()
             && polys.iter().all(|p| p.polynomial().coeffs().len() == len0 && !p.polynomial().coeffs()[0].is_zero());
         if batchable {
-            let devs = polys.iter().map(|p| device::device_poly(p.polynomial().coeffs())).collect::<Result<Vec<_>, _>>()?;
-            for (slot, c) in plain.iter_mut().zip(kzg10_hip::msm_batch::<E::G1Affine>(&powers.powers_of_g, &devs, 0, len0)?) {
+            // with the (opt-in) polynomial cache the device copies are kept for `open`; without it the host slices go straight to the
+            // library, which stages them pass by pass beside the running passes
+            let sums = if device::poly_cache_enabled() {
+                let devs = polys.iter().map(|p| device::device_poly(p.polynomial().coeffs())).collect::<Result<Vec<_>, _>>()?;
+                kzg10_hip::msm_batch::<E::G1Affine>(&powers.powers_of_g, &devs, 0, len0)?
+            } else {
+                let hosts: Vec<&[E::ScalarField]> = polys.iter().map(|p| p.polynomial().coeffs()).collect();
+                kzg10_hip::msm_batch_host::<E::G1Affine>(&powers.powers_of_g, &hosts, len0)?
+            };
+            for (slot, c) in plain.iter_mut().zip(sums) {
                 *slot = Some(c);
             }
         }

@@ -446,6 +446,11 @@ def test_msm_batch_fast_path_over_window_table(ctx, curve, k):
     assert (fast == slow).all()
     for j in (0, k // 2, k - 1):
         assert (fast[j] == O.msm_pippenger(curve, np.ascontiguousarray(b[off:off + m]), host[j], 8, 1)).all(), j
+    # HOST polynomials (what MarlinKZG10::commit hands over): the same passes, every pass's polynomials staged on its pipeline
+    mont = [np.ascontiguousarray(O.f_to_mont(curve, 1, h)) for h in host]
+    from_host = srs.msm_batch(mont, [m] * k, base_offsets=[off] * k, host=True)
+    assert (from_host == fast).all()
+    assert (srs.msm_batch(host, [m] * k, base_offsets=[off] * k, montgomery=False, host=True) == fast).all()      # canonical scalars
     # unequal lengths fall back to the per-polynomial pipelines
     lens = [m - j for j in range(k)]
     mixed = srs.msm_batch([t.data_ptr() for t in dev], lens, base_offsets=[off] * k)
