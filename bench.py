@@ -1202,7 +1202,7 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
 # ------------------------------------------------------------------------------------------------------------
 # configs[4]: Ligero over BLS12-381 Fr, 2^24 coefficients
 # ------------------------------------------------------------------------------------------------------------
-def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True):
+def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True, with_trait=True):
     import torch
     import oracle_lib as O
     from poly_commit_amd import sharded
@@ -1250,6 +1250,24 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True):
             ctx.merkle_tree(leaves.data_ptr(), "sha256", True, out=nodes.data_ptr(), n_leaves=N)
         torch.cuda.synchronize()
         merkle_ms = (time.perf_counter() - t0) / 3 * 1e3
+    # trait-shaped (world == 1): LinearCodePCS::commit keeps mat, ext_mat and the leaves in its commitment state on the HOST
+    # (linear_codes/mod.rs:248-297): one pc_hip_ligero_commit with the coefficient matrix coming from, and the encoded matrix going to,
+    # pageable host memory -- 0.5 GiB up, 2 GiB down
+    trait = None
+    if world == 1 and with_trait and rows * N * 32 <= (4 << 30):
+        hx = host_u64(x).reshape(rows, n_cols, 4)
+        hext = np.empty((rows, N, 4), dtype=np.uint64)
+        nodes_t, _ = ctx.ligero_commit(curve, hx, log_n, ext_out=hext)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            nodes_t, _ = ctx.ligero_commit(curve, hx, log_n, ext_out=hext)
+        dt_t = (time.perf_counter() - t0) / 2
+        ok_t = bool((hext[rows - 1] == host_u64(y.view(rows, N, 4)[rows - 1])).all() and (hext[0, :64] == host_u64(y.view(rows, N, 4)[0, :64])).all())
+        trait = {"ms_per_commit": dt_t * 1e3, "value": rows * n_cols / dt_t, "unit": "coeffs/s", "parity_ok": ok_t,
+                 "pcie_bytes": int(rows * (n_cols + N) * 32),
+                 "note": "one blocking pc_hip_ligero_commit: coefficient matrix from pageable host memory, encoded matrix + leaves + tree nodes back to it "
+                         "(what LinCodePCCommitmentState holds); the NTT + digests + tree are ~7 ms of it, the rest is PCIe"}
+        del hx, hext
     # N > 1: a column's digest needs the rows of every rank -- the digests' chaining states travel from rank to rank
     # (ShardedRows.commit / pc_hip_column_hash_part: 48 bytes per column and hop instead of a transpose of the matrix), the last
     # rank builds the tree and broadcasts the root
@@ -1327,7 +1345,7 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True):
             "value": world * rows * n_cols * steps / dt, "unit": "coeffs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "per_rank_ms_per_step": [float(v) / steps * 1e3 for v in per_rank],
             "ntt_phase_ms": {"pass_a": float(ph[0]), "pass_b": float(ph[1])},
-            "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms, "sharded_commit": chain,
+            "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms, "sharded_commit": chain, "trait_shaped": trait,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS if achieved else None,
                          "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
@@ -1537,7 +1555,7 @@ def main():
                 elif name == "ipa":
                     workloads[name] = ipa_case(ctx, 14 if small else 22, 2, with_cpu=not args.no_cpu_baseline)
                 elif name == "ligero":
-                    workloads[name] = ligero_case(ctx, D, curve, 16 if small else 24, 5 if small else 20, 2, with_cpu=not args.no_cpu_baseline)
+                    workloads[name] = ligero_case(ctx, D, curve, 16 if small else 24, 5 if small else 20, 2, with_cpu=not args.no_cpu_baseline, with_trait=not args.no_trait)
                 else:
                     workloads[name] = {"error": "unknown workload"}
             except Exception as e:      # one block failing must not lose the driver's line
