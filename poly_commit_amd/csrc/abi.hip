@@ -833,6 +833,10 @@ int pc_hip_ctx_trim(pc_ctx* ctx) {
     for (pc_srs* s : ctx->keys)
       for (int i = 0; i < PC_MSM_LANES; i++)
         if (s->lanes[i] && !s->lanes[i]->inflight) { s->lanes[i]->be.sync(); s->lanes[i]->be.trim(); }
+    // the staging copies of HOST polynomials in the batch pipelines (pc_hip_msm_batch: 2 x 8 polynomials)
+    for (pc_srs* s : ctx->keys)
+      for (int i = 0; i < 2; i++)
+        if (s->bm.stage[i] && s->bm.lanes[i]) { s->bm.lanes[i]->be.sync(); s->bm.lanes[i]->be.free(s->bm.stage[i]); s->bm.stage[i] = nullptr; }
     return (int)PC_OK;
   });
 }
