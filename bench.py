@@ -1266,7 +1266,8 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True, with_trait
         trait = {"ms_per_commit": dt_t * 1e3, "value": rows * n_cols / dt_t, "unit": "coeffs/s", "parity_ok": ok_t,
                  "pcie_bytes": int(rows * (n_cols + N) * 32),
                  "note": "one blocking pc_hip_ligero_commit: coefficient matrix from pageable host memory, encoded matrix + leaves + tree nodes back to it "
-                         "(what LinCodePCCommitmentState holds); the NTT + digests + tree are ~7 ms of it, the rest is PCIe"}
+                         "(what LinCodePCCommitmentState holds), in slabs of rows: the copy in, the NTT, the chained column digests of one slab run "
+                         "beside the previous slab's way out -- the call is the encoded matrix's PCIe time plus a few ms"}
         del hx, hext
     # N > 1: a column's digest needs the rows of every rank -- the digests' chaining states travel from rank to rank
     # (ShardedRows.commit / pc_hip_column_hash_part: 48 bytes per column and hop instead of a transpose of the matrix), the last

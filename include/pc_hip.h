@@ -275,12 +275,15 @@ int pc_hip_matrix_columns(pc_ctx* ctx, const void* mat_dev, size_t rows, size_t 
  * max(1, log_n), root first -- the commitment is nodes[0] plus the metadata the caller already has
  * (mod.rs:280-287).  leaves_out_host (2^log_n x 32 bytes) and ext_out (rows x 2^log_n Fr, host or
  * device per where_ext) are what LinCodePCCommitmentState keeps for open (mod.rs:264-268); either
- * may be NULL. */
+ * may be NULL.  With mat AND ext_out on the host -- the trait's shape -- the call runs in slabs of rows (32 MB of encoded matrix
+ * each, PC_HIP_LIGERO_SLAB_MB; 0 = off): slab s is copied in, encoded and absorbed into the column digests' chaining states while
+ * slab s - 1 travels back on a second queue, so the call costs little more than the encoded matrix's way over PCIe
+ * (config 5: 60 -> 41 ms) and holds two slabs instead of the encoded matrix in HBM; same bits either way. */
 int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
                          unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
                          pc_mem where_ext, void* leaves_out_host, void* nodes_out_host);
 /* Kernel-only milliseconds of the last pc_hip_ligero_commit (timing on): [NTT pass A, NTT pass B,
- * column digests, Merkle tree]. */
+ * column digests, Merkle tree]; a call that ran in slabs reports [0, 0, 0, Merkle tree] (its kernels run under the copies). */
 int pc_hip_last_ligero_phases_ms(const pc_ctx* ctx, float out[4]);
 
 /* out[i] = sum_j xi[j] * polys[j][i] for i < n_out (coefficients past lens[j] are zero): the

@@ -2,11 +2,14 @@
 // staging, error translation.  The kernels live in the per-curve / per-field translation units
 // (curve_*.hip, field_*.hip) and are reached through the ops tables of pc_internal.hpp.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
@@ -42,6 +45,8 @@ struct pc_ctx {
   float marks[8] = {0};          // the same marks as offsets from `epoch` (pc_hip_last_msm_marks_ms)
   hipEvent_t epoch = nullptr;    // recorded by pc_hip_set_timing(on)
   uint32_t shape[4] = {0};
+  // pc_hip_ligero_commit in row slabs: the slab buffers (grow-only up to LIGERO_KEEP, pc_hip_ctx_trim frees them) and the queue of the way out
+  void* lig_arena = nullptr; size_t lig_bytes = 0; hipStream_t lig_out_q = nullptr;
   std::vector<struct pc_srs*> keys;   // every key object of this context that is alive (pc_hip_ctx_bytes_resident, pc_hip_ctx_trim)
 };
 
@@ -212,6 +217,8 @@ void pc_hip_shutdown(pc_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   ctx->ntt_plans.clear();
   if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
+  if (ctx->lig_out_q) (void)hipStreamDestroy(ctx->lig_out_q);
+  ctx->be.free(ctx->lig_arena);
   ctx->be.destroy();
   delete ctx;
 }
@@ -825,6 +832,7 @@ int pc_hip_ctx_trim(pc_ctx* ctx) {
     ctx->be.sync();
     ctx->be.trim();
     ctx->ntt_plans.clear();
+    ctx->be.free(ctx->lig_arena); ctx->lig_arena = nullptr; ctx->lig_bytes = 0;      // pc_hip_ligero_commit's slab buffers
     // working keys that an opening handed back (pc_hip_ec_fold_from keeps one per committer key, with its three pipelines)
     std::vector<pc_srs*> cached;
     for (pc_srs* s : ctx->keys) if (s->work_cache) { cached.push_back(s->work_cache); s->work_cache = nullptr; }
@@ -1146,14 +1154,140 @@ int pc_hip_ipa_key_scalars(pc_ctx* ctx, pc_curve field_of, const void* coeffs_de
     return (int)PC_OK;
   });
 }
+// pc_hip_ligero_commit with the matrix AND the encoded matrix on the host (what LinearCodePCS::commit hands over and keeps,
+// linear_codes/mod.rs:248-268): the encoded matrix is 2^log_n / in_cols times the input and its way back over PCIe is the longest
+// leg of the call by far (config 5: 2 GiB, ~37 ms, against 9 ms in and 7 ms of kernels).  The rows are independent
+// (compute_matrices, mod.rs:131-135) and the column digests chain over row slabs (pc_hip_column_hash_part), so the call runs in slabs of
+// consecutive rows: slab s is copied in and encoded + absorbed on the context's queue while a helper thread copies slab s - 1 out on
+// a queue of its own (pageable copies block their calling thread; the two directions of the link only overlap from two threads).
+// Two slab buffers each way instead of the whole encoded matrix in HBM.  PC_HIP_LIGERO_SLAB_MB: encoded bytes per slab (default 32,
+// read per call; 0 = the whole-matrix path).  Measured on config 5 (tools/ligero_stream_probe.py): 60.1 ms whole, 42.7 / 40.9 / 41.8 /
+// 41.4 / 43.8 ms with slabs of 16 / 32 / 64 / 128 / 256 MB -- the 2 GiB on their way out alone take ~38 ms.
+static size_t ligero_slab_rows(size_t rows, size_t N) {
+  const char* e = getenv("PC_HIP_LIGERO_SLAB_MB");
+  const double mb = e ? atof(e) : 32.0;
+  if (!(mb > 0)) return 0;
+  size_t s = (size_t)(mb * 1048576.0 / ((double)N * 32.0));
+  s &= ~(size_t)1;                                     // every slab but the last holds an even number of rows (two rows fill a block)
+  if (s < 2) s = 2;
+  return s * 2 <= rows ? s : 0;                        // fewer than two slabs: nothing to overlap
+}
+
+static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* mat, size_t rows, size_t in_cols, unsigned log_n, size_t S,
+                                  pc_hash col_hash, pc_hash tree_hash, int len_prefix, char* ext_out, void* leaves_out_host, void* nodes_out_host) {
+  const size_t N = (size_t)1 << log_n, n_slabs = (rows + S - 1) / S;
+  const size_t in_row = in_cols * 32, ext_row = N * 32;
+  void* in_dev[2] = {nullptr, nullptr}; void* ext_dev[2] = {nullptr, nullptr};
+  void* state = nullptr; void* leaves = nullptr; void* nodes = nullptr; void* transient = nullptr;
+  hipStream_t out_q = nullptr;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t a_in = up(S * in_row), a_ext = up(S * ext_row), a_state = up(N * 48), a_leaves = up(N * 32), a_nodes = up((N > 1 ? N : 2) * 32);
+  const size_t arena_bytes = 2 * a_in + 2 * a_ext + a_state + a_leaves + a_nodes;
+  static constexpr size_t LIGERO_KEEP = (size_t)512 << 20;
+  std::vector<hipEvent_t> done(n_slabs, nullptr);
+  // main -> helper: slabs whose kernels are queued (their event is recorded); helper -> main: slabs copied out
+  std::mutex mu; std::condition_variable cv;
+  size_t queued = 0, copied = 0; bool stop = false; int helper_rc = PC_OK; std::string helper_err;
+  std::thread helper;
+  int rc = guarded(ctx, [&]() {
+    char* a;
+    if (arena_bytes <= LIGERO_KEEP) {
+      if (arena_bytes > ctx->lig_bytes) {
+        ctx->be.sync(); ctx->be.free(ctx->lig_arena); ctx->lig_arena = nullptr; ctx->lig_bytes = 0;
+        ctx->lig_arena = ctx->be.alloc(arena_bytes); ctx->lig_bytes = arena_bytes;
+      }
+      a = (char*)ctx->lig_arena;
+    } else {
+      a = (char*)(transient = ctx->be.alloc(arena_bytes));
+    }
+    for (int b = 0; b < 2; b++) { in_dev[b] = a; a += a_in; ext_dev[b] = a; a += a_ext; }
+    state = a; a += a_state; leaves = a; a += a_leaves; nodes = a;
+    if (!ctx->lig_out_q) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->lig_out_q, hipStreamNonBlocking));
+    out_q = ctx->lig_out_q;
+    for (auto& e : done) PC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto key = std::make_pair((int)field_of, log_n);
+    auto it = ctx->ntt_plans.find(key);
+    if (it == ctx->ntt_plans.end()) {
+      std::unique_ptr<NttRunner> r(pc::field_ops(field_of).make_ntt(ctx->be, log_n));
+      it = ctx->ntt_plans.emplace(key, std::move(r)).first;
+    }
+    NttRunner* ntt = it->second.get();
+    helper = std::thread([&]() {
+      try {
+        PC_HIP_CHECK(hipSetDevice(ctx->device));
+        for (size_t s = 0; s < n_slabs; s++) {
+          { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return queued > s || stop; }); if (queued <= s) return; }
+          const size_t r0 = s * S, nr = std::min(S, rows - r0);
+          PC_HIP_CHECK(hipStreamWaitEvent(out_q, done[s], 0));
+          PC_HIP_CHECK(hipMemcpyAsync(ext_out + r0 * ext_row, ext_dev[s & 1], nr * ext_row, hipMemcpyDeviceToHost, out_q));
+          PC_HIP_CHECK(hipStreamSynchronize(out_q));
+          { std::lock_guard<std::mutex> lk(mu); copied = s + 1; }
+          cv.notify_all();
+        }
+      } catch (const std::exception& e) {
+        { std::lock_guard<std::mutex> lk(mu); helper_rc = PC_ERR_HIP; helper_err = e.what(); copied = n_slabs; }      // releases a waiting producer
+        cv.notify_all();
+      }
+    });
+    const bool marks = ctx->be.timing_marks(false);
+    struct Restore { pc::HipBackend& be; bool m; ~Restore() { be.timing_marks(m); } } restore{ctx->be, marks};
+    for (size_t s = 0; s < n_slabs; s++) {
+      const int b = (int)(s & 1);
+      const size_t r0 = s * S, nr = std::min(S, rows - r0);
+      if (s >= 2) PC_HIP_CHECK(hipEventSynchronize(done[s - 2]));                      // in_dev[b] has been read
+      ctx->be.copy_h2d(in_dev[b], mat + r0 * in_row, nr * in_row);
+      if (s >= 2) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return copied >= s - 1; }); }   // ext_dev[b] is on the host
+      { std::lock_guard<std::mutex> lk(mu); if (helper_rc != PC_OK) break; }
+      ntt->run((const uint32_t*)in_dev[b], nr, in_cols, (uint32_t*)ext_dev[b]);
+      pc::field_ops(field_of).column_hash_part(ctx->be, (int)col_hash, (const uint32_t*)ext_dev[b], (uint32_t)nr, (uint32_t)N, (uint32_t)rows, 0u,
+                                               (uint32_t)N, s == 0, s + 1 == n_slabs, (uint32_t*)state, (uint32_t*)leaves);
+      PC_HIP_CHECK(hipEventRecord(done[s], ctx->be.stream));
+      { std::lock_guard<std::mutex> lk(mu); queued = s + 1; }
+      cv.notify_all();
+    }
+    return (int)PC_OK;
+  });
+  if (rc == PC_OK && helper_rc == PC_OK) {      // the tree and the small downloads run beside the last slab's way out
+    rc = pc_hip_merkle_tree(ctx, tree_hash, leaves, PC_MEM_DEVICE, N, len_prefix, nodes, PC_MEM_DEVICE);
+    if (rc == PC_OK) rc = guarded(ctx, [&]() {
+      unsigned h = 1; while (((size_t)1 << h) < N) h++;
+      ctx->be.copy_d2h(nodes_out_host, nodes, (((size_t)1 << h) - 1) * 32);
+      if (leaves_out_host) ctx->be.copy_d2h(leaves_out_host, leaves, N * 32);
+      return (int)PC_OK;
+    });
+  }
+  if (helper.joinable()) {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    helper.join();
+  }
+  if (rc == PC_OK && helper_rc != PC_OK) { ctx->last_error = helper_err; rc = helper_rc; }
+  (void)guarded(ctx, [&]() {
+    (void)hipStreamSynchronize(ctx->be.stream);
+    if (out_q) (void)hipStreamSynchronize(out_q);
+    ctx->be.free(transient);
+    for (auto e : done) if (e) (void)hipEventDestroy(e);
+    return (int)PC_OK;
+  });
+  const float ph[4] = {0, 0, 0, ctx->ntt_phases[0]};      // the slabs' kernels overlap the copies: only the tree has a bracket of its own
+  memcpy(ctx->ligero_phases, ph, sizeof ph);
+  return rc;
+}
+
 int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
                          unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
                          pc_mem where_ext, void* leaves_out_host, void* nodes_out_host) {
   if (!ctx || !rows || !in_cols || !mat || !nodes_out_host || log_n > 32 || in_cols > ((size_t)1 << log_n))
     return PC_ERR_INVALID_ARG;
   if (log_n > PC_HIP_NTT_MAX_LOG_N) return PC_ERR_UNSUPPORTED;
+  auto known = [](pc_hash h) { return (int)h == PC_HASH_SHA256 || (int)h == PC_HASH_BLAKE2S; };
+  if ((int)field_of < 0 || (int)field_of > 2 || !known(col_hash) || !known(tree_hash)) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   const size_t N = (size_t)1 << log_n;
+  if (where_in == PC_MEM_HOST && ext_out && where_ext == PC_MEM_HOST && rows < (1ull << 32))
+    if (const size_t S = ligero_slab_rows(rows, N))
+      return ligero_commit_streamed(ctx, field_of, (const char*)mat, rows, in_cols, log_n, S, col_hash, tree_hash, len_prefix, (char*)ext_out,
+                                    leaves_out_host, nodes_out_host);
   void* ext = nullptr; void* leaves = nullptr; void* nodes = nullptr;
   const bool own_ext = !(ext_out && where_ext == PC_MEM_DEVICE);
   int rc = guarded(ctx, [&]() {

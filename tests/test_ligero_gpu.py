@@ -107,3 +107,32 @@ def test_column_digests_chained_over_row_slabs(ctx, curve, hash_name):
     state = torch.zeros((n_cols, 12), dtype=torch.int32, device="cuda")
     with pytest.raises(pc.PcHipError):
         ctx.column_hash_part(curve, dev.data_ptr(), 3, n_cols, rows, state.data_ptr(), True, False, 0, hash_name)
+
+
+@pytest.mark.parametrize("curve,rows,in_cols,log_n", [("bls12_381", 37, 200, 9), ("bn254", 64, 128, 8), ("pallas", 11, 33, 7)])
+def test_host_to_host_commit_in_row_slabs(ctx, curve, rows, in_cols, log_n, monkeypatch):
+    """pc_hip_ligero_commit with the matrix and the encoded matrix on the host runs in slabs of rows (one slab copied in and encoded
+    while the one before is copied out by a helper thread; PC_HIP_LIGERO_SLAB_MB, read per call): encoded matrix, column digests and
+    tree equal to the whole-matrix path of the same call (slab size 0) and to the device-resident path, which the tests above
+    pin to the oracle -- for slabs of 2, 4 and 10 rows, an odd last slab, and a slab size that leaves one slab (whole-matrix path)."""
+    import torch
+    n = 1 << log_n
+    mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x57AB + rows, rows * in_cols)).reshape(rows, in_cols, 4)
+    monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", "0")
+    ext0 = np.zeros((rows, n, 4), dtype=np.uint64)
+    nodes0, leaves0 = ctx.ligero_commit(curve, mat, log_n, ext_out=ext0)
+    dev = torch.from_numpy(mat.view(np.int64)).cuda()
+    ext_dev = torch.zeros((rows, n, 4), dtype=torch.int64, device="cuda")
+    nodes_d, leaves_d = ctx.ligero_commit(curve, dev, log_n, rows=rows, in_cols=in_cols, ext_out=ext_dev)
+    assert (nodes_d == nodes0).all() and (leaves_d == leaves0).all() and (ext_dev.cpu().numpy().view(np.uint64) == ext0).all()
+    row_mb = n * 32 / 1048576.0
+    for slab_rows in (2, 4, 10, rows):
+        monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", repr(slab_rows * row_mb * 1.01))
+        ext = np.full((rows, n, 4), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
+        nodes, leaves = ctx.ligero_commit(curve, mat, log_n, ext_out=ext)
+        assert (ext == ext0).all(), (curve, slab_rows)
+        assert (leaves == leaves0).all() and (nodes == nodes0).all(), (curve, slab_rows)
+        nodes, _ = ctx.ligero_commit(curve, mat, log_n, ext_out=ext, want_leaves=False, col_hash="sha256", tree_hash="blake2s", len_prefix=False)
+        monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", "0")
+        nodes_w, _ = ctx.ligero_commit(curve, mat, log_n, ext_out=ext, want_leaves=False, col_hash="sha256", tree_hash="blake2s", len_prefix=False)
+        assert (nodes == nodes_w).all(), (curve, slab_rows, "sha256/blake2s")
