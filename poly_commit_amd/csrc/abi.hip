@@ -3,6 +3,7 @@
 // (curve_*.hip, field_*.hip) and are reached through the ops tables of pc_internal.hpp.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -11,8 +12,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include "pc_internal.hpp"
 
 using pc::MsmRunner;
@@ -46,7 +49,7 @@ struct pc_ctx {
   hipEvent_t epoch = nullptr;    // recorded by pc_hip_set_timing(on)
   uint32_t shape[4] = {0};
   // pc_hip_ligero_commit in row slabs: the slab buffers (grow-only up to LIGERO_KEEP, pc_hip_ctx_trim frees them) and the queue of the way out
-  void* lig_arena = nullptr; size_t lig_bytes = 0; hipStream_t lig_out_q = nullptr;
+  void* lig_arena = nullptr; size_t lig_bytes = 0; hipStream_t lig_out_q[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<struct pc_srs*> keys;   // every key object of this context that is alive (pc_hip_ctx_bytes_resident, pc_hip_ctx_trim)
 };
 
@@ -217,7 +220,7 @@ void pc_hip_shutdown(pc_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   ctx->ntt_plans.clear();
   if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
-  if (ctx->lig_out_q) (void)hipStreamDestroy(ctx->lig_out_q);
+  for (hipStream_t q : ctx->lig_out_q) if (q) (void)hipStreamDestroy(q);
   ctx->be.free(ctx->lig_arena);
   ctx->be.destroy();
   delete ctx;
@@ -1158,11 +1161,24 @@ int pc_hip_ipa_key_scalars(pc_ctx* ctx, pc_curve field_of, const void* coeffs_de
 // linear_codes/mod.rs:248-268): the encoded matrix is 2^log_n / in_cols times the input and its way back over PCIe is the longest
 // leg of the call by far (config 5: 2 GiB, ~37 ms, against 9 ms in and 7 ms of kernels).  The rows are independent
 // (compute_matrices, mod.rs:131-135) and the column digests chain over row slabs (pc_hip_column_hash_part), so the call runs in slabs of
-// consecutive rows: slab s is copied in and encoded + absorbed on the context's queue while a helper thread copies slab s - 1 out on
-// a queue of its own (pageable copies block their calling thread; the two directions of the link only overlap from two threads).
-// Two slab buffers each way instead of the whole encoded matrix in HBM.  PC_HIP_LIGERO_SLAB_MB: encoded bytes per slab (default 32,
-// read per call; 0 = the whole-matrix path).  Measured on config 5 (tools/ligero_stream_probe.py): 60.1 ms whole, 42.7 / 40.9 / 41.8 /
-// 41.4 / 43.8 ms with slabs of 16 / 32 / 64 / 128 / 256 MB -- the 2 GiB on their way out alone take ~38 ms.
+// consecutive rows: slab s is copied in and encoded + absorbed on the context's queue while helper threads copy the slabs before it
+// out on queues of their own.  helpers + 1 slab buffers each way instead of the whole encoded matrix in HBM.
+//
+// The caller's matrices are pageable memory, and a pageable copy blocks its calling thread while the runtime pins the pages (or finds
+// them in its cache of recent pins), moves them by DMA and lets go of them.  With ONE helper the call took 41 ms as long as that cache
+// hit -- the same buffers call after call in a quiet process -- and 80-82 ms whenever it did not (measured: from the moment a key with
+// its tables had been freed, for as long as the probe ran): pinning and unpinning 2 GiB costs about as much host time as moving them
+// takes, and one thread does the two one after the other.  So several helpers take the slabs in turn, one pinning while another's
+// DMA runs (after a key was freed: 82 / 53 / 46 / 52 ms with 1 / 2 / 3 / 4 helpers; quiet: 41-42 ms with any), and the calling thread
+// registers the pages of the coefficient matrix itself, in page-aligned pieces just ahead of its copies (released behind them;
+// registering does not write to the pages; memory the caller has registered already makes hipHostRegister fail, and the copies are
+// left as they are then) -- left to the runtime, the way in fell to a bounce-buffer memcpy at 11-27 GB/s of the calling thread.
+// The whole-matrix path of the same call: 58-60 ms in either state.
+// PC_HIP_LIGERO_SLAB_MB: encoded bytes per slab (default 32; 0 = the whole-matrix path), PC_HIP_LIGERO_HELPERS (default 3, at most 4),
+// PC_HIP_LIGERO_PIN=0: leave the coefficient matrix to the runtime, PC_HIP_LIGERO_TRACE=1: where the threads spent the call, on
+// stderr; all read per call.  tools/ligero_stream_probe.py sweeps them in both states of the process.
+static constexpr int LIG_MAX_HELPERS = 4;
+static int lig_helpers() { const char* e = getenv("PC_HIP_LIGERO_HELPERS"); const int h = e ? atoi(e) : 3; return h < 1 ? 1 : h > LIG_MAX_HELPERS ? LIG_MAX_HELPERS : h; }
 static size_t ligero_slab_rows(size_t rows, size_t N) {
   const char* e = getenv("PC_HIP_LIGERO_SLAB_MB");
   const double mb = e ? atof(e) : 32.0;
@@ -1173,22 +1189,56 @@ static size_t ligero_slab_rows(size_t rows, size_t N) {
   return s * 2 <= rows ? s : 0;                        // fewer than two slabs: nothing to overlap
 }
 
+namespace {
+// Page-aligned, disjoint registrations covering [lo, hi) piece by piece; every copy is cut at the pieces' edges.
+struct HostPins {
+  char* lo = nullptr; char* hi = nullptr; char* done_to = nullptr; size_t piece = (size_t)64 << 20; bool ok = true;
+  std::vector<char*> regs;
+  size_t freed = 0;                          // pieces [0, freed) are unregistered again
+  static uintptr_t page() { static const uintptr_t p = (uintptr_t)sysconf(_SC_PAGESIZE); return p; }
+  char* cut(size_t k) const {                // piece k covers [cut(k), cut(k + 1))
+    char* c = lo + k * piece;
+    if (c >= hi) return (char*)(((uintptr_t)hi + page() - 1) & ~(page() - 1));
+    return (char*)((uintptr_t)c & ~(page() - 1));
+  }
+  char* piece_end(char* a) const { const size_t k = (size_t)(a - lo) / piece; char* e = cut(k + 1); return e > a ? e : cut(k + 2); }
+  void cover(char* upto) {
+    while (ok && done_to < upto) {
+      const size_t k = regs.size();
+      char* b = cut(k); char* e = cut(k + 1);
+      if (e <= b) { done_to = hi; break; }
+      if (hipHostRegister(b, (size_t)(e - b), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+      regs.push_back(b); done_to = e;
+    }
+  }
+  void release_below(char* a) {             // every piece that ends at or below a (its copies have completed)
+    while (freed < regs.size() && cut(freed + 1) <= a) { (void)hipHostUnregister(regs[freed]); freed++; }
+  }
+  void release() { for (; freed < regs.size(); freed++) (void)hipHostUnregister(regs[freed]); }
+};
+}  // namespace
+
 static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* mat, size_t rows, size_t in_cols, unsigned log_n, size_t S,
                                   pc_hash col_hash, pc_hash tree_hash, int len_prefix, char* ext_out, void* leaves_out_host, void* nodes_out_host) {
   const size_t N = (size_t)1 << log_n, n_slabs = (rows + S - 1) / S;
   const size_t in_row = in_cols * 32, ext_row = N * 32;
-  void* in_dev[2] = {nullptr, nullptr}; void* ext_dev[2] = {nullptr, nullptr};
+  const int LIG_HELPERS = lig_helpers(), LIG_BUFS = LIG_HELPERS + 1;      // one slab under the kernels, one with every helper
+  void* in_dev[LIG_MAX_HELPERS + 1] = {}; void* ext_dev[LIG_MAX_HELPERS + 1] = {};
   void* state = nullptr; void* leaves = nullptr; void* nodes = nullptr; void* transient = nullptr;
-  hipStream_t out_q = nullptr;
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t a_in = up(S * in_row), a_ext = up(S * ext_row), a_state = up(N * 48), a_leaves = up(N * 32), a_nodes = up((N > 1 ? N : 2) * 32);
-  const size_t arena_bytes = 2 * a_in + 2 * a_ext + a_state + a_leaves + a_nodes;
+  const size_t arena_bytes = LIG_BUFS * (a_in + a_ext) + a_state + a_leaves + a_nodes;
   static constexpr size_t LIGERO_KEEP = (size_t)512 << 20;
   std::vector<hipEvent_t> done(n_slabs, nullptr);
-  // main -> helper: slabs whose kernels are queued (their event is recorded); helper -> main: slabs copied out
+  // caller -> helpers: slabs whose kernels are queued (their event is recorded); helpers -> caller: slabs that have arrived
   std::mutex mu; std::condition_variable cv;
-  size_t queued = 0, copied = 0; bool stop = false; int helper_rc = PC_OK; std::string helper_err;
-  std::thread helper;
+  size_t queued = 0; std::vector<char> arrived(n_slabs, 0); bool stop = false; int helper_rc = PC_OK; std::string helper_err;
+  std::thread helpers[LIG_MAX_HELPERS];
+  HostPins pins_in;
+  pins_in.lo = pins_in.done_to = const_cast<char*>(mat); pins_in.hi = pins_in.lo + rows * in_row;
+  if (const char* e = getenv("PC_HIP_LIGERO_PIN")) pins_in.ok = e[0] != '0';
+  double tr_out[LIG_MAX_HELPERS] = {}, tr_in[3] = {0, 0, 0};      // PC_HIP_LIGERO_TRACE: helpers [copies out], caller [input buffer free, pin + copy in, slab buffer free]
+  auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int rc = guarded(ctx, [&]() {
     char* a;
     if (arena_bytes <= LIGERO_KEEP) {
@@ -1200,10 +1250,10 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
     } else {
       a = (char*)(transient = ctx->be.alloc(arena_bytes));
     }
-    for (int b = 0; b < 2; b++) { in_dev[b] = a; a += a_in; ext_dev[b] = a; a += a_ext; }
+    for (int b = 0; b < LIG_BUFS; b++) { in_dev[b] = a; a += a_in; ext_dev[b] = a; a += a_ext; }
     state = a; a += a_state; leaves = a; a += a_leaves; nodes = a;
-    if (!ctx->lig_out_q) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->lig_out_q, hipStreamNonBlocking));
-    out_q = ctx->lig_out_q;
+    for (int h = 0; h < LIG_HELPERS; h++)
+      if (!ctx->lig_out_q[h]) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->lig_out_q[h], hipStreamNonBlocking));
     for (auto& e : done) PC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     auto key = std::make_pair((int)field_of, log_n);
     auto it = ctx->ntt_plans.find(key);
@@ -1212,31 +1262,48 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
       it = ctx->ntt_plans.emplace(key, std::move(r)).first;
     }
     NttRunner* ntt = it->second.get();
-    helper = std::thread([&]() {
-      try {
-        PC_HIP_CHECK(hipSetDevice(ctx->device));
-        for (size_t s = 0; s < n_slabs; s++) {
-          { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return queued > s || stop; }); if (queued <= s) return; }
-          const size_t r0 = s * S, nr = std::min(S, rows - r0);
-          PC_HIP_CHECK(hipStreamWaitEvent(out_q, done[s], 0));
-          PC_HIP_CHECK(hipMemcpyAsync(ext_out + r0 * ext_row, ext_dev[s & 1], nr * ext_row, hipMemcpyDeviceToHost, out_q));
-          PC_HIP_CHECK(hipStreamSynchronize(out_q));
-          { std::lock_guard<std::mutex> lk(mu); copied = s + 1; }
+    for (int h = 0; h < LIG_HELPERS; h++)
+      helpers[h] = std::thread([&, h]() {
+        try {
+          PC_HIP_CHECK(hipSetDevice(ctx->device));
+          hipStream_t q = ctx->lig_out_q[h];
+          for (size_t s = (size_t)h; s < n_slabs; s += LIG_HELPERS) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return queued > s || stop; }); if (queued <= s) return; }
+            const size_t r0 = s * S, nr = std::min(S, rows - r0);
+            const double t_a = now_ms();
+            PC_HIP_CHECK(hipStreamWaitEvent(q, done[s], 0));
+            PC_HIP_CHECK(hipMemcpyAsync(ext_out + r0 * ext_row, ext_dev[s % LIG_BUFS], nr * ext_row, hipMemcpyDeviceToHost, q));
+            PC_HIP_CHECK(hipStreamSynchronize(q));
+            tr_out[h] += now_ms() - t_a;
+            { std::lock_guard<std::mutex> lk(mu); arrived[s] = 1; }
+            cv.notify_all();
+          }
+        } catch (const std::exception& e) {
+          { std::lock_guard<std::mutex> lk(mu); helper_rc = PC_ERR_HIP; helper_err = e.what(); std::fill(arrived.begin(), arrived.end(), 1); }   // releases the caller
           cv.notify_all();
         }
-      } catch (const std::exception& e) {
-        { std::lock_guard<std::mutex> lk(mu); helper_rc = PC_ERR_HIP; helper_err = e.what(); copied = n_slabs; }      // releases a waiting producer
-        cv.notify_all();
-      }
-    });
+      });
     const bool marks = ctx->be.timing_marks(false);
     struct Restore { pc::HipBackend& be; bool m; ~Restore() { be.timing_marks(m); } } restore{ctx->be, marks};
     for (size_t s = 0; s < n_slabs; s++) {
-      const int b = (int)(s & 1);
+      const int b = (int)(s % LIG_BUFS);
       const size_t r0 = s * S, nr = std::min(S, rows - r0);
-      if (s >= 2) PC_HIP_CHECK(hipEventSynchronize(done[s - 2]));                      // in_dev[b] has been read
-      ctx->be.copy_h2d(in_dev[b], mat + r0 * in_row, nr * in_row);
-      if (s >= 2) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return copied >= s - 1; }); }   // ext_dev[b] is on the host
+      const double t_a = now_ms();
+      if (s >= (size_t)LIG_BUFS) PC_HIP_CHECK(hipEventSynchronize(done[s - LIG_BUFS]));        // in_dev[b] has been read
+      const double t_b = now_ms();
+      {
+        char* const h0 = pins_in.lo + r0 * in_row; char* const h1 = h0 + nr * in_row;
+        pins_in.cover(h1);
+        if (s >= (size_t)LIG_BUFS) pins_in.release_below(pins_in.lo + (s - LIG_BUFS + 1) * S * in_row);      // slab s - LIG_BUFS has been read
+        for (char* a = h0; a < h1;) {                     // no copy straddles two registrations
+          char* e = pins_in.ok ? std::min(h1, pins_in.piece_end(a)) : h1;
+          ctx->be.copy_h2d((char*)in_dev[b] + (a - h0), a, (size_t)(e - a));
+          a = e;
+        }
+      }
+      const double t_c = now_ms();
+      if (s >= (size_t)LIG_BUFS) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return arrived[s - LIG_BUFS] != 0; }); }   // ext_dev[b] is on the host
+      tr_in[0] += t_b - t_a; tr_in[1] += t_c - t_b; tr_in[2] += now_ms() - t_c;
       { std::lock_guard<std::mutex> lk(mu); if (helper_rc != PC_OK) break; }
       ntt->run((const uint32_t*)in_dev[b], nr, in_cols, (uint32_t*)ext_dev[b]);
       pc::field_ops(field_of).column_hash_part(ctx->be, (int)col_hash, (const uint32_t*)ext_dev[b], (uint32_t)nr, (uint32_t)N, (uint32_t)rows, 0u,
@@ -1247,7 +1314,7 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
     }
     return (int)PC_OK;
   });
-  if (rc == PC_OK && helper_rc == PC_OK) {      // the tree and the small downloads run beside the last slab's way out
+  if (rc == PC_OK && helper_rc == PC_OK) {      // the tree and the small downloads run beside the last slabs' way out
     rc = pc_hip_merkle_tree(ctx, tree_hash, leaves, PC_MEM_DEVICE, N, len_prefix, nodes, PC_MEM_DEVICE);
     if (rc == PC_OK) rc = guarded(ctx, [&]() {
       unsigned h = 1; while (((size_t)1 << h) < N) h++;
@@ -1256,19 +1323,21 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
       return (int)PC_OK;
     });
   }
-  if (helper.joinable()) {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
-    cv.notify_all();
-    helper.join();
-  }
+  { std::lock_guard<std::mutex> lk(mu); stop = true; }
+  cv.notify_all();
+  for (auto& t : helpers) if (t.joinable()) t.join();
   if (rc == PC_OK && helper_rc != PC_OK) { ctx->last_error = helper_err; rc = helper_rc; }
   (void)guarded(ctx, [&]() {
     (void)hipStreamSynchronize(ctx->be.stream);
-    if (out_q) (void)hipStreamSynchronize(out_q);
+    for (int h = 0; h < LIG_HELPERS; h++) if (ctx->lig_out_q[h]) (void)hipStreamSynchronize(ctx->lig_out_q[h]);
+    pins_in.release();
     ctx->be.free(transient);
     for (auto e : done) if (e) (void)hipEventDestroy(e);
     return (int)PC_OK;
   });
+  if (getenv("PC_HIP_LIGERO_TRACE"))
+    fprintf(stderr, "[pc_hip] ligero slabs %zu x %zu rows: helpers' copies out %.1f / %.1f ms | caller in-buffer %.1f pin + copy in %.1f out-buffer %.1f ms (input pinned: %d)\n",
+            n_slabs, S, tr_out[0], tr_out[LIG_HELPERS - 1], tr_in[0], tr_in[1], tr_in[2], (int)pins_in.ok);
   const float ph[4] = {0, 0, 0, ctx->ntt_phases[0]};      // the slabs' kernels overlap the copies: only the tree has a bracket of its own
   memcpy(ctx->ligero_phases, ph, sizeof ph);
   return rc;

@@ -112,9 +112,10 @@ def test_column_digests_chained_over_row_slabs(ctx, curve, hash_name):
 @pytest.mark.parametrize("curve,rows,in_cols,log_n", [("bls12_381", 37, 200, 9), ("bn254", 64, 128, 8), ("pallas", 11, 33, 7)])
 def test_host_to_host_commit_in_row_slabs(ctx, curve, rows, in_cols, log_n, monkeypatch):
     """pc_hip_ligero_commit with the matrix and the encoded matrix on the host runs in slabs of rows (one slab copied in and encoded
-    while the one before is copied out by a helper thread; PC_HIP_LIGERO_SLAB_MB, read per call): encoded matrix, column digests and
-    tree equal to the whole-matrix path of the same call (slab size 0) and to the device-resident path, which the tests above
-    pin to the oracle -- for slabs of 2, 4 and 10 rows, an odd last slab, and a slab size that leaves one slab (whole-matrix path)."""
+    while the ones before are copied out by helper threads; PC_HIP_LIGERO_SLAB_MB / _HELPERS / _PIN, read per call): encoded matrix,
+    column digests and tree equal to the whole-matrix path of the same call (slab size 0) and to the device-resident path, which the
+    tests above pin to the oracle -- for slabs of 2, 4 and 10 rows, an odd last slab, 1 to 4 helpers, and a slab size that leaves one
+    slab (whole-matrix path)."""
     import torch
     n = 1 << log_n
     mat = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0x57AB + rows, rows * in_cols)).reshape(rows, in_cols, 4)
@@ -126,8 +127,10 @@ def test_host_to_host_commit_in_row_slabs(ctx, curve, rows, in_cols, log_n, monk
     nodes_d, leaves_d = ctx.ligero_commit(curve, dev, log_n, rows=rows, in_cols=in_cols, ext_out=ext_dev)
     assert (nodes_d == nodes0).all() and (leaves_d == leaves0).all() and (ext_dev.cpu().numpy().view(np.uint64) == ext0).all()
     row_mb = n * 32 / 1048576.0
-    for slab_rows in (2, 4, 10, rows):
+    for slab_rows, helpers, pin in ((2, "3", "1"), (4, "1", "1"), (10, "4", "0"), (2, "2", "0"), (rows, "3", "1")):
         monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", repr(slab_rows * row_mb * 1.01))
+        monkeypatch.setenv("PC_HIP_LIGERO_HELPERS", helpers)      # threads copying slabs out (slab buffers: helpers + 1)
+        monkeypatch.setenv("PC_HIP_LIGERO_PIN", pin)              # the coefficient matrix registered by the call / left to the runtime
         ext = np.full((rows, n, 4), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
         nodes, leaves = ctx.ligero_commit(curve, mat, log_n, ext_out=ext)
         assert (ext == ext0).all(), (curve, slab_rows)

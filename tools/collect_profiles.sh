@@ -12,6 +12,7 @@ cp $G/d_lincomb.json profiles/${P}_lincomb_bn254.json
 [ -f $G/d_hyrax.jsonl ] && cp $G/d_hyrax.jsonl profiles/${P}_hyrax_bn254.jsonl
 [ -f $G/d_msm_size_sweep.json ] && cp $G/d_msm_size_sweep.json profiles/${P}_msm_size_sweep.json
 [ -f $G/d_host_parts.jsonl ] && cp $G/d_host_parts.jsonl profiles/${P}_host_parts.jsonl
+[ -f $G/d_ligero_stream.txt ] && cp $G/d_ligero_stream.txt profiles/${P}_ligero_stream.txt
 [ -f $G/d_ldsntt/bench_counter_collection.csv ] && python tools/lds_summary.py $G/d_ldsntt/bench_counter_collection.csv profiles/${P}_ntt_lds_conflicts.json
 cp $G/d_prof24/bench_kernel_stats.csv profiles/${P}_bench_2p24_kernel_stats.csv
 cp $G/d_prof20/bench_kernel_stats.csv profiles/${P}_bench_2p20_kernel_stats.csv

@@ -28,6 +28,8 @@ PC_SWEEP_LOGS=8,10,12,14,16,18,20,22 timeout -k 10 300 python tools/msm_size_swe
 # blocking calls on host memory (the trait-shaped calls): ONE MSM in parts (default weights), four equal parts, and round 4's two half-size MSMs
 rm -f gpurun_out/d_host_parts.jsonl
 for P in "1,2,5,8" "4" "0"; do PC_HIP_HOST_PARTS=$P timeout -k 10 300 python tools/host_parts_probe.py 24 2>/dev/null | tail -1 >> gpurun_out/d_host_parts.jsonl; done
+# pc_hip_ligero_commit host -> host against the slab size (0 = whole matrix)
+timeout -k 10 300 python tools/ligero_stream_probe.py --cold 2>/dev/null | grep slab > gpurun_out/d_ligero_stream.txt
 
 cd /tmp && export TMPDIR=/tmp
 B24="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-trait --inflight 0 --secondary-log-degree 0 --workloads none"
