@@ -1257,15 +1257,17 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True, with_trait
     if world == 1 and with_trait and rows * N * 32 <= (4 << 30):
         hx = host_u64(x).reshape(rows, n_cols, 4)
         hext = np.empty((rows, N, 4), dtype=np.uint64)
-        nodes_t, _ = ctx.ligero_commit(curve, hx, log_n, ext_out=hext)
+        for _ in range(2):      # the first call faults the pages of hext in, the second still pays for the pins the first one left behind
+            nodes_t, _ = ctx.ligero_commit(curve, hx, log_n, ext_out=hext)
         calls = []
-        for _ in range(4):
+        for _ in range(6):
             t0 = time.perf_counter()
             nodes_t, _ = ctx.ligero_commit(curve, hx, log_n, ext_out=hext)
             calls.append(time.perf_counter() - t0)
-        dt_t = sum(calls) / len(calls)
+        dt_t = sorted(calls)[len(calls) // 2]
         ok_t = bool((hext[rows - 1] == host_u64(y.view(rows, N, 4)[rows - 1])).all() and (hext[0, :64] == host_u64(y.view(rows, N, 4)[0, :64])).all())
-        trait = {"ms_per_commit": dt_t * 1e3, "ms_calls": [c * 1e3 for c in calls], "value": rows * n_cols / dt_t, "unit": "coeffs/s", "parity_ok": ok_t,
+        trait = {"ms_per_commit": dt_t * 1e3, "ms_per_commit_is": "median of six calls after two untimed ones", "ms_calls": [round(c * 1e3, 2) for c in calls],
+                 "ms_per_commit_mean": sum(calls) / len(calls) * 1e3, "value": rows * n_cols / dt_t, "unit": "coeffs/s", "parity_ok": ok_t,
                  "pcie_bytes": int(rows * (n_cols + N) * 32),
                  "note": "one blocking pc_hip_ligero_commit: coefficient matrix from pageable host memory, encoded matrix + leaves + tree nodes back to it "
                          "(what LinCodePCCommitmentState holds), in slabs of rows: the copy in, the NTT, the chained column digests of one slab run "

@@ -9,7 +9,8 @@
 //! (`poly-commit/src/utils.rs:49-61`), so a foreign crate can override `encode` but not `compute_matrices`.  Each row is
 //! therefore one blocking `pc_hip_ntt_batch(rows = 1)` call (the context serialises concurrent callers); the whole-matrix
 //! forms -- ONE `pc_hip_ntt_batch` for all rows, or `pc_hip_ligero_commit` for encode + column digests + Merkle tree with
-//! nothing but the root leaving HBM -- are exposed as [`encode_matrix`] / [`commit_root`] for callers that can take flat
+//! nothing but the root leaving HBM (or, with the encoded matrix coming back in slabs beside the kernels, [`commit_matrices`]) --
+//! are exposed as [`encode_matrix`] / [`commit_root`] for callers that can take flat
 //! buffers, and become the trait path with a one-line upstream change (`pub fn new_from_flat`).
 use ark_crypto_primitives::{
     crh::{CRHScheme, TwoToOneCRHScheme},
@@ -76,6 +77,33 @@ pub fn commit_root<F: HipField>(mat: &[F], rows: usize, in_cols: usize, rho_inv:
                                   core::ptr::null_mut(), ffi::PC_MEM_HOST, leaves.as_mut_ptr() as *mut c_void, nodes.as_mut_ptr() as *mut c_void)
     })?;
     Ok((nodes[0], leaves))
+}
+
+/// `commit_root` that also brings the encoded matrix back (`rows x 2^log_n`, row-major): with the coefficient matrix the caller
+/// already holds, everything `LinCodePCCommitmentState` keeps for `open` (`linear_codes/mod.rs:264-268`: mat, ext_mat, leaves).
+/// Matrix and encoded matrix both live in host memory here, which is the shape `pc_hip_ligero_commit` runs in slabs of rows: a slab
+/// is copied in, encoded and absorbed into the column digests while the slabs before it travel back (2^24 coefficients over
+/// BLS12-381 Fr: 2 GiB of encoded matrix, 42-46 ms for the call against 58-60 ms as one matrix).
+pub fn commit_matrices<F: HipField>(mat: &[F], rows: usize, in_cols: usize, rho_inv: usize, col_hash: c_int, tree_hash: c_int)
+    -> Result<([u8; 32], Vec<[u8; 32]>, Vec<F>), Error> {
+    assert_eq!(mat.len(), rows * in_cols);
+    let c = ctx()?;
+    let log_n = next_log2(in_cols * rho_inv);
+    if log_n > F::TWO_ADICITY {
+        return Err(Error::EncodingError);
+    }
+    let n = 1usize << log_n;
+    let mut leaves = vec![[0u8; 32]; n];
+    let mut nodes = vec![[0u8; 32]; (1usize << log_n.max(1)) - 1];
+    let mut ext = vec![[0u64; 4]; rows * n];
+    let packed;
+    let src = if F::layout_is_abi() { mat.as_ptr() as *const c_void } else { packed = pack_scalars(mat); packed.as_ptr() as *const c_void };
+    check(c, unsafe {
+        ffi::pc_hip_ligero_commit(c.raw, F::FIELD_OF, src, ffi::PC_MEM_HOST, rows, in_cols, log_n as c_uint, col_hash, tree_hash, 1,
+                                  ext.as_mut_ptr() as *mut c_void, ffi::PC_MEM_HOST, leaves.as_mut_ptr() as *mut c_void,
+                                  nodes.as_mut_ptr() as *mut c_void)
+    })?;
+    Ok((nodes[0], leaves, ext.into_iter().map(F::from_mont_limbs).collect()))
 }
 
 /// `commit_root` with the rows of the coefficient matrix spread over several devices (`pc_hip_group_ligero_commit`): every device
