@@ -216,7 +216,10 @@ int pc_hip_set_timing(pc_ctx* ctx, int on);
  * test_reed_solomon, utils.rs:303-331).
  * log_n <= PC_HIP_NTT_MAX_LOG_N (the transform runs as two LDS-staged passes of 2^ceil(log_n/2) and
  * 2^floor(log_n/2) points; Ligero's rows are 2^17 at 2^24 coefficients); larger sizes return
- * PC_ERR_UNSUPPORTED before anything is allocated. */
+ * PC_ERR_UNSUPPORTED before anything is allocated.  With `in` and `out` both in host memory and more than one
+ * slab of rows (32 MB of output each, PC_HIP_LIGERO_SLAB_MB) the call runs like pc_hip_ligero_commit's
+ * host-to-host form: a slab goes in and is transformed while the slabs before it travel back
+ * (pc_hip_last_ntt_phases_ms reports zeros then: the kernels run under the copies). */
 #define PC_HIP_NTT_MAX_LOG_N 22
 int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem where_in, size_t rows,
                      size_t in_cols, unsigned log_n, void* out, pc_mem where_out);

@@ -898,6 +898,9 @@ struct Staged {
   ~Staged() { if (owned) be.free(dev); }
 };
 
+static size_t ligero_slab_rows(size_t rows, size_t N);
+static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* mat, size_t rows, size_t in_cols, unsigned log_n, size_t S,
+                                  pc_hash col_hash, pc_hash tree_hash, int len_prefix, char* ext_out, void* leaves_out_host, void* nodes_out_host);
 int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem where_in, size_t rows, size_t in_cols,
                      unsigned log_n, void* out, pc_mem where_out) {
   if (!ctx || (int)field_of < 0 || (int)field_of > 2 || (rows && (!in || !out))) return PC_ERR_INVALID_ARG;
@@ -906,6 +909,13 @@ int pc_hip_ntt_batch(pc_ctx* ctx, pc_curve field_of, const void* in, pc_mem wher
   if (log_n > PC_HIP_NTT_MAX_LOG_N) return PC_ERR_UNSUPPORTED;   // two LDS-staged passes: one factor must fit the 160 KB LDS
   if (in_cols > ((size_t)1 << log_n)) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  // host -> host (LinearEncode::encode over a whole matrix, the shim's encode_matrix): in slabs of rows, the encoded slabs on their way
+  // back beside the kernels of the next ones -- pc_hip_ligero_commit's road without the digests
+  if (where_in == PC_MEM_HOST && where_out == PC_MEM_HOST && rows && in_cols && rows < (1ull << 32))
+    if (const size_t S = ligero_slab_rows(rows, (size_t)1 << log_n)) {
+      ctx->ntt_phases[0] = ctx->ntt_phases[1] = 0;
+      return ligero_commit_streamed(ctx, field_of, (const char*)in, rows, in_cols, log_n, S, PC_HASH_SHA256, PC_HASH_SHA256, 0, (char*)out, nullptr, nullptr);
+    }
   return guarded(ctx, [&]() {
     if (rows == 0) return (int)PC_OK;
     auto key = std::make_pair((int)field_of, log_n);
@@ -1222,6 +1232,7 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
                                   pc_hash col_hash, pc_hash tree_hash, int len_prefix, char* ext_out, void* leaves_out_host, void* nodes_out_host) {
   const size_t N = (size_t)1 << log_n, n_slabs = (rows + S - 1) / S;
   const size_t in_row = in_cols * 32, ext_row = N * 32;
+  const bool with_digests = nodes_out_host != nullptr;      // pc_hip_ntt_batch host -> host takes the same road without them
   const int LIG_HELPERS = lig_helpers(), LIG_BUFS = LIG_HELPERS + 1;      // one slab under the kernels, one with every helper
   void* in_dev[LIG_MAX_HELPERS + 1] = {}; void* ext_dev[LIG_MAX_HELPERS + 1] = {};
   void* state = nullptr; void* leaves = nullptr; void* nodes = nullptr; void* transient = nullptr;
@@ -1306,15 +1317,16 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
       tr_in[0] += t_b - t_a; tr_in[1] += t_c - t_b; tr_in[2] += now_ms() - t_c;
       { std::lock_guard<std::mutex> lk(mu); if (helper_rc != PC_OK) break; }
       ntt->run((const uint32_t*)in_dev[b], nr, in_cols, (uint32_t*)ext_dev[b]);
-      pc::field_ops(field_of).column_hash_part(ctx->be, (int)col_hash, (const uint32_t*)ext_dev[b], (uint32_t)nr, (uint32_t)N, (uint32_t)rows, 0u,
-                                               (uint32_t)N, s == 0, s + 1 == n_slabs, (uint32_t*)state, (uint32_t*)leaves);
+      if (with_digests)
+        pc::field_ops(field_of).column_hash_part(ctx->be, (int)col_hash, (const uint32_t*)ext_dev[b], (uint32_t)nr, (uint32_t)N, (uint32_t)rows, 0u,
+                                                 (uint32_t)N, s == 0, s + 1 == n_slabs, (uint32_t*)state, (uint32_t*)leaves);
       PC_HIP_CHECK(hipEventRecord(done[s], ctx->be.stream));
       { std::lock_guard<std::mutex> lk(mu); queued = s + 1; }
       cv.notify_all();
     }
     return (int)PC_OK;
   });
-  if (rc == PC_OK && helper_rc == PC_OK) {      // the tree and the small downloads run beside the last slabs' way out
+  if (rc == PC_OK && helper_rc == PC_OK && with_digests) {      // the tree and the small downloads run beside the last slabs' way out
     rc = pc_hip_merkle_tree(ctx, tree_hash, leaves, PC_MEM_DEVICE, N, len_prefix, nodes, PC_MEM_DEVICE);
     if (rc == PC_OK) rc = guarded(ctx, [&]() {
       unsigned h = 1; while (((size_t)1 << h) < N) h++;
@@ -1338,7 +1350,7 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
   if (getenv("PC_HIP_LIGERO_TRACE"))
     fprintf(stderr, "[pc_hip] ligero slabs %zu x %zu rows: helpers' copies out %.1f / %.1f ms | caller in-buffer %.1f pin + copy in %.1f out-buffer %.1f ms (input pinned: %d)\n",
             n_slabs, S, tr_out[0], tr_out[LIG_HELPERS - 1], tr_in[0], tr_in[1], tr_in[2], (int)pins_in.ok);
-  const float ph[4] = {0, 0, 0, ctx->ntt_phases[0]};      // the slabs' kernels overlap the copies: only the tree has a bracket of its own
+  const float ph[4] = {0, 0, 0, with_digests ? ctx->ntt_phases[0] : 0.f};      // the slabs' kernels overlap the copies: only the tree has a bracket of its own
   memcpy(ctx->ligero_phases, ph, sizeof ph);
   return rc;
 }

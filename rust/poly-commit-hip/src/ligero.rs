@@ -38,6 +38,8 @@ fn next_log2(n: usize) -> u32 {
 }
 
 /// `rows` messages of `in_cols` coefficients each (row-major) -> `rows x 2^log_n` evaluations, natural order, arkworks' omega.
+/// (Host memory on both sides: the library runs the call in slabs of rows, the transformed slabs travelling back beside the kernels
+/// of the next ones -- 512 x 2^15 -> 512 x 2^17 over BLS12-381 Fr in 41 ms instead of 55.)
 pub fn encode_matrix<F: HipField>(msgs: &[F], rows: usize, in_cols: usize, rho_inv: usize) -> Result<Vec<F>, Error> {
     assert_eq!(msgs.len(), rows * in_cols);
     let c = ctx()?;

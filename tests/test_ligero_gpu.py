@@ -135,6 +135,7 @@ def test_host_to_host_commit_in_row_slabs(ctx, curve, rows, in_cols, log_n, monk
         nodes, leaves = ctx.ligero_commit(curve, mat, log_n, ext_out=ext)
         assert (ext == ext0).all(), (curve, slab_rows)
         assert (leaves == leaves0).all() and (nodes == nodes0).all(), (curve, slab_rows)
+        assert (ctx.ntt_batch(curve, mat, log_n) == ext0).all(), (curve, slab_rows, "pc_hip_ntt_batch host -> host takes the same slabs, without digests")
         nodes, _ = ctx.ligero_commit(curve, mat, log_n, ext_out=ext, want_leaves=False, col_hash="sha256", tree_hash="blake2s", len_prefix=False)
         monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", "0")
         nodes_w, _ = ctx.ligero_commit(curve, mat, log_n, ext_out=ext, want_leaves=False, col_hash="sha256", tree_hash="blake2s", len_prefix=False)
