@@ -281,9 +281,8 @@ int pc_hip_matrix_columns(pc_ctx* ctx, const void* mat_dev, size_t rows, size_t 
  * may be NULL.  With mat AND ext_out on the host -- the trait's shape -- the call runs in slabs of rows (32 MB of encoded matrix
  * each, PC_HIP_LIGERO_SLAB_MB; 0 = off): slab s is copied in, encoded and absorbed into the column digests' chaining states while
  * the slabs before it travel back, copied by three helper threads on queues of their own (pageable copies block their caller while
- * the pages are pinned), so the call costs little more than the encoded matrix's way over PCIe (config 5: 58-60 -> 42-46 ms)
- * and holds four slabs instead of the encoded matrix in HBM; same bits either way.  The pages of `mat` are registered
- * (hipHostRegister) piece by piece for the duration of their copies; they are not written to. */
+ * the pages are pinned), so the call costs little more than the encoded matrix's way over PCIe (config 5: 58-60 -> 39-43 ms)
+ * and holds four slabs instead of the encoded matrix in HBM; same bits either way. */
 int pc_hip_ligero_commit(pc_ctx* ctx, pc_curve field_of, const void* mat, pc_mem where_in, size_t rows, size_t in_cols,
                          unsigned log_n, pc_hash col_hash, pc_hash tree_hash, int len_prefix, void* ext_out,
                          pc_mem where_ext, void* leaves_out_host, void* nodes_out_host);

@@ -1179,14 +1179,15 @@ int pc_hip_ipa_key_scalars(pc_ctx* ctx, pc_curve field_of, const void* coeffs_de
 // hit -- the same buffers call after call in a quiet process -- and 80-82 ms whenever it did not (measured: from the moment a key with
 // its tables had been freed, for as long as the probe ran): pinning and unpinning 2 GiB costs about as much host time as moving them
 // takes, and one thread does the two one after the other.  So several helpers take the slabs in turn, one pinning while another's
-// DMA runs (after a key was freed: 82 / 53 / 46 / 52 ms with 1 / 2 / 3 / 4 helpers; quiet: 41-42 ms with any), and the calling thread
-// registers the pages of the coefficient matrix itself, in page-aligned pieces just ahead of its copies (released behind them;
-// registering does not write to the pages; memory the caller has registered already makes hipHostRegister fail, and the copies are
-// left as they are then) -- left to the runtime, the way in fell to a bounce-buffer memcpy at 11-27 GB/s of the calling thread.
+// DMA runs (after a key was freed: 82 / 53 / 43-46 / 52 ms with 1 / 2 / 3 / 4 helpers; quiet: 40-42 ms with any).  The way IN stays with
+// the runtime too: with one helper it was the slow side after a key was freed (a bounce-buffer memcpy at 11 GB/s of the calling
+// thread), with three it hides under the way out, and registering the coefficient matrix's pages from the calling thread instead
+// (PC_HIP_LIGERO_PIN=1: page-aligned pieces just ahead of the copies, released behind them) measured 2-3 ms slower in both states
+// (42.3 vs 40.0 ms quiet, 46.0 vs 42.8 ms after a key was freed: releasing a registration waits for the device).
 // The whole-matrix path of the same call: 58-60 ms in either state.
 // PC_HIP_LIGERO_SLAB_MB: encoded bytes per slab (default 32; 0 = the whole-matrix path), PC_HIP_LIGERO_HELPERS (default 3, at most 4),
-// PC_HIP_LIGERO_PIN=0: leave the coefficient matrix to the runtime, PC_HIP_LIGERO_TRACE=1: where the threads spent the call, on
-// stderr; all read per call.  tools/ligero_stream_probe.py sweeps them in both states of the process.
+// PC_HIP_LIGERO_PIN=1: register the coefficient matrix's pages, PC_HIP_LIGERO_TRACE=1: where the threads spent the call, on stderr;
+// all read per call.  tools/ligero_stream_probe.py sweeps them in both states of the process.
 static constexpr int LIG_MAX_HELPERS = 4;
 static int lig_helpers() { const char* e = getenv("PC_HIP_LIGERO_HELPERS"); const int h = e ? atoi(e) : 3; return h < 1 ? 1 : h > LIG_MAX_HELPERS ? LIG_MAX_HELPERS : h; }
 static size_t ligero_slab_rows(size_t rows, size_t N) {
@@ -1247,7 +1248,8 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
   std::thread helpers[LIG_MAX_HELPERS];
   HostPins pins_in;
   pins_in.lo = pins_in.done_to = const_cast<char*>(mat); pins_in.hi = pins_in.lo + rows * in_row;
-  if (const char* e = getenv("PC_HIP_LIGERO_PIN")) pins_in.ok = e[0] != '0';
+  pins_in.ok = false;
+  if (const char* e = getenv("PC_HIP_LIGERO_PIN")) pins_in.ok = e[0] == '1';
   double tr_out[LIG_MAX_HELPERS] = {}, tr_in[3] = {0, 0, 0};      // PC_HIP_LIGERO_TRACE: helpers [copies out], caller [input buffer free, pin + copy in, slab buffer free]
   auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int rc = guarded(ctx, [&]() {

@@ -85,7 +85,7 @@ pub fn commit_root<F: HipField>(mat: &[F], rows: usize, in_cols: usize, rho_inv:
 /// already holds, everything `LinCodePCCommitmentState` keeps for `open` (`linear_codes/mod.rs:264-268`: mat, ext_mat, leaves).
 /// Matrix and encoded matrix both live in host memory here, which is the shape `pc_hip_ligero_commit` runs in slabs of rows: a slab
 /// is copied in, encoded and absorbed into the column digests while the slabs before it travel back (2^24 coefficients over
-/// BLS12-381 Fr: 2 GiB of encoded matrix, 42-46 ms for the call against 58-60 ms as one matrix).
+/// BLS12-381 Fr: 2 GiB of encoded matrix, 39-43 ms for the call against 58-60 ms as one matrix).
 pub fn commit_matrices<F: HipField>(mat: &[F], rows: usize, in_cols: usize, rho_inv: usize, col_hash: c_int, tree_hash: c_int)
     -> Result<([u8; 32], Vec<[u8; 32]>, Vec<F>), Error> {
     assert_eq!(mat.len(), rows * in_cols);

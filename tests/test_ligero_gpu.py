@@ -130,7 +130,7 @@ def test_host_to_host_commit_in_row_slabs(ctx, curve, rows, in_cols, log_n, monk
     for slab_rows, helpers, pin in ((2, "3", "1"), (4, "1", "1"), (10, "4", "0"), (2, "2", "0"), (rows, "3", "1")):
         monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", repr(slab_rows * row_mb * 1.01))
         monkeypatch.setenv("PC_HIP_LIGERO_HELPERS", helpers)      # threads copying slabs out (slab buffers: helpers + 1)
-        monkeypatch.setenv("PC_HIP_LIGERO_PIN", pin)              # the coefficient matrix registered by the call / left to the runtime
+        monkeypatch.setenv("PC_HIP_LIGERO_PIN", pin)              # the coefficient matrix's pages registered by the call (1) / left to the runtime (0, the default)
         ext = np.full((rows, n, 4), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
         nodes, leaves = ctx.ligero_commit(curve, mat, log_n, ext_out=ext)
         assert (ext == ext0).all(), (curve, slab_rows)
