@@ -58,8 +58,156 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PC_BENCH_FORCE_
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
+# ------------------------------------------------------------------------------------------------------------
+# the result line.  The driver parses ONE JSON line from stdout and keeps only a bounded tail of it: the line is a
+# compact summary of at most LINE_MAX_BYTES (round 5's 25 KB line came back unparsed); everything else -- per-fold
+# tables, notes, definitions, the other configs' full blocks -- goes to the detail file next to it.
+# ------------------------------------------------------------------------------------------------------------
+LINE_MAX_BYTES = 6144
+DETAIL_PATH = os.environ.get("PC_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+_PROSE_KEYS = ("note", "method", "definition", "kernels", "folds", "ms_calls", "per_round_ms", "loop_rates_per_s", "pass_phase_ms_sum")
+
+
+def _g(d, path, default=None):
+    for k in path.split("."):
+        if not isinstance(d, dict) or k not in d or d[k] is None:
+            return default
+        d = d[k]
+    return d
+
+
+def _num(v, sig=6):
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    if v == int(v) and abs(v) < 2 ** 53:          # byte and launch counts that travelled as floats stay exact
+        return int(v) if abs(v) >= 1e6 else v
+    return float(f"{v:.{sig}g}")
+
+
+def _slim(o, str_max=96):
+    """No prose, short strings, five significant digits: what is left of a block in the line."""
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if k in _PROSE_KEYS or k.endswith(("_note", "_definition", "_source", "_is", "_method")):
+                continue
+            out[k] = _slim(v, str_max)
+        return out
+    if isinstance(o, (list, tuple)):
+        return [_slim(v, str_max) for v in o]
+    if isinstance(o, str):
+        return o if len(o) <= str_max else o[:str_max - 3] + "..."
+    return _num(o)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _roofline_line(rf):
+    if not isinstance(rf, dict):
+        return None
+    out = _pick(rf, ("bound", "kernel", "kernel_ms", "launches", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch"))
+    ar = rf.get("arithmetic")
+    if isinstance(ar, dict):
+        out["arithmetic"] = _pick(ar, ("bound", "achieved", "peak", "frac", "unit"))
+    return _slim(out, 100)
+
+
+def _cpu_line(cb):
+    if not isinstance(cb, dict):
+        return None
+    out = _pick(cb, ("value", "unit", "cores", "kind", "sample", "logical_cpus", "agrees_with_gpu"))
+    if _g(cb, "per_core.value") is not None:
+        out["per_core_value"] = cb["per_core"]["value"]
+    return _slim(out, 120)
+
+
+def _ratio(a, b):
+    return None if not a or not b else a / b
+
+
+def _workload_line(name, w):
+    """{ms, roofline_frac, arithmetic_frac, cpu_ratio, parity_ok} (+ the two or three figures a reader of that config looks for)."""
+    if not isinstance(w, dict) or "error" in w:
+        return _slim(w)
+    if name == "latency":
+        rows = w.get("rows", {})
+        return {"ms": {k: _num(r.get("gpu_commit_open_ms"), 4) for k, r in rows.items()},
+                "cpu_port_ms": {k: _num(r["cpu_port_commit_open_ms"], 4) for k, r in rows.items() if "cpu_port_commit_open_ms" in r},
+                "parity_ok": all(r.get("parity_ok") for r in rows.values()) if rows else None,
+                "cpu_faster_up_to_log_degree": w.get("cpu_faster_up_to_log_degree")}
+    par = w.get("parity") or {}
+    flags = [v for k, v in par.items() if k.endswith("_ok")]
+    out = {"ms": w.get("open_ms") if name == "ipa" else w.get("ms_per_step"),
+           "roofline_frac": _g(w, "roofline.frac"), "arithmetic_frac": _g(w, "roofline.arithmetic.frac"),
+           "kernel_ms": _g(w, "roofline.kernel_ms"), "traffic": _g(w, "roofline.traffic"),
+           "cpu_ratio": _ratio(w.get("open_coeffs_per_s") if name == "ipa" else w.get("value"), _g(w, "cpu_baseline.value")),
+           "cpu_cores": _g(w, "cpu_baseline.cores"),
+           "parity_ok": all(bool(f) for f in flags) if flags else None}
+    if name == "ipa":
+        out.update(commit_ms=w.get("commit_ms"), open_arithmetic_frac=_g(w, "roofline_open.frac"),
+                   fixed_key_rounds_ms=_g(w, "roofline_open.fixed_key_rounds.ms_total"), msm_wait_ms=_g(w, "roofline_open.msm_wait_ms"))
+    if name == "ligero":
+        out.update(ntt_phase_ms=w.get("ntt_phase_ms"), column_hash_ms=w.get("column_hash_blake2s_ms"), tree_ms=w.get("merkle_tree_sha256_ms"),
+                   trait_shaped_ms=_g(w, "trait_shaped.ms_per_commit"))
+    if name == "batch":
+        out.update(trait_shaped_ms=_g(w, "trait_shaped.ms_per_step"), ms_per_commitment=w.get("ms_per_commitment"))
+    return _slim(out)
+
+
+def compact_line(obj):
+    """The driver's line: the contract's keys, compact `roofline` / `cpu_baseline` / `parity`, one short entry per extra workload."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: _num(obj[k]) if not isinstance(obj[k], str) else obj[k] for k in head if k in obj}
+    out["config"] = _slim(_pick(obj.get("config", {}), ("workload", "curve", "log_degree", "pairs_per_step", "inflight", "srs_window_table",
+                                                         "srs_window_table_build_ms", "parallelism", "polys_per_s", "mode")), 200)
+    for k in ("dist", "per_rank_ms_per_step", "commit_open_per_s", "value_trait_shaped", "value_h2d_inclusive", "blocking_msm_ms",
+              "exchange_host_ms", "msm_phase_ms", "ntt_phase_ms", "column_hash_blake2s_ms", "merkle_tree_sha256_ms", "ms_per_commitment",
+              "sharded_commit", "srs_window_table_build_ms"):
+        if obj.get(k) is not None:
+            out[k] = _slim(obj[k])
+    out["roofline"] = _roofline_line(obj.get("roofline"))
+    if obj.get("cpu_baseline") is not None:
+        out["cpu_baseline"] = _cpu_line(obj["cpu_baseline"])
+        out["gpu_over_cpu"] = _num(_ratio(obj.get("value"), _g(obj, "cpu_baseline.value")), 4)
+    out["parity"] = _slim({k: v for k, v in (obj.get("parity") or {}).items() if not isinstance(v, str) or len(v) < 40})
+    sec = obj.get("secondary")
+    if isinstance(sec, dict):
+        out["secondary"] = _slim({"log_degree": _g(sec, "config.log_degree"), "value": sec.get("value"), "ms_per_step": sec.get("ms_per_step"),
+                                  "steps": sec.get("steps"), "blocking_msm_ms": sec.get("blocking_msm_ms"),
+                                  "trait_shaped_ms": _g(sec, "trait_shaped.ms_per_commit_open"),
+                                  "roofline_frac": _g(sec, "roofline.frac"), "arithmetic_frac": _g(sec, "roofline.arithmetic.frac"),
+                                  "kernel_ms": _g(sec, "roofline.kernel_ms"),
+                                  "parity_ok": bool(_g(sec, "parity.commit_ok") and _g(sec, "parity.open_ok"))})
+    if isinstance(obj.get("workloads"), dict):
+        out["workloads"] = {n: _workload_line(n, w) for n, w in obj["workloads"].items()}
+    for k in ("bench_wall_s", "small_sizes"):
+        if k in obj:
+            out[k] = _num(obj[k], 4)
+    out["detail"] = os.path.relpath(DETAIL_PATH, ROOT) if DETAIL_PATH.startswith(ROOT) else DETAIL_PATH
+    # never above the cap: shed the optional blocks, least important first
+    for victim in ("msm_phase_ms", "exchange_host_ms", "value_h2d_inclusive", "secondary", "workloads", "dist", "sharded_commit", "config"):
+        if len(json.dumps(out)) <= LINE_MAX_BYTES:
+            break
+        out.pop(victim, None)
+    return out
+
+
 def emit(obj):
-    os.write(_RESULT_FD, (json.dumps(obj) + "\n").encode())
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(obj, f)
+    except OSError as e:
+        log(f"detail file not written ({e})")
+    if os.environ.get("PC_BENCH_FULL_LINE"):          # tools/gpu_full_run.sh, tools/gpu_probe.sh: the full record on stdout
+        os.write(_RESULT_FD, (json.dumps(obj) + "\n").encode())
+        return
+    line = json.dumps(compact_line(obj))
+    assert len(line) <= LINE_MAX_BYTES, len(line)
+    os.write(_RESULT_FD, (line + "\n").encode())
 
 
 def log(*a):
@@ -1182,6 +1330,7 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
     torch.cuda.empty_cache()
     return {"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: cm_commit MSM + open's {log_n} halving rounds (BASELINE configs[3])",
             "commit_ms": t_commit * 1e3, "open_ms": best * 1e3, "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / best,
+            "open_coeffs_per_s": n / best, "log_n": log_n,
             "open_breakdown_ms": {k: round(v, 2) for k, v in tm_best.items()}, "per_round_ms": [round(x, 2) for x in per_round],
             "roofline": msm_roofline(curve, n, shape_c["digits_per_scalar"], float(ph_c[3]), 1,
                                      "pc::k_accumulate<pallas> (bucket accumulation of the cm_commit MSM; the opening's 2 x 22 round MSMs run the same kernel "
@@ -1589,7 +1738,8 @@ def main():
             return (f"MarlinKZG10<{curve}> commit+open, dense poly deg 2^{lg} per GPU, true SRS resident, hiding off "
                     f"(BASELINE metric sizes: 2^20 = configs[1], 2^24 = north-star target)" + (" [--small test sizes]" if small else ""))
         out = {
-            "metric": "MSM G1-scalar-pairs/sec inside KZG commit+open (MarlinKZG10<Bls12_381> shape, hiding off)",
+            "metric": "MSM G1-scalar-pairs/sec inside KZG commit+open (MarlinKZG10<Bls12_381> shape, hiding off), inputs HBM-resident "
+                      "(host-input blocking calls: value_trait_shaped)",
             "value": prim["value"], "unit": "pairs/s", "n_gpus": world, "steps": prim["steps"], "warmup": prim["warmup"],
             "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer)", "data": "synthetic",
@@ -1608,6 +1758,11 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"SRS/coefficients of ONE polynomial of {world} x 2^{log_degree} coefficients sharded in "
                                                                  f"{world} contiguous chunks, one all_gather of partial points + division carries per step"},
             "commit_open_per_s": prim["commit_open_per_s"],
+            # what a caller of the trait gets: commit(&poly) + open(&poly) as two blocking calls on pageable host coefficients
+            "value_trait_shaped": None if not prim["trait_shaped"] else {
+                "value": prim["trait_shaped"]["value"], "unit": "pairs/s", "ms_per_step": prim["trait_shaped"]["ms_per_commit_open"],
+                "commit_ms": prim["trait_shaped"]["commit_ms"], "open_ms": prim["trait_shaped"]["open_ms"],
+                "parity_ok": prim["trait_shaped"]["parity_ok"], "coefficients": "pageable host memory, PCIe inside both calls"},
             "value_h2d_inclusive": prim["value_h2d_inclusive"],
             "trait_shaped": prim["trait_shaped"],
             "blocking_msm_ms": prim["blocking_msm_ms"],

@@ -71,3 +71,77 @@ def test_glv_split_reads_the_library_header():
             assert abs(k1) < 1 << 130 and abs(k2) < 1 << 130
             if curve in lam:
                 assert (k1 + k2 * lam[curve] - k) % r == 0
+
+
+# ---- the line the driver parses (round 5's 25 KB line came back with parsed = null) ----------------------------------------------
+def _recorded_lines():
+    import glob
+    import json
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[456]_*.json"))):
+        try:
+            d = json.load(open(f))
+        except ValueError:
+            continue
+        if isinstance(d, dict) and "metric" in d and "ms_per_step" in d:
+            yield os.path.basename(f), d
+
+
+def test_stdout_line_is_at_most_6144_bytes_and_keeps_the_contract():
+    """compact_line over every full record under profiles/ (the 25 KB round-5 line among them): <= 6 KB, the contract's keys, a
+    `roofline` with bound / achieved / peak / unit / frac / traffic and a `cpu_baseline` with value / unit / cores / kind / sample."""
+    import json
+    import bench
+    seen = 0
+    for name, d in _recorded_lines():
+        c = bench.compact_line(d)
+        line = json.dumps(c)
+        assert len(line) <= bench.LINE_MAX_BYTES == 6144, (name, len(line))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+            assert c[k] == d[k] or abs(c[k] - d[k]) <= 1e-5 * abs(d[k]), (name, k)
+        assert "workload" in c["config"]
+        if d.get("roofline"):
+            for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+                assert k in c["roofline"], (name, k)
+            assert abs(c["roofline"]["frac"] - d["roofline"]["frac"]) <= 1e-5 * d["roofline"]["frac"]
+            if "algorithmic_bytes_per_launch" in d["roofline"]:
+                assert c["roofline"]["algorithmic_bytes_per_launch"] == int(d["roofline"]["algorithmic_bytes_per_launch"])
+        if d.get("cpu_baseline"):
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in c["cpu_baseline"], (name, k)
+        if "workloads" in d:
+            assert set(c["workloads"]) == set(d["workloads"])
+            for n, w in c["workloads"].items():
+                assert "parity_ok" in w and "ms" in w, (name, n)
+        seen += 1
+    assert seen >= 8          # the recorded lines of rounds 4 and 5 are in the tree
+
+
+def test_stdout_line_sheds_blocks_rather_than_grow():
+    import json
+    import bench
+    fat = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "w" * 500},
+           "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 1.0 / 8000, "traffic": None, "kernel": "k" * 900},
+           "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 1, "kind": "port", "sample": "s" * 900},
+           "parity": {"commit_ok": True, "method": "x" * 4000},
+           "workloads": {f"w{i}": {"ms_per_step": 1.0, "parity": {"a_ok": True}, "roofline": {"frac": 0.1}, "junk": ["y" * 90] * 40} for i in range(64)},
+           "per_rank_ms_per_step": [1.0] * 8, "msm_phase_ms": {f"p{i}": 0.123456789 for i in range(200)}}
+    c = bench.compact_line(fat)
+    assert len(json.dumps(c)) <= 6144
+    assert c["roofline"]["frac"] == 1.0 / 8000 and c["cpu_baseline"]["kind"] == "port" and c["parity"] == {"commit_ok": True}
+    assert c["per_rank_ms_per_step"] == [1.0] * 8
+
+
+def test_emit_writes_the_detail_file_and_one_short_line(tmp_path, monkeypatch):
+    import json
+    import bench
+    rd, wr = os.pipe()
+    monkeypatch.setattr(bench, "_RESULT_FD", wr)
+    monkeypatch.setattr(bench, "DETAIL_PATH", str(tmp_path / "detail.json"))
+    name, d = next(x for x in _recorded_lines() if x[0] == "r05_bench_n1.json")
+    bench.emit(d)
+    os.close(wr)
+    out = os.read(rd, 1 << 16).decode()
+    assert out.count("\n") == 1 and len(out) <= 6145
+    assert json.loads(out)["detail"] == str(tmp_path / "detail.json")
+    assert json.load(open(tmp_path / "detail.json")) == d

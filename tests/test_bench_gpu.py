@@ -13,15 +13,43 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_MAX = 6144          # bench.LINE_MAX_BYTES: the driver keeps a bounded tail of stdout (round 5's 25 KB line came back unparsed)
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "parity", "detail")
+
+
+def _check_line(line):
+    """The stdout line itself: short, and carrying what the contract asks of it."""
+    assert len(line) <= LINE_MAX, f"stdout line is {len(line)} bytes"
+    c = json.loads(line)
+    for k in _LINE_KEYS:
+        assert k in c, k
+    assert "workload" in c["config"]
+    if c["roofline"] is not None:
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in c["roofline"], k
+    return c
+
+
+def _detail(tmp, line):
+    """The full record the line points at (what the assertions below read), with the line under `_line`."""
+    d = json.load(open(tmp))
+    d["_line"] = line
+    return d
+
+
 def run_bench(argv, env_extra=None, timeout=900):
+    import tempfile
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, f"expected ONE line on stdout, got {len(lines)}"
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        env["PC_BENCH_DETAIL"] = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout)
+        assert r.returncode == 0, r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, f"expected ONE line on stdout, got {len(lines)}"
+        return _detail(env["PC_BENCH_DETAIL"], _check_line(lines[0]))
 
 
 def test_default_line_small():
@@ -42,6 +70,18 @@ def test_default_line_small():
     assert w["ipa"]["parity"]["commit_ok"] and w["ipa"]["parity"]["final_comm_key_ok"]
     assert w["ligero"]["parity"]["horner_spot_checks_ok"] and w["ligero"]["parity"]["one_row_vs_oracle_ntt_ok"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    # the line the driver parses carries the same figures in short form
+    c = d["_line"]
+    assert c["value"] == pytest.approx(d["value"], rel=1e-4) and c["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-4)
+    assert c["roofline"]["frac"] == pytest.approx(rf["frac"], rel=1e-4) and c["roofline"]["arithmetic"]["frac"] > 0
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert c["value_trait_shaped"]["ms_per_step"] == pytest.approx(d["trait_shaped"]["ms_per_commit_open"], rel=1e-4)
+    assert set(c["workloads"]) == {"latency", "batch", "ipa", "ligero"}
+    for name in ("batch", "ipa", "ligero"):
+        wl = c["workloads"][name]
+        assert wl["parity_ok"] is True and wl["ms"] > 0 and wl["roofline_frac"] > 0 and wl["arithmetic_frac"] > 0 and wl["cpu_ratio"] > 0, (name, wl)
+    assert c["workloads"]["latency"]["parity_ok"] is True and c["secondary"]["parity_ok"] is True
 
 
 def test_two_ranks_self_launched_kzg():
@@ -78,11 +118,11 @@ def test_group_mode_one_process():
     assert d["n_gpus"] == 1 and d["parity"]["all_steps_ok"]
 
 
-def test_two_ranks_started_by_torchrun_as_the_driver_does():
+def test_two_ranks_started_by_torchrun_as_the_driver_does(tmp_path):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`:
     the command line of the driver's scaling runs (the ranks come from the environment, nothing is self-launched): one JSON line
     from rank 0, weak scaling, both ranks' chunks in the parity check."""
-    env = dict(os.environ, PC_BENCH_DEVICES="0,0")
+    env = dict(os.environ, PC_BENCH_DEVICES="0,0", PC_BENCH_DETAIL=str(tmp_path / "detail.json"))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -92,7 +132,8 @@ def test_two_ranks_started_by_torchrun_as_the_driver_does():
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = _detail(env["PC_BENCH_DETAIL"], _check_line(lines[0]))
+    assert d["_line"]["n_gpus"] == 2 and len(d["_line"]["per_rank_ms_per_step"]) == 2
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dist"]["world_size"] == 2
     assert d["parity"]["commit_ok"] and d["parity"]["open_ok"] and d["parity"]["commitments_checked"] == 3
 
@@ -101,11 +142,11 @@ def test_two_ranks_started_by_torchrun_as_the_driver_does():
 EIGHT = {"PC_BENCH_DEVICES": ",".join(["0"] * 8)}
 
 
-def test_eight_ranks_started_by_torchrun_as_the_driver_does():
+def test_eight_ranks_started_by_torchrun_as_the_driver_does(tmp_path):
     """The driver's N = 8 command line, all eight ranks on device 0 (gloo carries the collective: RCCL refuses ranks that share a
     device): ONE polynomial of 8 x 2^13 coefficients over eight real chunks of one true SRS, every commitment / proof of the timed
     region against the closed form of the WHOLE polynomial; the line carries what the N = 1 line carries."""
-    env = dict(os.environ, **EIGHT)
+    env = dict(os.environ, PC_BENCH_DETAIL=str(tmp_path / "detail.json"), **EIGHT)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
@@ -114,7 +155,10 @@ def test_eight_ranks_started_by_torchrun_as_the_driver_does():
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = _detail(env["PC_BENCH_DETAIL"], _check_line(lines[0]))
+    c = d["_line"]          # the N > 1 line obeys the same cap and carries roofline + per-rank ms_per_step
+    assert c["n_gpus"] == 8 and len(c["per_rank_ms_per_step"]) == 8 and c["roofline"]["frac"] > 0 and c["roofline"]["arithmetic"]["frac"] > 0
+    assert c["parity"]["commit_ok"] and c["parity"]["open_ok"] and c["exchange_host_ms"]["calls"] >= 3
     assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "weak" and d["dist"]["world_size"] == 8
     assert len(d["per_rank_ms_per_step"]) == 8 and all(x > 0 for x in d["per_rank_ms_per_step"])
     assert d["config"]["pairs_per_step"] == 8 * 2 * (1 << 13) - 1

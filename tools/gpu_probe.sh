@@ -24,6 +24,7 @@ set -x
 TAG=${1:-probe}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R; mkdir -p gpurun_out
+export PC_BENCH_FULL_LINE=1          # full records on stdout (the driver's run gets the short line + bench_detail.json)
 make -s -C oracle
 for kv in $ENVS; do export "$kv"; done
 VARIANTS=${VARIANTS:-default}
