@@ -382,7 +382,18 @@ def oracle_scalar_mul(curve, g_xy, k):
     return O.msm_naive(curve, np.ascontiguousarray(g_xy).reshape(1, -1), np.ascontiguousarray(sc))
 
 
-_PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
+_PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
+
+
+def checked_traffic(traffic, algorithmic_bytes):
+    """Counter traffic of a launch can exceed its algorithmic bytes (re-reads), never undercut them: a figure below means the PMC summary
+    averaged launches of another size into this one (round 5's NTT block did) -- refuse it rather than print it."""
+    if traffic is None or algorithmic_bytes is None:
+        return traffic
+    if traffic < 0.98 * algorithmic_bytes:
+        log(f"PMC traffic {traffic:.3e} B is below the algorithmic {algorithmic_bytes:.3e} B of the launch: refused (traffic = null)")
+        return None
+    return traffic
 
 
 def pmc_traffic(key, field="accumulate_hbm_bytes_per_launch"):
@@ -393,13 +404,19 @@ def pmc_traffic(key, field="accumulate_hbm_bytes_per_launch"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name))).get(field, {}).get(key)
             if v is not None:
+                _PMC_HIT[0] = "profiles/" + name
                 return v
         except Exception:
             pass
     return None
 
 
+_PMC_HIT = [None]
+
+
 def pmc_source():
+    if _PMC_HIT[0]:
+        return _PMC_HIT[0]
     for name in _PMC_FILES:
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             return "profiles/" + name
@@ -522,7 +539,7 @@ def msm_roofline(curve, pairs_per_launch, digits, kernel_ms, launches, kernel, t
     pk = madd_peak(curve)
     adds = pairs_per_launch * digits
     r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS if ach else None,
-         "traffic": pmc_traffic(traffic_key) if traffic_key else None,
+         "traffic": checked_traffic(pmc_traffic(traffic_key), bytes_per_launch) if traffic_key else None,
          "traffic_source": f"{pmc_source()} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE doubled per "
                            "the guide's gfx950 note; not measured in this run)",
          "kernel": kernel, "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -1502,7 +1519,7 @@ def ligero_case(ctx, D, curve, log_len, steps, warmup, with_cpu=True, with_trait
             "column_hash_blake2s_ms": hash_ms, "merkle_tree_sha256_ms": merkle_ms, "sharded_commit": chain, "trait_shaped": trait,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS if achieved else None,
-                         "traffic": pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch") if world == 1 else None,
+                         "traffic": checked_traffic(pmc_traffic(f"ntt:{curve}:2^{log_len}", "ntt_hbm_bytes_per_batch"), alg_bytes) if world == 1 else None,
                          "traffic_source": f"{pmc_source()} (separate rocprofv3 --pmc passes of this workload; not measured in this run)",
                          "kernel": "pc::k_ntt_pass_a + pc::k_ntt_pass_b (one batched NTT = both), hipEvent brackets on the context's stream inside the timed region",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes, "arithmetic": arith},
@@ -1650,7 +1667,8 @@ def main():
     t_start = time.perf_counter()
 
     if args.workload == "ntt":
-        r = ligero_case(ctx, D, curve, 16 if small else 24, args.steps or (5 if small else 100), args.warmup, with_cpu=not args.no_cpu_baseline)
+        r = ligero_case(ctx, D, curve, 16 if small else 24, args.steps or (5 if small else 100), args.warmup, with_cpu=not args.no_cpu_baseline,
+                        with_trait=not args.no_trait)
         if rank == 0:
             emit({"metric": "Ligero Reed-Solomon NTT input coefficients/sec (LigeroPCS over BLS12-381 Fr, 2^24 coeffs)",
                   "value": r["value"], "unit": "coeffs/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,

@@ -35,7 +35,7 @@ timeout -k 10 300 python tools/ligero_stream_probe.py --cold 2>/dev/null | grep 
 cd /tmp && export TMPDIR=/tmp
 B24="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-trait --inflight 0 --secondary-log-degree 0 --workloads none"
 B20="python $R/bench.py --log-degree 20 --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-trait --inflight 0 --secondary-log-degree 0 --workloads none"
-NTT="python $R/bench.py --workload ntt --steps 3 --warmup 1"
+NTT="python $R/bench.py --workload ntt --steps 3 --warmup 1 --no-trait --no-cpu-baseline"   # config 5 ALONE: no slab launches of the host-to-host leg in the per-kernel averages
 BATCH="python $R/bench.py --workload batch --steps 2 --warmup 1"
 PAL="python $R/tools/msm_one.py pallas 22 6"
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"

@@ -15,14 +15,27 @@ from collections import defaultdict
 
 
 def per_kernel(path, counter):
-    acc = defaultdict(lambda: defaultdict(float))      # kernel -> dispatch id -> value (summed over XCDs/SEs)
+    """kernel -> {launches, avg_per_launch_KiB} over the launches of the kernel's LARGEST launch geometry only.
+
+    A profiled process also launches the same kernel on other sizes (the row slabs of the host-to-host Ligero calls, the parity
+    checks' single rows, half-size parts of a host MSM): averaging those in made round 5's NTT figure 13x too small.  Launches are
+    classed by (Grid_Size, Workgroup_Size); the class with the largest grid is the workload's own launch."""
+    acc = defaultdict(lambda: defaultdict(float))      # (kernel, geometry) -> dispatch id -> value (summed over XCDs/SEs)
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
             name = re.sub(r"\(.*$", "", r["Kernel_Name"]).strip()
-            acc[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    return {k: {"launches": len(v), "avg_per_launch_KiB": sum(v.values()) / len(v)} for k, v in acc.items()}
+            geom = (int(float(r.get("Grid_Size") or 0)), int(float(r.get("Workgroup_Size") or 0)))
+            acc[(name, geom)][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    out = {}
+    for (name, geom), v in acc.items():
+        if name in out and out[name]["grid_size"] >= geom[0]:
+            continue
+        out[name] = {"launches": len(v), "avg_per_launch_KiB": sum(v.values()) / len(v), "grid_size": geom[0], "workgroup_size": geom[1]}
+    for name in out:
+        out[name]["launches_all_geometries"] = sum(len(v) for (n, _), v in acc.items() if n == name)
+    return out
 
 
 def main():
