@@ -215,9 +215,22 @@ int pc_hip_init(int device_id, pc_ctx** out) {
   return PC_OK;
 }
 
+static void srs_release_device(pc_srs* srs);
 void pc_hip_shutdown(pc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  {
+    // Keys that outlive their context (Drop order of an Arc<ResidentKey> against the context, a Python object collected late): their
+    // device memory and pipelines go now, the host object stays behind as a tombstone (ctx = nullptr) that a later pc_hip_srs_free
+    // only deletes -- it must never lock a mutex inside the context deleted below.  Cached working keys are held by nobody: deleted.
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    std::vector<pc_srs*> alive = ctx->keys, cached;
+    for (pc_srs* s : alive) if (s->work_cache) { cached.push_back(s->work_cache); s->work_cache = nullptr; }
+    for (pc_srs* s : alive) { s->parent = nullptr; s->work_out = nullptr; }
+    for (pc_srs* s : alive) { srs_release_device(s); s->ctx = nullptr; }
+    for (pc_srs* s : cached) delete s;
+    ctx->keys.clear();
+  }
   ctx->ntt_plans.clear();
   if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
   for (hipStream_t q : ctx->lig_out_q) if (q) (void)hipStreamDestroy(q);
@@ -387,7 +400,7 @@ int pc_hip_universal_params_layout(pc_curve curve, const void* bytes, size_t n_b
 // Every path mutates shared context state (ctx->keys, the backend's byte ledger, a parent's work cache) and is reached from arbitrary
 // threads (Drop of the last Arc<ResidentKey>, device::release, the LRU eviction of the Rust shim) while other threads may be inside
 // pc_hip_srs_upload / pc_hip_ctx_trim / any alloc: the context lock is held for the whole call (recursive: pc_hip_ctx_trim and the
-// work-cache recursion below re-enter).  The mutex lives in the context, which outlives its keys (pc_hip_shutdown frees them first).
+// work-cache recursion below re-enter).  The mutex lives in the context; pc_hip_shutdown releases every key still alive and leaves it with ctx == nullptr, so a key freed after its context never touches that mutex.
 static void srs_free_locked(pc_srs* srs);
 void pc_hip_srs_free(pc_srs* srs) {
   if (!srs) return;
@@ -405,22 +418,29 @@ static void srs_free_locked(pc_srs* srs) {
   }
   if (srs->work_cache) { srs->work_cache->parent = nullptr; srs_free_locked(srs->work_cache); srs->work_cache = nullptr; }
   if (srs->work_out) { srs->work_out->parent = nullptr; srs->work_out = nullptr; }      // still held by the caller: it frees it
-  if (srs->ctx) (void)hipSetDevice(srs->ctx->device);
+  srs_release_device(srs);
+  delete srs;
+}
+// everything a key holds on the device and in its context's books; the host object is left empty (a key whose context was shut down
+// under it has ctx == nullptr and nothing left to release)
+static void srs_release_device(pc_srs* srs) {
+  if (!srs->ctx) return;
+  (void)hipSetDevice(srs->ctx->device);
   for (int i = 0; i < PC_MSM_LANES; i++) {
     if (srs->lanes[i] && srs->lanes[i]->inflight) {   // abandon: let the stream drain, mark the job failed
       (void)hipStreamSynchronize(srs->lanes[i]->be.stream);
       if (srs->lanes[i]->be.tail_stream) (void)hipStreamSynchronize(srs->lanes[i]->be.tail_stream);
       srs->lanes[i]->inflight->done = true; srs->lanes[i]->inflight->status = PC_ERR_INVALID_ARG;
     }
-    delete srs->lanes[i];
+    delete srs->lanes[i]; srs->lanes[i] = nullptr;
   }
-  if (srs->ctx) { auto& ks = srs->ctx->keys; ks.erase(std::remove(ks.begin(), ks.end(), srs), ks.end()); }
+  { auto& ks = srs->ctx->keys; ks.erase(std::remove(ks.begin(), ks.end(), srs), ks.end()); }
   if (srs->bases) srs->ctx->be.free(srs->bases);
   if (srs->fold_tbl) srs->ctx->be.free(srs->fold_tbl);
   drop_batch_many(srs);
   if (srs->table) srs->ctx->be.free(srs->table);
   drop_many(srs);
-  delete srs;
+  srs->bases = srs->fold_tbl = srs->table = nullptr; srs->n = 0;
 }
 // windows of the key's table: the 255-bit scalar's, or those of its 130-bit GLV halves
 static uint32_t table_windows(const pc_srs* srs, uint32_t c, bool glv) {
@@ -651,6 +671,11 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
         const uint32_t sets = srs->cfg.tbl_glv ? 2u : 1u;
         const uint32_t Wd = sets * table_windows(srs, srs->cfg.tbl_c, srs->cfg.tbl_glv);      // digits per scalar
         while (G >= 2 && ((uint64_t)G * m * Wd >= (1ull << 32) || ((uint64_t)G * sets << (srs->cfg.tbl_c - 1)) >= (1ull << 31))) G /= 2;
+        // HOST polynomials are staged on the device, G of them per pipeline: that copy has a budget (BATCH_STAGE_MAX per pipeline; 8 x
+        // 2^24 coefficients would be 2 x 4 GiB beside the passes' own workspace).  G shrinks to fit; below two polynomials per pass
+        // the call takes the per-polynomial pipeline further down, which stages one polynomial at a time.
+        static const size_t BATCH_STAGE_MAX = []() { const char* e = getenv("PC_HIP_BATCH_STAGE_MAX_MB"); long v = e ? atol(e) : 1024; return (size_t)(v < 0 ? 0 : v) << 20; }();
+        if (where == PC_MEM_HOST) while (G >= 2 && (uint64_t)G * m * 32 > BATCH_STAGE_MAX) G /= 2;
         if (G >= 2) {
           pc_srs::BatchMany& B = srs->bm;
           if (B.m != m || B.G != G) {
@@ -663,6 +688,20 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
             }
             B.m = m; B.G = G;
           }
+          // both staging buffers before any pass is queued: when the device cannot give them, nothing is in flight yet and the
+          // call goes on through the per-polynomial pipeline instead of failing (host inputs took that road before this path existed)
+          bool staged_ok = true;
+          if (where == PC_MEM_HOST)
+            for (int i = 0; i < 2 && staged_ok; i++)
+              if (!B.stage[i]) {
+                try { B.stage[i] = (uint32_t*)B.lanes[i]->be.alloc(G * m * 32); }
+                catch (const std::exception&) {
+                  staged_ok = false;
+                  (void)hipGetLastError();
+                  for (int j = 0; j < 2; j++) if (B.stage[j]) { B.lanes[j]->be.free(B.stage[j]); B.stage[j] = nullptr; }
+                }
+              }
+          if (staged_ok) {
           for (int i = 0; i < PC_MSM_LANES; i++)       // nothing of the single-MSM pipelines may be in flight on this key's outputs
             if (srs->lanes[i] && srs->lanes[i]->inflight) complete_job(ctx, srs->lanes[i]->inflight);
           const size_t pb = (size_t)srs->aw * 4;
@@ -694,7 +733,6 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
             std::vector<uint64_t> ptrs(cnt);
             if (where == PC_MEM_HOST) {
               pc::HipBackend& lbe = B.lanes[li]->be;
-              if (!B.stage[li]) B.stage[li] = (uint32_t*)lbe.alloc(G * m * 32);
               for (size_t k = 0; k < cnt; k++) {
                 uint32_t* dst = B.stage[li] + k * m * 8;
                 lbe.copy_h2d(dst, scalars[first + k], m * 32);
@@ -715,7 +753,12 @@ int pc_hip_msm_batch(pc_ctx* ctx, const pc_srs* srs_c, const size_t* base_offset
             for (int i = 0; i < 8; i++) ctx->phases[i] = ph_sum[i];
             B.lanes[0]->runner->shape(ctx->shape);
           }
+          // staging above the keep threshold is transient, as the single-call buffers are (CallBuf / STAGE_KEEP)
+          static constexpr size_t BATCH_STAGE_KEEP = (size_t)256 << 20;
+          if (where == PC_MEM_HOST && G * m * 32 > BATCH_STAGE_KEEP)
+            for (int i = 0; i < 2; i++) if (B.stage[i]) { B.lanes[i]->be.free(B.stage[i]); B.stage[i] = nullptr; }
           return (int)PC_OK;
+          }      // staged_ok
         }
       }
     }
@@ -843,7 +886,7 @@ int pc_hip_ctx_trim(pc_ctx* ctx) {
     // idle pipelines give their sort / scan scratch back (the plan's own workspace stays: it is what makes the next call cheap)
     for (pc_srs* s : ctx->keys)
       for (int i = 0; i < PC_MSM_LANES; i++)
-        if (s->lanes[i] && !s->lanes[i]->inflight) { s->lanes[i]->be.sync(); s->lanes[i]->be.trim(); }
+        if (s->lanes[i] && !s->lanes[i]->inflight) { s->lanes[i]->be.sync(); s->lanes[i]->be.trim(); if (s->lanes[i]->runner) s->lanes[i]->runner->trim(); }
     // the staging copies of HOST polynomials in the batch pipelines (pc_hip_msm_batch: 2 x 8 polynomials)
     for (pc_srs* s : ctx->keys)
       for (int i = 0; i < 2; i++)

@@ -119,6 +119,7 @@ struct MsmRunnerT : MsmRunner {
     const MsmGeom& g = plan.last_geom();
     out[0] = g.c; out[1] = g.Wd; out[2] = g.NB; out[3] = g.tbl_stride ? 1u : 0u;
   }
+  void trim() override { plan.trim(); }
 };
 
 template <class C>

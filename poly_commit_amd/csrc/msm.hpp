@@ -846,6 +846,15 @@ class MsmPlan {
     result_host_ = nullptr;
   }
 
+  // What a host call in parts added on first use (second sort output, offsets, bucket array: ~1.2 GB on a 2^24 BLS12-381 key) goes back;
+  // begin_parts re-creates it.  Only on an idle plan (the caller synchronised the pipeline).
+  void trim() {
+    if (in_parts_) return;
+    void* ps[] = {entries2_, offsets2_, buckets2_, hist2_, cursor2_};
+    entries2_ = offsets2_ = buckets2_ = hist2_ = cursor2_ = nullptr;
+    for (void* p : ps) be_.free(p);
+  }
+
   const MsmGeom& geom() const { return g_; }
   uint32_t* scalar_staging() { return scalars_; }
   const MsmGeom& last_geom() const { return g_; }

@@ -28,6 +28,7 @@ struct MsmRunner {
   virtual void finish(uint32_t* out_host) = 0;
   // geometry of the last enqueue: {window bits c, signed digits per scalar, buckets, 1 if the window table was used}
   virtual void shape(uint32_t out[4]) const = 0;
+  virtual void trim() = 0;          // give back what can be rebuilt on demand (idle pipeline only)
 };
 
 struct NttRunner {

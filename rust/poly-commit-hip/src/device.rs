@@ -287,13 +287,13 @@ pub fn poly_cache_bytes() -> usize {
     *V.get_or_init(|| env_usize("PC_HIP_POLY_CACHE_MB", 0) << 20)
 }
 
-/// The device copy of `coeffs`: found by address, length and fingerprint, else uploaded and remembered (LRU, bounded by
-/// `PC_HIP_POLY_CACHE_MB`).  With the cache on, `commit` calls this and `open` of the same polynomial sends nothing over PCIe.
 /// true iff the opt-in polynomial cache is on (`PC_HIP_POLY_CACHE_MB` > 0)
 pub fn poly_cache_enabled() -> bool {
     poly_cache_bytes() > 0
 }
 
+/// The device copy of `coeffs`: found by address, length and fingerprint, else uploaded and remembered (LRU, bounded by
+/// `PC_HIP_POLY_CACHE_MB`).  With the cache on, `commit` calls this and `open` of the same polynomial sends nothing over PCIe.
 pub fn device_poly<F: HipField>(coeffs: &[F]) -> Result<Arc<DevicePoly>, Error> {
     let cap = poly_cache_bytes();
     if cap == 0 || coeffs.is_empty() {

@@ -114,6 +114,10 @@ where
     G::ScalarField: HipField,
     G::Group: VariableBaseMSM<MulBase = G>,
 {
+    // a safe fn must not let the C side read past a slice: every polynomial holds n coefficients, the key n bases
+    if polys.iter().any(|p| p.len() < n) || bases.len() < n {
+        return Err(Error::IncorrectInputLength(format!("msm_batch_host: {} coefficients per polynomial asked of shorter inputs", n)));
+    }
     if !<G::ScalarField as HipField>::layout_is_abi() {
         // (an Fp layout other than 4 little-endian u64 limbs: repack through device copies, the path above)
         let devs = polys.iter().map(|p| device::device_poly(&p[..n])).collect::<Result<Vec<_>, _>>()?;

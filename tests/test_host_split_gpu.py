@@ -1,5 +1,5 @@
 """pc_hip_msm with HOST scalars and pc_hip_kzg_open with HOST coefficients run large inputs in parts (the PCIe copy and the sort of a part
-under the accumulation of the one before; abi.hip host_split_min, default 2^23 pairs; host_parts, default 4).  The split is forced down to 2^10 here
+under the accumulation of the one before; abi.hip host_split_min, default 2^21 pairs (PC_HIP_HOST_SPLIT_LOG2); host_parts, default 4).  The split is forced down to 2^10 here
 (PC_HIP_HOST_SPLIT_LOG2, read once per process: hence the subprocess) and compared with the oracle's kzg_commit / kzg_open
 (kzg10/mod.rs:157-210, :287-310) bit for bit; the unsplit paths of the same calls run in the same child."""
 import os

@@ -72,3 +72,92 @@ print("fold bytes", before)
     assert r.returncode == 0 and "refused" in r.stdout and "fold bytes 0" in r.stdout, r.stdout + r.stderr[-2000:]
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "built" in r.stdout and "fold bytes %d" % (131 * (1 << 11) * 64) in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def _child(code, env=None, timeout=600):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = "import sys, os\nROOT = %r\nsys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')]\n" % root
+    return subprocess.run([sys.executable, "-c", pre + code], env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
+
+
+def test_key_freed_after_its_context_was_shut_down():
+    """pc_hip_shutdown releases what the keys still alive hold and leaves them as tombstones: a key dropped AFTER its context (Rust Drop
+    order of an Arc<ResidentKey>) must not touch the deleted context (advisor, round 5)."""
+    r = _child(r'''
+import ctypes as C
+import numpy as np
+import oracle_lib as O
+import poly_commit_amd as pc
+from poly_commit_amd import _ffi
+lib = _ffi.load_library()
+ctx = pc.Context(0)
+srs = ctx.upload_srs("bn254", O.gen_bases("bn254", 1 << 12))
+srs.precompute(min_pairs=1)
+sc = O.gen_scalars("bn254", 3, 1 << 12)
+assert (srs.msm(sc)[0] == O.msm_pippenger("bn254", O.gen_bases("bn254", 1 << 12), sc, 8, 1)).all()
+h, k = ctx.h, srs.h
+lib.pc_hip_shutdown(h)          # the context goes first ...
+lib.pc_hip_srs_free(k)          # ... the key after it
+ctx.h = None; srs.h = None
+ctx2 = pc.Context(0)            # and the device is as usable as before
+srs2 = ctx2.upload_srs("bn254", O.gen_bases("bn254", 64))
+assert (srs2.msm(sc[:64])[0] == O.msm_naive("bn254", O.gen_bases("bn254", 64), sc[:64])).all()
+print("ok")
+''')
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_trim_gives_back_the_second_buffers_of_host_calls_in_parts():
+    """A blocking MSM on HOST scalars above the split size allocates a second sort output and bucket array on its pipeline
+    (MsmPlan::begin_parts); pc_hip_ctx_trim releases them (advisor, round 5) and the next host call brings them back."""
+    r = _child(r'''
+import numpy as np
+import oracle_lib as O
+import poly_commit_amd as pc
+ctx = pc.Context(0)
+n = 1 << 13
+powers = O.gen_bases("bls12_381", n)
+srs = ctx.upload_srs("bls12_381", powers)
+sc = O.gen_scalars("bls12_381", 9, n)
+want = O.msm_pippenger("bls12_381", powers, sc, 8, 1)
+assert (srs.msm(sc)[0] == want).all()
+a = srs.bytes_resident()["pipelines"]
+ctx.trim()
+b = srs.bytes_resident()["pipelines"]
+assert b < a, (a, b)
+assert (srs.msm(sc)[0] == want).all()
+assert srs.bytes_resident()["pipelines"] == a
+print("ok", a, b)
+''', env={"PC_HIP_HOST_SPLIT_LOG2": "10"})
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("budget_mb", ["1", "0"])
+def test_host_batch_staging_budget(budget_mb):
+    """pc_hip_msm_batch on HOST polynomials stages G polynomials per pipeline on the device: with a budget too small for 8 (or for
+    2: the per-polynomial pipeline) the call gives the same commitments and keeps at most the budget resident (advisor, round 5)."""
+    r = _child(r'''
+import numpy as np
+import oracle_lib as O
+import poly_commit_amd as pc
+ctx = pc.Context(0)
+curve, m, k = "bn254", 1 << 14, 10
+powers = O.gen_bases(curve, m)
+srs = ctx.upload_srs(curve, powers)
+srs.precompute(min_pairs=1)
+polys = [O.f_to_mont(curve, 1, O.gen_scalars(curve, 40 + j, m)) for j in range(k)]
+base = ctx.bytes_resident()["device_total"]
+out = srs.msm_batch(polys, [m] * k, montgomery=True, host=True)
+for j in (0, 3, 9):
+    assert (out[j] == O.msm_pippenger(curve, powers, O.f_from_mont(curve, 1, polys[j]), 8, 1)).all(), j
+budget = int(os.environ["PC_HIP_BATCH_STAGE_MAX_MB"]) << 20
+G = 8
+while G >= 2 and G * m * 32 > budget: G //= 2
+grown = ctx.bytes_resident()["device_total"] - base
+print("ok G", G, grown)
+''', env={"PC_HIP_BATCH_STAGE_MAX_MB": budget_mb})
+    assert r.returncode == 0 and "ok G" in r.stdout, r.stdout + r.stderr[-3000:]
+    assert ("ok G 2" if budget_mb == "1" else "ok G 1") in r.stdout
