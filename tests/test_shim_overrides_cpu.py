@@ -42,3 +42,11 @@ def test_shim_overrides_every_method_the_reference_type_overrides(ref_file, ref_
     assert {"setup", "trim", "commit", "open", "check"} <= ref, ref          # the parser found the impl block
     missing = ref - shim
     assert not missing, f"{shim_type} inherits the trait's default for {sorted(missing)}; {ref_type} overrides them"
+
+
+def test_rust_sources_pass_the_syntactic_lint():
+    """tools/rust_lint.py over both crates (details and the planted-mistake checks: tests/test_rust_lint_cpu.py)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rust_lint.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
