@@ -65,7 +65,7 @@ def test_lint_finds_an_unbalanced_brace_and_a_bad_path(tmp_path):
 
 
 def test_lint_finds_a_path_to_nothing(tmp_path):
-    findings = _mutated(tmp_path, "src/marlin_kzg10.rs", "use crate::kzg10_hip::{", "use crate::kzg10_hipp::{", 1)
+    findings = _mutated(tmp_path, "src/marlin_kzg10.rs", "use crate::curve::{", "use crate::curvee::{", 1)
     assert any("no module or item" in f for f in findings), findings[:5]
-    findings = _mutated(tmp_path / "b", "src/marlin_kzg10.rs", "use crate::device;", "use crate::device::not_there;", 1)
+    findings = _mutated(tmp_path / "b", "src/marlin_kzg10.rs", "use crate::device::{self, check,", "use crate::device::{self, not_there, check,", 1)
     assert any("is not defined in" in f for f in findings), findings[:5]
