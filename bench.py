@@ -1225,12 +1225,27 @@ def glv_split(gc, k):
     return k - c1 * a1 - c2 * a2, -c1 * b1 - c2 * b2
 
 
-def ipa_open_roofline(curve, log_n, challenges_mont, fold_rounds, per_round_ms, breakdown_ms, open_ms):
+def _wnaf_weight_and_top(v, w):
+    """Non-zero digits and the position of the highest one in the width-w NAF of v (csrc/glv.hpp wnaf_digits)."""
+    weight, top, bit = 0, 0, 0
+    while v:
+        if v & 1:
+            d = v & ((1 << w) - 1)
+            if d >= 1 << (w - 1):
+                d -= 1 << w
+            v -= d
+            weight, top = weight + 1, bit
+        v >>= 1
+        bit += 1
+    return weight, top
+
+
+def ipa_open_roofline(curve, log_n, challenges_mont, fold_rounds, per_round_ms, breakdown_ms, open_ms, fold_kinds=None, naf_w=2):
     """Places InnerProductArgPC::open (ipa_pc/mod.rs:664-711) against ceilings.  Its largest part is the key fold k_l += u k_r: the first
     fold from the committer key's fold table (EcFoldTableBody: one XYZZ mixed addition per non-zero NAF digit of the GLV halves of u,
     plus one base-field product for the phi half), the next ones by the shared GLV ladder (EcFoldGlvBody: Jacobian doublings and
     Jacobian += affine).  Each fold's ceiling = elements x (operations / the memory-free loop rate of that operation, tools/microbench);
-    the blocking wall time of the fold call is set against it.  The rounds on the fixed key (n <= 2^17) are latency-bound: their
+    the blocking wall time of the fold call is set against it.  The rounds on the fixed key (n <= 2^16) are latency-bound: their
     floor is stated, not priced."""
     try:
         gc = glv_header_constants(curve)
@@ -1241,21 +1256,33 @@ def ipa_open_roofline(curve, log_n, challenges_mont, fold_rounds, per_round_ms, 
     ja, _ = micro_rate("jac_madd", curve)
     fm, _ = micro_rate("fmul", f"{curve}_fq")
     folds, tot_ms, tot_ceiling, madd_eq = [], 0.0, 0.0, 0.0
+    r_mod = fr_modulus(curve)
+    kinds = fold_kinds or (["table1"] + ["ladder"] * (len(fold_rounds) - 1))
     for i, (h, ms) in enumerate(fold_rounds):
         u = from_mont_limbs(curve, challenges_mont[i])
-        k1, k2 = glv_split(gc, u)
-        (w1, t1), (w2, t2) = _naf_weight_and_top(abs(k1)), _naf_weight_and_top(abs(k2))
-        table = i == 0
-        if table:
+        kind = kinds[i] if i < len(kinds) else "ladder"
+        if kind == "deferred":          # two-level table: round 1 leaves the key alone, round 2 folds twice in one step
+            continue
+        if kind in ("table1", "table2"):
+            # one XYZZ mixed addition per non-zero width-w NAF digit of the GLV halves of every term's scalar, one base-field product per
+            # digit of the phi half; table2: three terms (u2, u1, u1 u2) over the quarters of the committer key
+            scal = [u] if kind == "table1" else [u, from_mont_limbs(curve, challenges_mont[i - 1]), u * from_mont_limbs(curve, challenges_mont[i - 1]) % r_mod]
+            w1 = w2 = 0
+            for sc in scal:
+                k1, k2 = glv_split(gc, sc)
+                w1 += _wnaf_weight_and_top(abs(k1), naf_w)[0]
+                w2 += _wnaf_weight_and_top(abs(k2), naf_w)[0]
             ceil_s = h * ((w1 + w2) / madd + (w2 / fm if fm else 0.0))
-            ops = {"xyzz_mixed_additions": w1 + w2, "phi_products": w2}
-            kern = "pc::EcFoldTableBody<pallas> + XyzzBatchAffineBody"
+            ops = {"xyzz_mixed_additions": w1 + w2, "phi_products": w2, "terms": len(scal), "naf_width": naf_w}
+            kern = f"pc::EcFoldTableBody<{curve}> + XyzzBatchAffineBody"
         else:
+            k1, k2 = glv_split(gc, u)
+            (w1, t1), (w2, t2) = _naf_weight_and_top(abs(k1)), _naf_weight_and_top(abs(k2))
             nd, na = max(t1, t2), w1 + w2 + 1
             ceil_s = h * (nd / jd + na / ja) if jd and ja else None
             ops = {"jacobian_doublings": nd, "jacobian_mixed_additions": na}
-            kern = "pc::EcFoldGlvBody<pallas> + JacBatchAffineBody"
-        folds.append({"round": i + 1, "elements": h, "kernel": kern, "ops_per_element": ops, "wall_ms": ms,
+            kern = f"pc::EcFoldGlvBody<{curve}> + JacBatchAffineBody"
+        folds.append({"round": i + 1, "elements": h, "kind": kind, "kernel": kern, "ops_per_element": ops, "wall_ms": ms,
                       "ceiling_ms": ceil_s * 1e3 if ceil_s else None, "frac": ceil_s * 1e3 / ms if ceil_s and ms else None})
         if ceil_s:
             tot_ms += ms
@@ -1273,7 +1300,7 @@ def ipa_open_roofline(curve, log_n, challenges_mont, fold_rounds, per_round_ms, 
             "folds": folds, "fold_share_of_open": tot_ms / open_ms if open_ms else None,
             "msm_wait_ms": breakdown_ms.get("msm_wait"), "host_point_mul_ms": breakdown_ms.get("host_point_mul"),
             "fixed_key_rounds": {"count": len(tail), "ms_each_mean": float(np.mean(tail)) if tail else None, "ms_total": float(np.sum(tail)) if tail else None,
-                                 "note": "rounds with n <= 2^17 keep the key and run two 2^17-pair MSMs over per-base factors: each is one scalar kernel, two "
+                                 "note": "rounds with n <= 2^16 keep the key and run two 2^16-pair MSMs over per-base factors: each is one scalar kernel, two "
                                          "pipelined MSM launches (sort, accumulate, three reduction levels, 64-byte download), two host point multiplications "
                                          "and the Horner tails -- a launch / latency floor of ~1 ms per round that no kernel rate changes"}}
 
@@ -1301,6 +1328,7 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
     srs.precompute()
     srs.precompute_fold()
     key_tables_ms = (time.perf_counter() - t0) * 1e3
+    fold_table_form, fold_table_bytes = srs.fold_table_info(), srs.bytes_resident()["fold_table"]
     cdev = rand_fr_device(0xA11CE, n)
     point = mont_limbs(curve, seed_fr(curve, 0xB0B))
     ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, log_n))
@@ -1325,7 +1353,9 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
             best, tm_best = dt, tm
     per_round = tm_best.pop("per_round_ms", [])
     fold_rounds = tm_best.pop("ec_fold_per_round_ms", [])
-    roof_open = ipa_open_roofline(curve, log_n, ch, fold_rounds, per_round, tm_best, best * 1e3)
+    fold_kinds = tm_best.pop("ec_fold_kind", None)
+    roof_open = ipa_open_roofline(curve, log_n, ch, fold_rounds, per_round, tm_best, best * 1e3, fold_kinds, fold_table_form[1] or 2)
+    roof_open["fold_table"] = {"levels": fold_table_form[0], "naf_width": fold_table_form[1], "bytes": fold_table_bytes}
     cpu = None
     if with_cpu:
         try:
@@ -1357,7 +1387,7 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
                                             "window_bits": shape_c["window_bits"], "buckets": shape_c["buckets"]}),
             "roofline_open": roof_open, "cpu_baseline": cpu,
             "key_gen_ms": key_gen_ms, "key_tables_build_ms": key_tables_ms,
-            "key_tables_note": "window table + fold table (131 x n/2 points) of the committer key, built once per key outside the timing",
+            "key_tables_note": "window table + fold table of the committer key (two levels: 131 x 2^(w-2) rows of the upper three quarters), built once per key outside the timing",
             "parity": {"commit_ok": ok_commit, "final_comm_key_ok": ok_key,
                        "method": "generators a^i g built on the device: commitment == p(a) g (oracle Horner + scalar multiplication); "
                                  "final_comm_key == prod_i (1 + u_i a^(2^(log n - 1 - i))) g for the supplied round challenges u_i "

@@ -358,12 +358,33 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host);
  * leaving src (the committer key, resident across openings) untouched -- the round's two MSMs run on src itself (with its
  * window table, if built) and no working copy of the key is needed.  If pc_hip_srs_precompute_fold was called on src and
  * n_half is half its length, the multiplication by u costs ~86 mixed additions per element out of the fold table instead of
- * a 130-doubling ladder. */
+ * a 130-doubling ladder (a ONE-level table; a key with a two-level table folds with pc_hip_ec_fold2_from). */
 int pc_hip_ec_fold_from(pc_ctx* ctx, const pc_srs* src, size_t n_half, const void* u_host, pc_srs** out);
 /* Once per committer key (like pc_hip_srs_precompute, at `trim`): the fold table T[b][j] = 2^b * key[n/2 + j], b < 131, of the
  * upper half of the key (131 x n/2 affine points: 17 GB for a 2^22-point Pallas key), used by pc_hip_ec_fold_from: every
  * opening's first fold multiplies THIS half by its round challenge.  Nothing in the reference corresponds to it.  n even. */
 int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs);   /* PC_ERR_UNSUPPORTED when the table would exceed half of the free device memory (PC_HIP_FOLD_TABLE_MAX_FRAC) */
+/* The same table in its general form (pc_hip_srs_precompute_fold = the library's choice, or PC_HIP_FOLD_TABLE="levels,width"):
+ *   levels     1: the upper half of the key (the first fold of an opening); 2: the upper three quarters -- the key after the first
+ *              TWO folds (ipa_pc/mod.rs:699-707, rounds 1 and 2) then comes straight from the committer key,
+ *                K''[i] = K[i] + u2 K[q + i] + u1 K[2q + i] + (u1 u2) K[3q + i],  q = n / 4          (pc_hip_ec_fold2_from),
+ *              as table additions only, and round 2's commitments are MSMs on the committer key itself (by linearity, see
+ *              pc_hip_ec_fold2_from); n divisible by 4.  0: two levels from 2^16 points on, if the memory share allows
+ *   naf_width  2 .. 5: the table holds the odd multiples d < 2^(w-1) of every doubling, for width-w NAF digits of the challenges'
+ *              GLV halves: 2 x 130 / (w + 1) additions per term and element (86 / 65 / 52 / 43) for 131 x 2^(w-2) rows.  0: the
+ *              widest form (up to 4) that fits PC_HIP_FOLD_TABLE_MAX_FRAC of the free device memory
+ * A 2^22-point Pallas key: 17.6 GB (1, 2), 26 / 53 / 106 GB (2, 2 / 3 / 4).  Built once per committer key, like the window table. */
+int pc_hip_srs_precompute_fold_ex(pc_ctx* ctx, pc_srs* srs, unsigned levels, unsigned naf_width);
+/* What pc_hip_srs_precompute_fold[_ex] built on this key: levels (0: no table) and the NAF width of its digits. */
+int pc_hip_srs_fold_table_info(const pc_srs* srs, unsigned* out_levels, unsigned* out_naf_width);
+/* The first TWO key folds of an opening in one step, out of place: *out = a new resident key of n_quarter points,
+ *   out[i] = affine(src[i] + u2 * src[q + i] + u1 * src[2q + i] + u1 u2 * src[3q + i]),  q = n_quarter,
+ * i.e. the key after `k_l += k_r * u1` and `k_l += k_r * u2` (ipa_pc/mod.rs:699-707 in rounds 1 and 2); src (the committer key) is
+ * untouched.  The caller runs round 2's commitments on src by linearity of the MSM,
+ *   MSM(K'[a .. a + q), s) = MSM(K[a .. a + q), s) + u1 * MSM(K[a + 2q .. a + 3q), s),   K' = the key after the first fold,
+ * so the once-folded key never exists.  With a two-level fold table on src: 3 x ~52 table additions per element (width 4); without
+ * one the two folds run one after the other (table / ladder): same result, no gain. */
+int pc_hip_ec_fold2_from(pc_ctx* ctx, const pc_srs* src, size_t n_quarter, const void* u1_host, const void* u2_host, pc_srs** out);
 /* Late halving rounds without folding the key (same l_vec / r_vec / final_comm_key, bit for bit): once n has
  * shrunk to n0 the resident key K0 = key[0..n0) stays as it is and the per-base factors s_j that the remaining
  * folds `k_l += k_r * u` (ipa_pc/mod.rs:699-701) would have applied are kept as a device vector s (n0 Fr,

@@ -101,6 +101,9 @@ def load_library():
     lib.pc_hip_ec_fold.argtypes = [vp, vp, sz, vp]
     lib.pc_hip_ec_fold_from.argtypes = [vp, vp, sz, vp, C.POINTER(vp)]
     lib.pc_hip_srs_precompute_fold.argtypes = [vp, vp]
+    lib.pc_hip_srs_precompute_fold_ex.argtypes = [vp, vp, C.c_uint, C.c_uint]
+    lib.pc_hip_srs_fold_table_info.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    lib.pc_hip_ec_fold2_from.argtypes = [vp, vp, sz, vp, vp, C.POINTER(vp)]
     lib.pc_hip_ipa_key_scalars.argtypes = [vp, ip, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
@@ -497,10 +500,32 @@ class Srs:
         u = np.ascontiguousarray(u, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.pc_hip_ec_fold(self.ctx.h, self.h, n_half, C.c_void_p(u.ctypes.data)))
 
-    def precompute_fold(self):
-        """Fold table of the upper half of this (committer) key: pc_hip_srs_precompute_fold."""
-        self.ctx.check(self.ctx.lib.pc_hip_srs_precompute_fold(self.ctx.h, self.h))
+    def precompute_fold(self, levels=None, naf_width=None):
+        """Fold table of this (committer) key: pc_hip_srs_precompute_fold (the library's choice of form), or
+        pc_hip_srs_precompute_fold_ex(levels, naf_width) -- levels 1: the upper half (first fold of an opening), 2: the upper three
+        quarters (the first two folds in one step, fold2_from); naf_width 2 .. 5; 0 = the library chooses that parameter."""
+        if levels is None and naf_width is None:
+            self.ctx.check(self.ctx.lib.pc_hip_srs_precompute_fold(self.ctx.h, self.h))
+        else:
+            self.ctx.check(self.ctx.lib.pc_hip_srs_precompute_fold_ex(self.ctx.h, self.h, levels or 0, naf_width or 0))
         return self
+
+    def fold_table_info(self):
+        """(levels, naf_width) of the fold table on this key; (0, 0): none."""
+        a, b = C.c_uint(), C.c_uint()
+        self.ctx.check(self.ctx.lib.pc_hip_srs_fold_table_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def fold2_from(self, n_quarter, u1, u2):
+        """A new resident key of n_quarter points: the key after the first TWO folds (by u1, then u2), straight from this key
+        (pc_hip_ec_fold2_from); self is left as it is."""
+        u1 = np.ascontiguousarray(u1, dtype=np.uint64)
+        u2 = np.ascontiguousarray(u2, dtype=np.uint64)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.pc_hip_ec_fold2_from(self.ctx.h, self.h, n_quarter, C.c_void_p(u1.ctypes.data), C.c_void_p(u2.ctypes.data), C.byref(h)))
+        out = Srs.__new__(Srs)
+        out.ctx, out.curve, out.h, out.n = self.ctx, self.curve, h, n_quarter
+        return out
 
     def fold_from(self, n_half, u):
         """A new resident key: affine(self[i] + u * self[n_half + i]), i < n_half; self is left as it is (pc_hip_ec_fold_from)."""

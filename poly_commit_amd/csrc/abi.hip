@@ -62,8 +62,10 @@ struct pc_srs {
   size_t n = 0;
   uint32_t* bases = nullptr;     // packed x||y
   uint32_t* table = nullptr;     // precomputed window table (pc_hip_srs_precompute), or null
-  uint32_t* fold_tbl = nullptr;  // fold table of the upper half (pc_hip_srs_precompute_fold), or null
-  size_t fold_half = 0;
+  uint32_t* fold_tbl = nullptr;  // fold table (pc_hip_srs_precompute_fold[_ex]) of the key points [fold_half, fold_half + fold_pts), or null
+  size_t fold_half = 0;          // points of the key the table leaves out = size of the key it folds to: n / 2 (one level) or n / 4 (two)
+  size_t fold_pts = 0;           // points per table row: n / 2 or 3 n / 4
+  uint32_t fold_levels = 0, fold_w = 2;   // folds the table serves in one step; width of the NAF digits it holds the odd multiples for
   // pc_hip_ec_fold_from: the half-size working key of an opening keeps its buffers and pipelines across openings -- freeing it
   // hands it back to the committer key it was folded from (a fresh key cost ~4 ms of pipeline workspace allocation per opening)
   pc_srs* parent = nullptr;      // the key this one was folded from (while that key is alive)
@@ -437,6 +439,7 @@ static void srs_release_device(pc_srs* srs) {
   { auto& ks = srs->ctx->keys; ks.erase(std::remove(ks.begin(), ks.end(), srs), ks.end()); }
   if (srs->bases) srs->ctx->be.free(srs->bases);
   if (srs->fold_tbl) srs->ctx->be.free(srs->fold_tbl);
+  srs->fold_tbl = nullptr;
   drop_batch_many(srs);
   if (srs->table) srs->ctx->be.free(srs->table);
   drop_many(srs);
@@ -847,7 +850,7 @@ static void srs_bytes(const pc_srs* s, size_t out[4]) {
   out[1] = 0;
   if (s->table) out[1] = (size_t)table_windows(s, s->cfg.tbl_c, s->cfg.tbl_glv) * s->n * s->cfg.tbl_pt_stride * 4;
   if (s->many.table) { const uint32_t bits = pc::curve_ops(s->curve).scalar_bits; out[1] += (size_t)pc::msm_num_windows(bits, pc::msm_choose_table_c(s->many.m, bits, 0)) * s->many.m * pb; }
-  out[2] = s->fold_tbl ? (size_t)pc::curve_ops(s->curve).fold_rows * s->fold_half * pb : 0;
+  out[2] = s->fold_tbl ? ((size_t)pc::curve_ops(s->curve).fold_rows << (s->fold_w - 2)) * s->fold_pts * pb : 0;
   out[3] = 0;
   for (int i = 0; i < PC_MSM_LANES; i++) out[3] += lane_bytes(s->lanes[i]);
   out[3] += lane_bytes(s->many.lane) + lane_bytes(s->bm.lanes[0]) + lane_bytes(s->bm.lanes[1]);
@@ -1536,6 +1539,7 @@ int pc_hip_fr_lincomb(pc_ctx* ctx, pc_curve field_of, const void* const* polys, 
     return (int)PC_OK;
   });
 }
+static void drop_fold_table(pc_srs* srs);
 int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) {
   if (!ctx || !srs || srs->ctx != ctx || !u_host || 2 * n_half > srs->n) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1545,58 +1549,133 @@ int pc_hip_ec_fold(pc_ctx* ctx, pc_srs* srs, size_t n_half, const void* u_host) 
     if (!n_half) return (int)PC_OK;
     drop_table(srs);                            // the key changes: its window tables are stale
     drop_many(srs);
-    if (srs->fold_tbl) { ctx->be.free(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
+    drop_fold_table(srs);
     pc::curve_ops(srs->curve).ec_fold(ctx->be, srs->bases, n_half, (const uint32_t*)u_host);
     return (int)PC_OK;
   });
 }
-int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs) {
-  if (!ctx || !srs || srs->ctx != ctx || srs->n < 2 || (srs->n & 1)) return PC_ERR_INVALID_ARG;
+static void drop_fold_table(pc_srs* srs) {
+  if (srs->fold_tbl) srs->ctx->be.free(srs->fold_tbl);
+  srs->fold_tbl = nullptr; srs->fold_half = srs->fold_pts = 0; srs->fold_levels = 0; srs->fold_w = 2;
+}
+int pc_hip_srs_precompute_fold_ex(pc_ctx* ctx, pc_srs* srs, unsigned levels, unsigned naf_width) {
+  if (!ctx || !srs || srs->ctx != ctx || levels > 2 || (naf_width && (naf_width < 2 || naf_width > 5))) return PC_ERR_INVALID_ARG;
+  if (srs->n < 2 || (srs->n & 1) || (levels == 2 && (srs->n & 3))) return PC_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   return guarded(ctx, [&]() {
-    if (srs->fold_tbl) { ctx->be.free(srs->fold_tbl); srs->fold_tbl = nullptr; srs->fold_half = 0; }
-    const size_t half = srs->n / 2, pb = (size_t)srs->aw * 4;
+    drop_fold_table(srs);
+    const size_t pb = (size_t)srs->aw * 4;
     const pc::CurveOps& ops = pc::curve_ops(srs->curve);
-    // 131 rows x n/2 points (17.6 GB for a 2^22-point Pallas key): refused above a share of the device's FREE memory
-    // (PC_HIP_FOLD_TABLE_MAX_FRAC, default 0.5) instead of driving a shared GPU out of memory; the opening then runs the GLV ladder
-    {
-      static const double frac = []() { const char* e = getenv("PC_HIP_FOLD_TABLE_MAX_FRAC"); double v = e ? atof(e) : 0.5; return v < 0 ? 0.0 : v > 1 ? 1.0 : v; }();
-      size_t free_b = 0, total_b = 0;
-      PC_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-      const size_t need = (size_t)ops.fold_rows * half * pb;
-      if ((double)need > frac * (double)free_b) {
-        ctx->last_error = "fold table of " + std::to_string(need >> 20) + " MiB exceeds " + std::to_string(frac) + " of the free device memory (" + std::to_string(free_b >> 20) + " MiB)";
-        return (int)PC_ERR_UNSUPPORTED;
-      }
+    // Refused above a share of the device's FREE memory (PC_HIP_FOLD_TABLE_MAX_FRAC, default 0.5) instead of driving a shared GPU out
+    // of memory; the opening then runs the GLV ladder.  levels / naf_width 0: the largest form that fits that share -- two levels
+    // from 2^16 points on (below, the second fold is a latency-bound ladder either way), digits as wide as the memory allows:
+    //   rows = 131 * 2^(w-2), points per row = n / 2 or 3 n / 4:  a 2^22-point Pallas key: 17.6 GB (1, 2) .. 26 / 53 / 106 GB (2, 2 / 3 / 4)
+    static const double frac = []() { const char* e = getenv("PC_HIP_FOLD_TABLE_MAX_FRAC"); double v = e ? atof(e) : 0.5; return v < 0 ? 0.0 : v > 1 ? 1.0 : v; }();
+    size_t free_b = 0, total_b = 0;
+    PC_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    auto bytes_of = [&](unsigned L, unsigned w) { return ((size_t)ops.fold_rows << (w - 2)) * (srs->n - (srs->n >> L)) * pb; };
+    unsigned L = levels, w = naf_width;
+    if (!L) L = (srs->n >= ((size_t)1 << 16) && !(srs->n & 3)) ? 2u : 1u;
+    if (!w) { w = 4; while (w > 2 && (double)bytes_of(L, w) > frac * (double)free_b) w--; }
+    if (!levels && L == 2 && (double)bytes_of(L, w) > frac * (double)free_b) L = 1;
+    const size_t need = bytes_of(L, w);
+    if ((double)need > frac * (double)free_b) {
+      ctx->last_error = "fold table of " + std::to_string(need >> 20) + " MiB exceeds " + std::to_string(frac) + " of the free device memory (" + std::to_string(free_b >> 20) + " MiB)";
+      return (int)PC_ERR_UNSUPPORTED;
     }
-    uint32_t* t = (uint32_t*)ctx->be.alloc((size_t)ops.fold_rows * half * pb);
-    try { ops.fold_table_build(ctx->be, srs->bases + half * (size_t)srs->aw, half, t); }
+    const size_t q = srs->n >> L, pts = srs->n - q;
+    uint32_t* t = (uint32_t*)ctx->be.alloc(need);
+    try { ops.fold_table_build(ctx->be, srs->bases + q * (size_t)srs->aw, pts, w, t); }
     catch (...) { ctx->be.free(t); throw; }
-    srs->fold_tbl = t; srs->fold_half = half;
+    srs->fold_tbl = t; srs->fold_half = q; srs->fold_pts = pts; srs->fold_levels = L; srs->fold_w = w;
     return (int)PC_OK;
   });
 }
+int pc_hip_srs_precompute_fold(pc_ctx* ctx, pc_srs* srs) {
+  // PC_HIP_FOLD_TABLE="levels,width" (e.g. "1,2": the one-level table of plain NAF digits of rounds 3-5); unset: the library's choice
+  static const std::pair<unsigned, unsigned> form = []() {
+    const char* e = getenv("PC_HIP_FOLD_TABLE"); unsigned l = 0, w = 0;
+    if (e) { l = (unsigned)atoi(e); const char* c = strchr(e, ','); if (c) w = (unsigned)atoi(c + 1); }
+    return std::make_pair(l > 2 ? 0u : l, (w && (w < 2 || w > 5)) ? 0u : w);
+  }();
+  return pc_hip_srs_precompute_fold_ex(ctx, srs, form.first, form.second);
+}
+int pc_hip_srs_fold_table_info(const pc_srs* srs, unsigned* out_levels, unsigned* out_naf_width) {
+  if (!srs) return PC_ERR_INVALID_ARG;
+  if (out_levels) *out_levels = srs->fold_tbl ? srs->fold_levels : 0u;
+  if (out_naf_width) *out_naf_width = srs->fold_tbl ? srs->fold_w : 0u;
+  return PC_OK;
+}
 
+// the working key of `count` points an opening folds the committer key `par` into: the one the last opening handed back, or a new one
+static pc_srs* working_key(pc_ctx* ctx, pc_srs* par, size_t count, bool* fresh) {
+  pc_srs* dst = nullptr;
+  if (par->work_cache && par->work_cache->n == count) { dst = par->work_cache; par->work_cache = nullptr; }      // buffers and pipelines of the last opening
+  *fresh = dst == nullptr;
+  if (*fresh) {
+    dst = new (std::nothrow) pc_srs();
+    if (!dst) return nullptr;
+    dst->ctx = ctx; dst->curve = par->curve; dst->n = count; dst->aw = par->aw;
+    ctx->keys.push_back(dst);
+  }
+  return dst;
+}
 int pc_hip_ec_fold_from(pc_ctx* ctx, const pc_srs* src, size_t n_half, const void* u_host, pc_srs** out) {
   if (!ctx || !src || src->ctx != ctx || !u_host || !out || !n_half || 2 * n_half > src->n) return PC_ERR_INVALID_ARG;
   *out = nullptr;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   pc_srs* par = const_cast<pc_srs*>(src);
-  pc_srs* dst = nullptr;
-  if (par->work_cache && par->work_cache->n == n_half) { dst = par->work_cache; par->work_cache = nullptr; }      // buffers and pipelines of the last opening
-  const bool fresh = dst == nullptr;
-  if (fresh) {
-    dst = new (std::nothrow) pc_srs();
-    if (!dst) return PC_ERR_OOM;
-    dst->ctx = ctx; dst->curve = src->curve; dst->n = n_half; dst->aw = src->aw;
-    ctx->keys.push_back(dst);
-  }
+  bool fresh = false;
+  pc_srs* dst = working_key(ctx, par, n_half, &fresh);
+  if (!dst) return PC_ERR_OOM;
   int rc = guarded(ctx, [&]() {
     if (fresh) { dst->bases = (uint32_t*)ctx->be.alloc(n_half * (size_t)src->aw * 4); dst->cfg = ctx->msm_cfg; }
     else { drop_table(dst); drop_many(dst); }
-    const uint32_t* tbl = (src->fold_tbl && src->fold_half == n_half) ? src->fold_tbl : nullptr;
-    pc::curve_ops(src->curve).ec_fold_to(ctx->be, src->bases, dst->bases, n_half, (const uint32_t*)u_host, tbl);
+    const uint32_t* tbl = (src->fold_tbl && src->fold_levels == 1 && src->fold_half == n_half) ? src->fold_tbl : nullptr;
+    pc::curve_ops(src->curve).ec_fold_to(ctx->be, src->bases, dst->bases, n_half, (const uint32_t*)u_host, tbl, src->fold_w);
     if (fresh) for (int i = 0; i < PC_MSM_LANES; i++) srs_lane(dst, i);      // all pipelines now: the next rounds' MSMs find them ready
+    return (int)PC_OK;
+  });
+  if (rc != PC_OK) { dst->parent = nullptr; pc_hip_srs_free(dst); return rc; }
+  if (!par->work_out) { dst->parent = par; par->work_out = dst; } else dst->parent = nullptr;
+  *out = dst;
+  return PC_OK;
+}
+int pc_hip_ec_fold2_from(pc_ctx* ctx, const pc_srs* src, size_t n_quarter, const void* u1_host, const void* u2_host, pc_srs** out) {
+  if (!ctx || !src || src->ctx != ctx || !u1_host || !u2_host || !out || !n_quarter || 4 * n_quarter > src->n) return PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  pc_srs* par = const_cast<pc_srs*>(src);
+  const bool have = src->fold_tbl && src->fold_levels == 2 && src->fold_half == n_quarter;
+  bool fresh = false;
+  pc_srs* dst = working_key(ctx, par, n_quarter, &fresh);
+  if (!dst) return PC_ERR_OOM;
+  int rc = guarded(ctx, [&]() {
+    const pc::CurveOps& ops = pc::curve_ops(src->curve);
+    const size_t aw = (size_t)src->aw;
+    if (fresh) { dst->bases = (uint32_t*)ctx->be.alloc(n_quarter * aw * 4); dst->cfg = ctx->msm_cfg; }
+    else { drop_table(dst); drop_many(dst); }
+    bool done = false;
+    if (have) {
+      // terms in the order of the table's points: K[q .. 2q) by u2, K[2q .. 3q) by u1, K[3q .. 4q) by u1 u2
+      uint32_t u12[8];
+      ops.fr_mul((const uint32_t*)u1_host, (const uint32_t*)u2_host, u12);
+      const uint32_t* us[3] = {(const uint32_t*)u2_host, (const uint32_t*)u1_host, u12};
+      done = ops.ec_fold_table(ctx->be, src->bases, dst->bases, n_quarter, src->fold_pts, 3, us, src->fold_w, src->fold_tbl);
+    }
+    if (!done) {
+      // no two-level table on this key (or a split beyond its rows): the two folds one after the other, through a scratch half key
+      uint32_t* tmp = (uint32_t*)ctx->be.alloc(2 * n_quarter * aw * 4);
+      try {
+        const uint32_t* tbl1 = (src->fold_tbl && src->fold_levels == 1 && src->fold_half == 2 * n_quarter) ? src->fold_tbl : nullptr;
+        ops.ec_fold_to(ctx->be, src->bases, tmp, 2 * n_quarter, (const uint32_t*)u1_host, tbl1, src->fold_w);
+        ops.ec_fold_to(ctx->be, tmp, tmp, n_quarter, (const uint32_t*)u2_host, nullptr, 2);
+        ctx->be.copy_d2d(dst->bases, tmp, n_quarter * aw * 4);
+        ctx->be.sync();
+      } catch (...) { ctx->be.free(tmp); throw; }
+      ctx->be.free(tmp);
+    }
+    if (fresh) for (int i = 0; i < PC_MSM_LANES; i++) srs_lane(dst, i);
     return (int)PC_OK;
   });
   if (rc != PC_OK) { dst->parent = nullptr; pc_hip_srs_free(dst); return rc; }

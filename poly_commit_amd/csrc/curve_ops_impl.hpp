@@ -8,6 +8,7 @@
 #include "hip_backend_msm.hpp"
 #include "ipa.hpp"
 #include "glv.hpp"
+#include "fold_table.hpp"
 #include "serialize.hpp"
 
 namespace pc {
@@ -154,44 +155,20 @@ void ec_fold_run(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_m
 }
 
 // out[i] = affine(in[i] + u * in[half + i]), i < half (out may be `in` itself: the in-place fold).  table != null: the first
-// fold of an opening from the committer key's fold table (glv.hpp), else the GLV ladder per element.
+// fold of an opening from the committer key's (one-level) fold table of width-w NAF digits, else the GLV ladder per element.
 template <class C>
-void ec_fold_to_run(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table) {
+void ec_fold_to_run(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table, uint32_t w) {
   typedef typename GlvOf<C>::T G;
   constexpr int FN = C::FqP::N;
+  if (table) {
+    const uint32_t* us[1] = {u_mont};
+    if (ec_fold_table_run<C>(be, in, out, half, half, 1, us, w, table)) return;
+    // a split that does not fit the table's rows (never seen: |k1|, |k2| <= 2^128): the ladder below
+  }
   Fd<typename C::FrP> u = Fd<typename C::FrP>::load(u_mont).from_mont();
   uint64_t k[4]; memcpy(k, u.l, 32);
   GlvSplit sp = glv_decompose<G>(k);
   NafMasks<5> n1, n2; n1.from_scalar(sp.k1); n2.from_scalar(sp.k2);
-  if (table) {
-    EcFoldTableBody<C> body; body.key_lo = in; body.table = table; body.half = (uint32_t)half; body.n_ops = 0;
-    for (int i = 0; i < FN; i++) body.beta[i] = G::BETA_MONT[i];
-    bool fits = true;
-    for (uint32_t bit = 0; bit < 32 * 6; bit++) {
-      const uint32_t w = bit >> 5, m = 1u << (bit & 31);
-      for (int which = 0; which < 2; which++) {
-        const NafMasks<5>& nm = which ? n2 : n1;
-        const uint32_t sgn = which ? sp.neg2 : sp.neg1;
-        const bool pos = nm.pos[w] & m, neg = nm.neg[w] & m;
-        if (!pos && !neg) continue;
-        if (bit >= FOLD_ROWS || body.n_ops >= EcFoldTableBody<C>::MAX_OPS) { fits = false; continue; }
-        const bool negate = (neg ? 1u : 0u) ^ (sgn ? 1u : 0u);
-        body.ops[body.n_ops++] = (uint16_t)(bit | (which ? 0x4000u : 0u) | (negate ? 0x8000u : 0u));
-      }
-    }
-    if (fits) {
-      // XYZZ sums | prefix products, then one inversion per K points into `out`
-      uint32_t* ws = (uint32_t*)be.workspace(half * (size_t)5 * FN * 4);
-      body.out_xyzz = ws;
-      be.launch(body, half, 64);
-      const uint32_t K = half >= ((size_t)1 << 20) ? 16 : half >= ((size_t)1 << 17) ? 8 : 4;
-      XyzzBatchAffineBody<C> nb{ws, ws + half * (size_t)4 * FN, out, (uint32_t)half, K};
-      be.launch(nb, (half + K - 1) / K, 64);
-      be.sync();
-      return;
-    }
-    // a split that does not fit the table's rows (never seen: |k1|, |k2| <= 2^128): the ladder below
-  }
   EcFoldGlvBody<C> body; body.key = out; body.key_in = in == out ? nullptr : in; body.half = (uint32_t)half;
   body.n1 = n1; body.n2 = n2; body.neg1 = sp.neg1; body.neg2 = sp.neg2;
   for (int i = 0; i < FN; i++) body.beta[i] = G::BETA_MONT[i];
@@ -203,20 +180,6 @@ void ec_fold_to_run(HipBackend& be, const uint32_t* in, uint32_t* out, size_t ha
     JacBatchAffineBody<C> nb{ws, ws + half * (size_t)3 * FN, out, (uint32_t)half, K};
     be.launch(nb, (half + K - 1) / K, 64);
   } else be.launch(body, half, 64);
-  be.sync();
-}
-
-// T[b][j] = 2^b * key_hi[j] (glv.hpp): row 0 is a copy, every further row one batched affine doubling of the previous one
-template <class C>
-void fold_table_build_run(HipBackend& be, const uint32_t* key_hi, size_t half, uint32_t* table) {
-  constexpr int FN = C::FqP::N, AW = 2 * FN;
-  be.copy_d2d(table, key_hi, half * (size_t)AW * 4);
-  uint32_t* scratch = (uint32_t*)be.workspace(half * (size_t)FN * 4);
-  const uint32_t K = 64;
-  for (uint32_t b = 1; b < FOLD_ROWS; b++) {
-    AffineDoubleRowBody<C> body{table + (size_t)(b - 1) * half * AW, table + (size_t)b * half * AW, scratch, (uint32_t)half, K};
-    be.launch(body, (half + K - 1) / K, 64);
-  }
   be.sync();
 }
 
@@ -232,10 +195,18 @@ struct CurveOpsImpl {
   static void ec_fold(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont) {
     ec_fold_run<C>(be, key, half, u_mont);
   }
-  static void ec_fold_to(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table) {
-    ec_fold_to_run<C>(be, in, out, half, u_mont, table);
+  static void ec_fold_to(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table, uint32_t w) {
+    ec_fold_to_run<C>(be, in, out, half, u_mont, table, w);
   }
-  static void fold_table_build(HipBackend& be, const uint32_t* key_hi, size_t half, uint32_t* table) { fold_table_build_run<C>(be, key_hi, half, table); }
+  static bool ec_fold_table(HipBackend& be, const uint32_t* key_lo, uint32_t* out, size_t count, size_t row_pts, uint32_t terms,
+                            const uint32_t* const* u_monts, uint32_t w, const uint32_t* table) {
+    return ec_fold_table_run<C>(be, key_lo, out, count, row_pts, terms, u_monts, w, table);
+  }
+  static void fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    typedef Fd<typename C::FrP> Fr;
+    Fr::load(a).mul(Fr::load(b)).store(out);
+  }
+  static void fold_table_build(HipBackend& be, const uint32_t* pts, size_t count, uint32_t w, uint32_t* table) { fold_table_build_run<C>(be, pts, count, w, table); }
   static void fixed_base(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out) {
     if (n < 4096) {          // a handful of scalars: the per-lane ladder, no table
       FixedBaseMulBody<C> body; body.scalars = scalars; body.out = out;
@@ -306,7 +277,7 @@ struct CurveOpsImpl {
     acc.store_affine(out);
   }
   static CurveOps table() {
-    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &ec_fold_to, &fold_table_build, (uint32_t)FOLD_ROWS, &fixed_base, &srs_decode, &srs_encode, &points_sum, &point_mul};
+    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &ec_fold_to, &ec_fold_table, &fold_table_build, (uint32_t)FOLD_ROWS, &fixed_base, &srs_decode, &srs_encode, &points_sum, &point_mul, &fr_mul};
   }
 };
 

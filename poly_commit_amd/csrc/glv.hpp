@@ -188,24 +188,70 @@ struct AffineDoubleRowBody {
   }
 };
 
-// out_xyzz[i] = K[i] + sum of the listed table entries (ops: row | which << 14 | negate << 15; which = 1: phi of the entry)
+// row(d + 2, 0) of the fold table from row(d, 0) and row(1, 1): out[j] = a[j] + b[j], affine, one inversion per K points.
+// The operands are d P and 2 P of the same point P (d odd, >= 1): in a prime-order group their x coordinates differ unless P is the
+// point at infinity, so only that case is handled besides the general chord.
+template <class C>
+struct AffineAddRowBody {
+  typedef Fd<typename C::FqP> Fq;
+  static constexpr int FN = Fq::N, AW = 2 * FN;
+  const uint32_t* a; const uint32_t* b; uint32_t* out; uint32_t* scratch;   // scratch: n x Fq (prefix products)
+  uint32_t n, K;
+  PC_HD void operator()(uint32_t t) const {
+    const uint32_t s = t * K, e = (n - s > K) ? s + K : n;
+    Fq run = Fq::one();
+    for (uint32_t j = s; j < e; j++) {
+      run.store(scratch + (size_t)j * FN);
+      const AffD<C> p = AffD<C>::load(a + (size_t)j * AW), q = AffD<C>::load(b + (size_t)j * AW);
+      const Fq d = q.x.sub(p.x);
+      if (!p.is_inf() && !q.is_inf() && !d.is_zero()) run = run.mul(d);
+    }
+    Fq inv = run.inv();
+    for (uint32_t j = e; j-- > s;) {
+      const AffD<C> p = AffD<C>::load(a + (size_t)j * AW), q = AffD<C>::load(b + (size_t)j * AW);
+      AffD<C> r = p.is_inf() ? q : p;                 // one operand at infinity: the other one
+      const Fq d = q.x.sub(p.x);
+      if (!p.is_inf() && !q.is_inf()) {
+        if (d.is_zero()) r = AffD<C>::infinity();     // (d P = -2 P: not reachable for points of prime order; d P = 2 P neither)
+        else {
+          const Fq di = inv.mul(Fq::load(scratch + (size_t)j * FN));       // 1 / (x2 - x1)
+          inv = inv.mul(d);
+          const Fq lam = q.y.sub(p.y).mul(di);
+          r.x = lam.sqr().sub(p.x).sub(q.x);
+          r.y = lam.mul(p.x.sub(r.x)).sub(p.y);
+        }
+      }
+      r.store(out + (size_t)j * AW);
+    }
+  }
+};
+
+// out_xyzz[i] = K[i] + sum of the listed table entries.  The table holds, for the `row_pts` key points it covers, FOLD_ROWS rows per
+// odd multiple d = 1, 3, .., 2^(w-1) - 1:  T[(d >> 1) * FOLD_ROWS + b][j] = d * 2^b * P_j.  An op names one entry for lane i:
+//   bits 0..9 row, bits 10..11 term (the entry is at point term * count + i of its row), bit 14: phi of the entry, bit 15: negate.
+// One level (the first fold of an opening, ipa_pc/mod.rs:699-701): one term, the upper half of the key, scalar u.  Two levels: the
+// key after TWO folds straight from the committer key,
+//   K''[i] = K[i] + u2 K[q + i] + u1 K[2q + i] + (u1 u2) K[3q + i],  q = n / 4,
+// three terms over the table of K[q .. 4q) -- 3 x (2 x 130 / (w + 1)) mixed additions per element and no doubling, where the first
+// fold from a one-level table plus a ladder for the second cost 86 additions per element of the half and 127 doublings + 94
+// additions per element of the quarter.
 template <class C>
 struct EcFoldTableBody {
   typedef Fd<typename C::FqP> Fq;
   static constexpr int AW = 2 * Fq::N;
-  static constexpr uint32_t MAX_OPS = 272;
-  const uint32_t* key_lo;    // K[0 .. half)
-  const uint32_t* table;     // FOLD_ROWS x half affine points
-  uint32_t half, n_ops;
+  static constexpr uint32_t MAX_OPS = 448;
+  const uint32_t* key_lo;    // K[0 .. count)
+  const uint32_t* table;     // rows of row_pts affine points
+  uint32_t count, row_pts, n_ops;
   uint16_t ops[MAX_OPS];
   uint32_t beta[Fq::N];
-  uint32_t* out_xyzz;        // half x XyzzD::WORDS
+  uint32_t* out_xyzz;        // count x XyzzD::WORDS
   PC_HD void operator()(uint32_t i) const {
     XyzzD<C> acc = XyzzD<C>::from_affine(AffD<C>::load(key_lo + (size_t)i * AW));
     const Fq b = Fq::load(beta);
     for (uint32_t k = 0; k < n_ops; k++) {
-      const uint32_t op = ops[k], row = op & 0x3fffu;
-      AffD<C> p = AffD<C>::load(table + ((size_t)row * half + i) * AW);
+      const uint32_t op = ops[k], row = op & 0x3ffu, term = (op >> 10) & 3u;
+      AffD<C> p = AffD<C>::load(table + ((size_t)row * row_pts + (size_t)term * count + i) * AW);
       if (p.is_inf()) continue;
       if (op & 0x4000u) p.x = p.x.mul(b);
       acc.add_affine(p.neg_if((op & 0x8000u) != 0));
@@ -213,5 +259,29 @@ struct EcFoldTableBody {
     acc.store(out_xyzz + (size_t)i * XyzzD<C>::WORDS);
   }
 };
+
+// width-w NAF of a 160-bit magnitude (host): digits odd, |digit| < 2^(w-1), at most one non-zero digit in any w consecutive
+// positions (w = 2: the plain NAF).  out[bit] in (-2^(w-1), 2^(w-1)); returns the number of positions written.
+inline int wnaf_digits(const uint32_t k[5], int w, int8_t out[200]) {
+  uint32_t t[6] = {k[0], k[1], k[2], k[3], k[4], 0};
+  const uint32_t mask = (1u << w) - 1, half = 1u << (w - 1);
+  int len = 0;
+  for (int bit = 0; bit < 200; bit++) {
+    out[bit] = 0;
+    bool any = false; for (int i = 0; i < 6; i++) any |= t[i] != 0;
+    if (!any) continue;
+    if (t[0] & 1) {
+      const uint32_t m = t[0] & mask;
+      if (m >= half) {                       // digit m - 2^w < 0: t += 2^w - m
+        out[bit] = (int8_t)((int)m - (int)(mask + 1));
+        uint64_t c = (uint64_t)(mask + 1 - m); for (int i = 0; i < 6; i++) { c += t[i]; t[i] = (uint32_t)c; c >>= 32; }
+      } else { out[bit] = (int8_t)m; t[0] -= m; }
+      len = bit + 1;
+    }
+    for (int i = 0; i < 5; i++) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    t[5] >>= 1;
+  }
+  return len;
+}
 
 }  // namespace pc

@@ -42,9 +42,13 @@ struct CurveOps {
   MsmRunner* (*make_runner)(HipBackend& be, size_t n_max, const MsmConfig& cfg, uint32_t subs);
   void (*window_table)(HipBackend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride);
   void (*ec_fold)(HipBackend& be, uint32_t* key, size_t half, const uint32_t* u_mont);
-  // out[i] = affine(in[i] + u * in[half + i]); table: the key's fold table (or null: GLV ladder).  out == in: in place.
-  void (*ec_fold_to)(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table);
-  void (*fold_table_build)(HipBackend& be, const uint32_t* key_hi, size_t half, uint32_t* table);
+  // out[i] = affine(in[i] + u * in[half + i]); table: the key's one-level fold table of width-w NAF digits (or null: GLV ladder).  out == in: in place.
+  void (*ec_fold_to)(HipBackend& be, const uint32_t* in, uint32_t* out, size_t half, const uint32_t* u_mont, const uint32_t* table, uint32_t w);
+  // out[i] = affine(key_lo[i] + sum_t u_t * P_t[i]) from the fold table (term t = table points [t count, (t + 1) count)); false: does not fit
+  bool (*ec_fold_table)(HipBackend& be, const uint32_t* key_lo, uint32_t* out, size_t count, size_t row_pts, uint32_t terms,
+                        const uint32_t* const* u_monts, uint32_t w, const uint32_t* table);
+  // fold table of `count` key points for width-w NAF digits: 2^(w-2) * fold_rows rows of `count` points
+  void (*fold_table_build)(HipBackend& be, const uint32_t* pts, size_t count, uint32_t w, uint32_t* table);
   uint32_t fold_rows;
   void (*fixed_base)(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out);
   // ark-serialize bytes of n points (device) -> n resident affine points; returns the number of invalid points
@@ -54,6 +58,7 @@ struct CurveOps {
   // host-side helpers (a handful of points, as the reference does on the host)
   void (*points_sum)(const uint32_t* pts, size_t count, uint32_t* out);
   void (*point_mul)(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out);
+  void (*fr_mul)(const uint32_t* a_mont, const uint32_t* b_mont, uint32_t* out_mont);      // one scalar-field product on the host
 };
 
 struct FieldOps {

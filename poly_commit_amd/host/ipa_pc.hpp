@@ -119,7 +119,7 @@ struct InnerProductArgPC {
   // (pc_hip_ipa_key_scalars: the same points, without a latency-bound scalar-multiplication pass per round).
   static Error open_rounds(pc_ctx* ctx, const std::vector<G1Affine<E>>& comm_key, const std::vector<Fr>& coeffs, const Fr& point,
                            const G1Affine<E>& h_prime, IpaChallengeSource<E>& challenges, IpaProof<E>& proof,
-                           size_t fixed_key_below = (size_t)1 << 17) {
+                           size_t fixed_key_below = (size_t)1 << 16) {
     size_t n = coeffs.size();
     if (n == 0 || (n & (n - 1)) || comm_key.size() != n) { Error e; e.kind = Error::Backend; e.msg = "ipa: key / coefficient lengths must be one power of two"; return e; }
     proof = IpaProof<E>();

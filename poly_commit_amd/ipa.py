@@ -87,7 +87,11 @@ def ipa_open(ctx, curve, comm_key, h_xy, polys_dev, lens, comms, point_mont, ope
     return ipa_open_rounds(ctx, curve, comm_key, comb, n, point_mont, h_prime, next_challenge, timings), rc
 
 
-FIXED_KEY_BELOW = 1 << 17     # rounds with n <= this keep the key and fold per-base factors instead (pc_hip_ipa_key_scalars)
+# rounds with n <= this keep the key and fold per-base factors instead (pc_hip_ipa_key_scalars).  Round 6: 2^16 -- one more ladder fold
+# (2^16 elements: ~2 ms, its latency floor) buys 16 rounds of two 2^16-pair MSMs instead of 2^17-pair ones (0.85 against 1.05 ms per
+# round): 73.4 against 74.9 ms per opening at 2^22; a window table on the fixed key makes the rounds 0.70-0.76 ms but costs 7-8 ms to
+# build per opening (measured, dropped)
+FIXED_KEY_BELOW = 1 << 16
 
 
 def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, timings=None,
@@ -132,6 +136,12 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     with _T("fold_dots"):
         dots = ctx.ipa_fold_dots(curve, cptr, zptr, n)
     u_prev = None
+    # A resident committer key with a TWO-level fold table (pc_hip_srs_precompute_fold_ex): the key is not folded in round 1; round 2's
+    # commitments run on the committer key by linearity -- with K' = K_l + u1 K_r the key after one fold and q = n / 4,
+    #   MSM(K'[a .. a + q), s) = MSM(K[a .. a + q), s) + u1 MSM(K[a + 2q .. a + 3q), s)
+    # -- and the key after BOTH folds then comes out of the table in one step (pc_hip_ec_fold2_from)
+    two_level = resident and n >= 8 and n == srs.n and n // 2 > fixed_key_below and srs.fold_table_info()[0] == 2
+    u_first, root = None, srs
     while n > 1:
         h = n // 2
         t_round = time.perf_counter()
@@ -152,6 +162,23 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
                 if not many:
                     jl = srs.msm_async(alr.data_ptr(), n=n0, base_offset=0, montgomery=True)
                     jr = srs.msm_async(alr.data_ptr() + 32 * n0, n=n0, base_offset=0, montgomery=True)
+            elif u_first is not None:
+                # round 2 on the committer key (its window table serves it): by linearity, with q = h,
+                #   l = MSM(K[0 .. q), c_r) + u1 MSM(K[2q .. 3q), c_r) = MSM(K[0 .. 3q), (c_r | 0 | u1 c_r))
+                #   r = MSM(K[q .. 2q), c_l) + u1 MSM(K[3q .. 4q), c_l) = MSM(K[q .. 4q), (c_l | 0 | u1 c_l))
+                # two MSMs of 3q pairs, a third of them zero scalars (no bucket entries), instead of four of q with two host point
+                # multiplications and a fourth job queued behind the first on the key's three pipelines (measured: 5 ms more)
+                q = h
+                sc2 = torch.zeros((2, 3 * q, 4), dtype=torch.int64, device=coeffs_dev.device)
+                cv = coeffs_dev.view(-1, 4)
+                sc2[0, :q] = cv[q:2 * q]
+                sc2[1, :q] = cv[:q]
+                torch.cuda.synchronize()
+                u1row = np.ascontiguousarray(u_first, dtype=np.uint64).reshape(1, 4)
+                ctx.fr_lincomb(curve, [cptr + 32 * q], u1row, n_out=q, out=sc2[0, 2 * q:].data_ptr(), lens=[q])
+                ctx.fr_lincomb(curve, [cptr], u1row, n_out=q, out=sc2[1, 2 * q:].data_ptr(), lens=[q])
+                jl = srs.msm_async(sc2[0].data_ptr(), n=3 * q, base_offset=0, montgomery=True)
+                jr = srs.msm_async(sc2[1].data_ptr(), n=3 * q, base_offset=q, montgomery=True)
             else:
                 jl = srs.msm_async(cptr + 32 * h, n=h, base_offset=0, montgomery=True)
                 jr = srs.msm_async(cptr, n=h, base_offset=h, montgomery=True)
@@ -176,13 +203,21 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
         t_fold = time.perf_counter()
         with _T("ec_fold"):
             if n0:
-                u_prev = u                                                  # applied to the factors at the top of the next round
+                u_prev, kind = u, None                                      # applied to the factors at the top of the next round
+            elif two_level and u_first is None and srs is root:
+                u_first, kind = u, "deferred"                               # round 1: the key stays; round 2 runs on it as well
+            elif u_first is not None:
+                srs, owned = root.fold2_from(h, u_first, u), True           # round 2: the key after both folds, from the table
+                u_first, two_level, kind = None, False, "table2"
             elif owned:
                 srs.ec_fold(h, u)                                           # key_l += u key_r, normalised
+                kind = "ladder"
             else:
+                kind = "table1" if (srs.fold_table_info()[0] == 1 and srs.n == 2 * h) else "ladder"
                 srs, owned = srs.fold_from(h, u), True                      # the same fold, out of place: the committer key stays
-        if timings is not None and not n0:                                  # (blocking calls: wall time = the fold's kernels + launch)
+        if timings is not None and kind is not None:                        # (blocking calls: wall time = the fold's kernels + launch)
             timings.setdefault("ec_fold_per_round_ms", []).append((h, round((time.perf_counter() - t_fold) * 1e3, 3)))
+            timings.setdefault("ec_fold_kind", []).append(kind)
         if timings is not None:
             timings.setdefault("per_round_ms", []).append(round((time.perf_counter() - t_round) * 1e3, 3))
         n = h

@@ -11,7 +11,7 @@
 //!   h' * <..>     `pc_hip_point_mul` (one point, host -- as in the reference)
 //!   transcript    `serialize_uncompressed` + `compute_random_oracle_challenge`: the reference's own Rust, two points a round
 //!   folds         `pc_hip_ipa_fold_dots`: c_l += u^-1 c_r, z_l += u z_r + the next round's inner products, 64 bytes back `:691-697`
-//!   key fold      `pc_hip_ec_fold` (GLV ladder per element + batched normalisation) while n > 2^17; from there on the key
+//!   key fold      `pc_hip_ec_fold` (GLV ladder per element + batched normalisation) while n > 2^16; from there on the key
 //!                 stays FIXED and the folds act on per-base factors s_j (`pc_hip_ipa_key_scalars`): the round's MSMs run
 //!                 over the fixed key with scalars c * s, `final_comm_key = sum_j s_j K_j` is one last MSM -- the same
 //!                 points, bit for bit, without a latency-bound ladder pass per round                  `:699-707`
@@ -37,7 +37,7 @@ use crate::ffi;
 use crate::kzg10_hip::{msm, Scalars};
 
 /// Rounds with n at most this keep the key fixed (see the module doc); `PC_HIP_IPA_FIXED_KEY_BELOW` overrides.
-const FIXED_KEY_BELOW: usize = 1 << 17;
+const FIXED_KEY_BELOW: usize = 1 << 16;
 
 pub struct HipIpaPC<G: AffineRepr, D: Digest, P: DenseUVPolynomial<G::ScalarField>> {
     _projective: PhantomData<G>,
@@ -126,7 +126,10 @@ where
         }
         let mut guard = if off == 0 && resident.n == d1 {
             if d1 >= 2 && !resident.fold_table_built.swap(true, std::sync::atomic::Ordering::SeqCst) {
-                let _ = unsafe { ffi::pc_hip_srs_precompute_fold(c.raw, resident.srs) };      // OOM: the ladder fold stays in use
+                // ONE level (this loop folds round by round with pc_hip_ec_fold_from), digits as wide as the memory share allows (0):
+                // ~52 instead of ~86 table additions per element at width 4.  The two-level form (pc_hip_ec_fold2_from: rounds 1 and 2
+                // in one step, round 2's MSMs on the committer key -- poly_commit_amd/ipa.py) is the next step for this loop.
+                let _ = unsafe { ffi::pc_hip_srs_precompute_fold_ex(c.raw, resident.srs, 1, 0) };      // refused / OOM: the ladder fold stays in use
             }
             KeyGuard(resident.srs, false)
         } else {

@@ -12,6 +12,7 @@
 #include "../../poly_commit_amd/csrc/hash.hpp"
 #include "../../poly_commit_amd/csrc/glv.hpp"
 #include "../../poly_commit_amd/csrc/serialize.hpp"
+#include "../../poly_commit_amd/csrc/fold_table.hpp"
 
 struct CpuStepBackend {
   void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
@@ -67,6 +68,7 @@ struct CpuStepBackend {
   template <class B> void launch(const B& body, size_t lanes) {
     for (size_t i = 0; i < lanes; i++) body((uint32_t)i);
   }
+  template <class B> void launch(const B& body, size_t lanes, int) { launch(body, lanes); }
 };
 
 template <class C>
@@ -535,3 +537,31 @@ extern "C" void emu_glv_lambda(int curve, uint64_t* out) {
     case 2: memcpy(out, pc_glv_pallas::LAMBDA, 32); break;
   }
 }
+
+// the fold table of an IPA committer key (fold_table.hpp): built for `levels` folds and width-w NAF digits over key[n >> levels .. n), then
+// the fold(s) out of it -- one term (u1) or three (u2, u1, u1 u2) -- exactly the calls pc_hip_srs_precompute_fold_ex / pc_hip_ec_fold_from /
+// pc_hip_ec_fold2_from make.  Returns 0 if the split did not fit the table (the library then takes the ladder).
+template <class C>
+static int fold_table(const uint32_t* key, uint32_t n, uint32_t levels, uint32_t w, const uint32_t* u1_mont, const uint32_t* u2_mont, uint32_t* out) {
+  typedef pc::Fd<typename C::FrP> Fr;
+  constexpr int AW = 2 * C::FqP::N;
+  const size_t q = n >> levels, pts = n - q;
+  std::vector<uint32_t> table(((size_t)pc::FOLD_ROWS << (w - 2)) * pts * AW, 0xabababab);
+  CpuStepBackend be;
+  pc::fold_table_build_run<C>(be, key + q * AW, pts, w, table.data());
+  uint32_t u12[C::FrP::N];
+  Fr::load(u1_mont).mul(Fr::load(u2_mont)).store(u12);
+  const uint32_t* us1[1] = {u1_mont};
+  const uint32_t* us3[3] = {u2_mont, u1_mont, u12};
+  return pc::ec_fold_table_run<C>(be, key, out, q, pts, levels == 2 ? 3u : 1u, levels == 2 ? us3 : us1, w, table.data()) ? 1 : 0;
+}
+extern "C" int emu_fold_table(int curve, const uint32_t* key, uint32_t n, uint32_t levels, uint32_t w, const uint32_t* u1_mont, const uint32_t* u2_mont,
+                              uint32_t* out) {
+  switch (curve) {
+    case 0: return fold_table<pc_curve_bls12_381>(key, n, levels, w, u1_mont, u2_mont, out);
+    case 1: return fold_table<pc_curve_bn254>(key, n, levels, w, u1_mont, u2_mont, out);
+    case 2: return fold_table<pc_curve_pallas>(key, n, levels, w, u1_mont, u2_mont, out);
+  }
+  return -1;
+}
+extern "C" int emu_wnaf(const uint32_t* k5, int w, int8_t* out200) { return pc::wnaf_digits(k5, w, out200); }

@@ -24,7 +24,7 @@ def emu():
     if _emu is None:
         so = os.path.join(HERE, "emu", "libemu.so")
         srcs = [os.path.join(HERE, "emu", "emu_msm.cpp")] + [
-            os.path.join(HERE, "..", "poly_commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp", "ipa.hpp", "glv.hpp", "serialize.hpp")]
+            os.path.join(HERE, "..", "poly_commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp", "ipa.hpp", "glv.hpp", "serialize.hpp", "fold_table.hpp")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
         _emu = C.CDLL(so)
@@ -691,3 +691,50 @@ def test_msm_in_parts_stepped(curve):
     assert (run(part, 8, 0, 4, base_off=60) == O.msm_naive(curve, b[60:], part)).all()
     assert (run(O.f_to_mont(curve, 1, uni), 6, 1, 3, from_mont=1) == O.msm_naive(curve, b, uni)).all()
     assert not run(np.zeros((n, 4), dtype=np.uint64), 7, 0, 3).any()
+
+
+# ---- the fold table of an IPA committer key in its general form (csrc/fold_table.hpp, glv.hpp) ----------------------------------------
+@pytest.mark.parametrize("w", [2, 3, 4, 5])
+def test_wnaf_digits(w):
+    """Width-w NAF of 160-bit magnitudes: the digits rebuild the value, are odd and below 2^(w-1), and no two non-zero digits sit within
+    w positions of each other (what bounds the additions per term at 130 / (w + 1))."""
+    rnd = random.Random(w)
+    vals = [0, 1, 2, 3, (1 << 130) - 1, 1 << 129, (1 << 128) + 1, 0xAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA] + [rnd.getrandbits(rnd.choice([8, 64, 128, 130])) for _ in range(200)]
+    for v in vals:
+        k = np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range(5)], dtype=np.uint32)
+        out = np.zeros(200, dtype=np.int8)
+        ln = emu().emu_wnaf(p32(k), w, out.ctypes.data_as(C.POINTER(C.c_int8)))
+        assert sum(int(d) << i for i, d in enumerate(out)) == v
+        nz = [i for i, d in enumerate(out) if d]
+        assert all(int(out[i]) % 2 and abs(int(out[i])) < (1 << (w - 1)) for i in nz)
+        assert all(b - a >= w for a, b in zip(nz, nz[1:]))
+        assert ln == (nz[-1] + 1 if nz else 0) and ln <= 131
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("levels,w", [(1, 2), (1, 4), (2, 2), (2, 3), (2, 4)])
+def test_fold_table_one_and_two_levels(curve, levels, w):
+    """Table build (affine doublings, odd multiples by affine additions) + the fold out of it, stepped on the CPU, against Python big
+    ints: one level = K[i] + u1 K[h + i]; two levels = the key after the folds by u1 and by u2 (ipa_pc/mod.rs:699-707 twice), i.e.
+    K[i] + u2 K[q + i] + u1 K[2q + i] + u1 u2 K[3q + i].  A point at infinity sits in every quarter of the key."""
+    fr = R.CURVES[curve]["fr"]
+    p = R.FIELDS[fr]["p"]
+    n = 16
+    pts = R.gen_bases(curve, n + 3)[3:]
+    for j in (1, 6, 9, 15):
+        pts[j] = None
+    key = O.points_to_array(curve, pts)
+    u1, u2 = R.gen_scalars(fr, 0xF01D + levels, 2)
+    out = np.zeros((n >> levels, key.shape[1]), dtype=np.uint64)
+    um = O.fr_mont_array(curve, [u1, u2])
+    ok = emu().emu_fold_table(O.CURVES[curve], p32(key.view(np.uint32)), n, levels, w, p32(um[0].view(np.uint32)), p32(um[1].view(np.uint32)),
+                              p32(out.view(np.uint32)))
+    assert ok == 1
+    got = O.array_to_points(curve, out)
+    h = n // 2
+    k1 = [R.ec_add(curve, pts[i], R.ec_mul(curve, u1, pts[h + i])) for i in range(h)]
+    if levels == 1:
+        assert got == k1
+    else:
+        q = n // 4
+        assert got == [R.ec_add(curve, k1[i], R.ec_mul(curve, u2, k1[q + i])) for i in range(q)]

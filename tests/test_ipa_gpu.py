@@ -70,6 +70,70 @@ def test_ipa_open_rounds_on_a_resident_key(ctx, curve, n, fkb, tables):
     srs.free()
 
 
+@pytest.mark.parametrize("curve,n,fkb,levels,w", [("pallas", 1 << 13, 64, 2, 2), ("pallas", 1 << 13, 64, 2, 3), ("pallas", 1 << 13, 64, 2, 4),
+                                                  ("pallas", 1 << 12, 1 << 10, 2, 4), ("pallas", 1 << 12, 1 << 11, 2, 4), ("bn254", 1 << 11, 16, 2, 3),
+                                                  ("bls12_381", 1 << 10, 16, 2, 4), ("bls12_381", 1 << 10, 16, 1, 4), ("pallas", 1 << 12, 0, 1, 3),
+                                                  ("pallas", 8, 0, 2, 4), ("pallas", 1 << 16, None, 0, 0)])
+def test_ipa_open_rounds_with_the_general_fold_table(ctx, curve, n, fkb, levels, w):
+    """pc_hip_srs_precompute_fold_ex: the fold table in its general form.  Two levels: round 1 leaves the key alone, round 2's four MSMs run
+    on the committer key (linearity), pc_hip_ec_fold2_from then gives the key after both folds out of the table (width-w NAF digits,
+    three terms).  One level with wider digits: the first fold as before with fewer additions.  levels = w = 0: the library's choice.
+    Infinities sit in all four quarters of the key; two openings in a row on the same resident key; every proof bit for bit the oracle's
+    (which folds the key round by round, ipa_pc/mod.rs:699-707); the committer key itself is untouched."""
+    import torch
+    from poly_commit_amd import ipa
+    lg = n.bit_length() - 1
+    key = O.gen_bases(curve, n + 1)
+    for j in (1, n // 4 + 2, n // 2 + 3, 3 * n // 4 + 1):
+        key[j] = 0
+    comm_key, h_prime = np.ascontiguousarray(key[:n]), key[n]
+    srs = ctx.upload_srs(curve, comm_key)
+    srs.precompute(min_pairs=1)
+    srs.precompute_fold(levels, w)
+    got_levels, got_w = srs.fold_table_info()
+    assert (got_levels, got_w) == (levels, w) if levels else (got_levels == 2 and 2 <= got_w <= 4)
+    rows = 131 << (got_w - 2)
+    assert srs.bytes_resident()["fold_table"] == rows * (n - (n >> got_levels)) * comm_key.shape[1] * 8
+    before = srs.read(0, n).copy()
+    for rep in range(2):
+        coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE + rep, n))
+        point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B + rep, 1))[0]
+        ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1 + rep, lg))
+        want_l, want_r, want_key, want_c = O.ipa_rounds(curve, comm_key, coeffs, point, np.ascontiguousarray(h_prime), ch)
+        it = iter(range(lg))
+        cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+        tm = {}
+        l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, timings=tm)
+        assert (l == want_l).all() and (r == want_r).all() and (fk == want_key).all() and (c == want_c).all()
+        kinds = tm.get("ec_fold_kind", [])
+        limit = ipa.FIXED_KEY_BELOW if fkb is None else fkb
+        if got_levels == 2 and n // 2 > limit:
+            assert kinds[:2] == ["deferred", "table2"], kinds
+        elif got_levels == 1 and n > limit:
+            assert kinds[0] == "table1", kinds
+    assert (srs.read(0, n) == before).all()
+    srs.free()
+
+
+def test_fold2_from_without_a_two_level_table_is_the_two_folds(ctx):
+    """pc_hip_ec_fold2_from on a key with no table / a one-level table: the two folds one after the other, the same key as two calls."""
+    curve, n = "pallas", 1 << 10
+    key = np.ascontiguousarray(O.gen_bases(curve, n))
+    u = O.f_to_mont(curve, 1, O.gen_scalars(curve, 77, 2))
+    srs = ctx.upload_srs(curve, key)
+    want = srs.fold_from(n // 2, u[0])
+    want.ec_fold(n // 4, u[1])
+    ref = want.read(0, n // 4).copy()
+    want.free()
+    for form in (None, (1, 3), (2, 2)):
+        if form:
+            srs.precompute_fold(*form)
+        k2 = srs.fold2_from(n // 4, u[0], u[1])
+        assert (k2.read(0, n // 4) == ref).all(), form
+        k2.free()
+    srs.free()
+
+
 def _open_inputs(curve, n, k=2):
     key = O.gen_bases(curve, n + 1)
     comm_key, h = np.ascontiguousarray(key[:n]), np.ascontiguousarray(key[n])

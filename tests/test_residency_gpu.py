@@ -71,7 +71,8 @@ print("fold bytes", before)
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, PC_HIP_FOLD_TABLE_MAX_FRAC="0.00000001"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "refused" in r.stdout and "fold bytes 0" in r.stdout, r.stdout + r.stderr[-2000:]
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "built" in r.stdout and "fold bytes %d" % (131 * (1 << 11) * 64) in r.stdout, r.stdout + r.stderr[-2000:]
+    # (2^12 points: one level; the library's choice of digit width is the widest, 4: 4 x 131 rows of the upper half)
+    assert r.returncode == 0 and "built" in r.stdout and "fold bytes %d" % (4 * 131 * (1 << 11) * 64) in r.stdout, r.stdout + r.stderr[-2000:]
 
 
 def _child(code, env=None, timeout=600):

@@ -18,8 +18,10 @@ coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE, n))
 point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B, 1))[0]
 ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, log_n))
 srs = ctx.upload_srs(curve, np.ascontiguousarray(key[:n]))
-if os.environ.get("PC_IPA_TABLES", "1") != "0":        # once per committer key: window table + fold table of the upper half
+t_tables = time.perf_counter()
+if os.environ.get("PC_IPA_TABLES", "1") != "0":        # once per committer key: window table + fold table
     srs.precompute(); srs.precompute_fold()
+t_tables = time.perf_counter() - t_tables
 cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
 torch.cuda.synchronize()
 for _ in range(3):      # every pipeline of the SRS exists (streams + workspace are created on first use)
@@ -38,11 +40,13 @@ for rep in range(int(os.environ.get("PC_IPA_REPS", "3"))):
     t_open = time.perf_counter() - t
     per_round = tm.pop("per_round_ms", [])
     tm.pop("ec_fold_per_round_ms", None)
+    kinds = tm.pop("ec_fold_kind", None)
     runs.append((t_open, tm, per_round))
 first = runs[0][0]
 t_open, tm, per_round = min(runs, key=lambda r: r[0])
 print(json.dumps({"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: commit MSM + {log_n} halving rounds (challenges supplied)",
                   "commit_ms": t_commit * 1e3, "open_rounds_ms": t_open * 1e3, "first_open_rounds_ms": first * 1e3, "openings": len(runs),
                   "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open, "fixed_key_below": fkb or ipa.FIXED_KEY_BELOW,
-                  "key_tables": os.environ.get("PC_IPA_TABLES", "1") != "0",
+                  "key_tables": os.environ.get("PC_IPA_TABLES", "1") != "0", "fold_table": list(srs.fold_table_info()) + [srs.bytes_resident()["fold_table"]],
+                  "key_tables_build_ms": t_tables * 1e3,
                   "open_breakdown_ms": {k: round(v, 1) for k, v in tm.items()}, "per_round_ms": per_round}))
