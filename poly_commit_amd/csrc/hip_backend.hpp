@@ -204,9 +204,18 @@ struct HipBackend {
   }
   void aux_begin(int wait_a, int wait_b) {      // everything queued until aux_end() goes to the auxiliary queue, after the two tokens
     if (!aux_stream) PC_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
-    aux_saved = stream; stream = aux_stream;
     if (wait_a >= 0) PC_HIP_CHECK(hipStreamWaitEvent(aux_stream, tok_ev[wait_a], 0));
     if (wait_b >= 0) PC_HIP_CHECK(hipStreamWaitEvent(aux_stream, tok_ev[wait_b], 0));
+    aux_saved = stream; stream = aux_stream;      // LAST: a failing wait above must not leave the backend on the auxiliary queue (the callers' scope guards are built after this call)
+  }
+  // a call that failed half way (between the parts of an MSM in parts): nothing of it may still run when the pipeline is used again
+  void quiesce() {
+    if (aux_saved) { stream = aux_saved; aux_saved = nullptr; }
+    if (tail_stream) stream = main_stream;
+    if (aux_stream) (void)hipStreamSynchronize(aux_stream);
+    if (tail_stream) (void)hipStreamSynchronize(tail_stream);
+    (void)hipStreamSynchronize(stream);
+    (void)hipGetLastError();
   }
   int aux_end() { stream = aux_saved; aux_saved = nullptr; return new_token(aux_stream); }      // (the main queue is back before anything can throw)
   void wait_token(int t) { if (t >= 0) PC_HIP_CHECK(hipStreamWaitEvent(stream, tok_ev[t], 0)); }

@@ -971,8 +971,10 @@ class MsmPlan {
     // (only while the reductions are a sizeable share of the MSM: 20-30 % faster steps up to 2^18, 10-15 % at
     // 2^20, but 8 % slower at 2^21 and beyond, where a delayed reduction stalls the caller's pipeline)
     const bool tail_queue = !in_parts_ && n <= ((size_t)3 << 19);
-    if (tail_queue) be_.begin_tail();
-    tail_open_ = tail_queue;
+    // (a throw in the launches below must not leave the backend on its low-priority queue: the guard hands the open tail over to
+    // reduce_and_download -- tail_open_ -- only once they are all queued)
+    struct TailGuard { Backend& b; bool armed; ~TailGuard() { if (armed) b.end_tail(); } } tail_guard{be_, false};
+    if (tail_queue) { be_.begin_tail(); tail_guard.armed = true; }
     size_t slots = 2 * lanes; uint32_t level = 1; int cur = 0;
     for (;;) {
       size_t lanes2 = ceil_div_u32(slots, level == 1 ? g.T2 : g.T2b);
@@ -991,6 +993,7 @@ class MsmPlan {
       parts_k_++;
     }
     last_g_ = g;
+    tail_open_ = tail_queue; tail_guard.armed = false;
   }
 
   void reduce_and_download() {
@@ -1058,6 +1061,13 @@ class MsmPlan {
       return;
     }
     if (pending_empty_) { for (int i = 0; i < AW; i++) out_host[i] = 0; return; }
+    if (in_parts_) {
+      // a call in parts that never reached its last part (a failure between two parts): there is no result to wait for -- result_host_
+      // is the previous call's -- and work of the parts that were queued may still run on the main and auxiliary queues
+      be_.quiesce();
+      in_parts_ = false; tail_open_ = false;
+      throw std::runtime_error("MsmPlan: a call in parts was abandoned before its last part");
+    }
     be_.wait_done();
     host_tail(out_host);
   }

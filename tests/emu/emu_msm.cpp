@@ -29,6 +29,7 @@ struct CpuStepBackend {
   void record_done() {}
   void begin_tail() {}
   void end_tail() {}
+  void quiesce() {}
   void wait_done() {}
   void* alloc_host(size_t b) { return calloc(1, b ? b : 1); }
   void free_host(void* p) { if (p) ::free(p); }
