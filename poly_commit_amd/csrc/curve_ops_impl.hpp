@@ -13,13 +13,14 @@
 
 namespace pc {
 
-// One MSM pipeline.  With PC_HIP_GRAPHS=1 a call that repeats an earlier one exactly (same resident bases, same device
-// scalar buffer, same length -- the late rounds of an IPA opening, a prover that keeps its buffers) replays the ~25
-// launches of the MSM from a captured hipGraph: the first occurrence runs normally (it also grows every lazily sized
-// workspace), the second is captured, later ones are one hipGraphLaunch.  Off by default: measured on one box, it
-// changed nothing (2^20 commit+open 5.79-5.82 vs 5.81-5.84 ms, blocking MSM 3.86 vs 3.85 ms, Pallas IPA open 126.3 vs
-// 126.6 ms) -- the launches are issued asynchronously behind running kernels, and the six (pipeline, buffer) pairs of an
-// IPA's late rounds pay one capture + instantiation each for three or four replays.
+// One MSM pipeline.  A call that repeats an earlier one exactly (same resident bases, same device scalar buffer, same length -- the
+// late rounds of an IPA opening, a prover that keeps its buffers) replays the ~25 launches of the MSM from a captured hipGraph: the
+// first occurrence runs normally (it also grows every lazily sized workspace), the second is captured, later ones are one
+// hipGraphLaunch.  On for calls of at most 2^18 pairs (PC_HIP_GRAPHS=0: never, =1: every size): there the host-side cost of queueing
+// the launches IS the latency -- a kernel trace of the fixed-key rounds of a Pallas opening showed the second MSM of a round starting
+// 160 us after the first (the time the host takes to queue 14 launches) in a round of 970 us; with replays the 16 rounds take 13.8
+// instead of 16.2 ms (open 62.0 against 65.5 ms at 2^22).  Large calls gain nothing (2^20 commit+open 5.79-5.82 vs 5.81-5.84 ms:
+// their launches are issued behind running kernels) and stay on plain launches.
 template <class C>
 struct MsmRunnerT : MsmRunner {
   HipBackend& be;
@@ -28,15 +29,19 @@ struct MsmRunnerT : MsmRunner {
     const uint32_t* bases; uint32_t base_off; const uint32_t* scalars; size_t n; bool from_mont;
     bool operator==(const CallKey& o) const { return bases == o.bases && base_off == o.base_off && scalars == o.scalars && n == o.n && from_mont == o.from_mont; }
   };
-  struct GraphSlot { CallKey key; int seen = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; uint64_t stamp = 0; };
+  // epoch: the backend's free_epoch when the graph was captured; plain_epoch: after the key's last plain run (which sized every scratch
+  // buffer for it) -- a capture is only attempted while nothing was freed since, i.e. while it cannot meet an allocation
+  struct GraphSlot { CallKey key; int seen = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; uint64_t stamp = 0; uint64_t epoch = 0, plain_epoch = ~0ull; };
   static constexpr int GRAPH_SLOTS = 4;
   GraphSlot slots[GRAPH_SLOTS];
   uint64_t clock = 0;
   bool graphs_on;
+  size_t graph_max_n;
   hipEvent_t join_ev = nullptr;
   MsmRunnerT(HipBackend& b, size_t n, const MsmConfig& cfg, uint32_t subs = 0) : be(b), plan(b, n, cfg, subs) {
     const char* e = getenv("PC_HIP_GRAPHS");
-    graphs_on = e && !strcmp(e, "1") && subs == 0;
+    graphs_on = subs == 0 && !(e && !strcmp(e, "0"));
+    graph_max_n = (e && !strcmp(e, "1")) ? (size_t)-1 : (size_t)1 << 18;
   }
   ~MsmRunnerT() override {
     for (auto& s : slots) drop(s);
@@ -49,7 +54,13 @@ struct MsmRunnerT : MsmRunner {
   }
   GraphSlot* slot_for(const CallKey& k) {
     GraphSlot* lru = &slots[0];
-    for (auto& s : slots) { if (s.seen && s.key == k) return &s; if (s.stamp < lru->stamp) lru = &s; }
+    for (auto& s : slots) {
+      if (s.seen && s.key == k) {
+        if (s.exec && s.epoch != be.free_epoch) { drop(s); s.key = k; }      // a buffer the graph may point into was freed since: start over
+        return &s;
+      }
+      if (s.stamp < lru->stamp) lru = &s;
+    }
     drop(*lru); lru->key = k;
     return lru;
   }
@@ -69,8 +80,13 @@ struct MsmRunnerT : MsmRunner {
     hipGraph_t g = nullptr;
     if (hipStreamEndCapture(origin, &g) != hipSuccess || !g) { (void)hipGetLastError(); ok = false; }
     if (ok && hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); s.exec = nullptr; ok = false; }
-    if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
-    s.graph = g;
+    if (!ok) {
+      if (g) (void)hipGraphDestroy(g);
+      be.stream = origin;
+      try { be.replace_capturing_streams(); } catch (...) {}      // a queue left in capture mode would refuse the plain launches that follow
+      return false;
+    }
+    s.graph = g; s.epoch = be.free_epoch;
     return true;
   }
   void enqueue(const uint32_t* bases, uint32_t base_off, const void* scalars, pc_mem where, size_t n, bool from_mont) override {
@@ -80,10 +96,10 @@ struct MsmRunnerT : MsmRunner {
       be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
       sdev = plan.scalar_staging();
     }
-    if (graphs_on && !be.timing && where == PC_MEM_DEVICE && n >= 32) {
+    if (graphs_on && !be.timing && where == PC_MEM_DEVICE && n >= 32 && n <= graph_max_n) {
       GraphSlot* s = slot_for(CallKey{bases, base_off, sdev, n, from_mont});
       s->stamp = ++clock;
-      if (s->seen >= 1 && !s->exec && !capture(*s, bases, base_off, sdev, n, from_mont)) graphs_on = false;   // this runner stays on plain launches
+      if (s->seen >= 1 && !s->exec && s->plain_epoch == be.free_epoch && !capture(*s, bases, base_off, sdev, n, from_mont)) graphs_on = false;   // this runner stays on plain launches
       if (s->exec) {
         plan.prepare_replay(n);
         PC_HIP_CHECK(hipGraphLaunch(s->exec, be.stream));
@@ -92,6 +108,9 @@ struct MsmRunnerT : MsmRunner {
         return;
       }
       s->seen++;
+      plan.enqueue(bases, base_off, sdev, n, from_mont);
+      s->plain_epoch = be.free_epoch;      // whatever this run had to grow is grown: the next occurrence may be captured
+      return;
     }
     plan.enqueue(bases, base_off, sdev, n, from_mont);
   }

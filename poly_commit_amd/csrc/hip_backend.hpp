@@ -158,6 +158,7 @@ struct HipBackend {
       if (const char* e = getenv("PC_HIP_MAIN_PRIO")) main_prio = !strcmp(e, "hi") ? hi : !strcmp(e, "lo") ? lo : 0;
       PC_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, main_prio));
       PC_HIP_CHECK(hipStreamCreateWithPriority(&tail_stream, hipStreamNonBlocking, tail_prio));
+      main_prio_ = main_prio; tail_prio_ = tail_prio;
       PC_HIP_CHECK(hipEventCreateWithFlags(&tail_ev, hipEventDisableTiming));
       main_stream = stream;
     } else {
@@ -166,6 +167,28 @@ struct HipBackend {
     for (int i = 0; i < MAX_EV; i++) PC_HIP_CHECK(hipEventCreate(&ev[i]));
     PC_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
+  // After a stream capture that did not end cleanly (curve_ops_impl.hpp: a captured call that threw): a queue the runtime still
+  // counts as capturing refuses every further launch ("operation failed due to a previous error during capture").  Such a queue
+  // is replaced; its real work, if any, finishes on the old one (hipStreamDestroy releases it when idle).
+  void replace_capturing_streams() {
+    auto stuck = [](hipStream_t q) {
+      if (!q) return false;
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      const hipError_t e = hipStreamIsCapturing(q, &st);
+      (void)hipGetLastError();
+      return e != hipSuccess || st != hipStreamCaptureStatusNone;
+    };
+    if (!tail_split) return;
+    if (stuck(tail_stream)) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; PC_HIP_CHECK(hipStreamCreateWithPriority(&tail_stream, hipStreamNonBlocking, tail_prio_)); }
+    if (stuck(main_stream)) {
+      const bool on_main = stream == main_stream;
+      (void)hipStreamDestroy(main_stream); main_stream = nullptr;
+      PC_HIP_CHECK(hipStreamCreateWithPriority(&main_stream, hipStreamNonBlocking, main_prio_));
+      if (on_main) stream = main_stream;
+    }
+    if (stream != main_stream && stream != tail_stream && stream != aux_stream) stream = main_stream;
+  }
+  int main_prio_ = 0, tail_prio_ = 0;
   void destroy() {
     trim();
     for (int i = 0; i < MAX_EV; i++) (void)hipEventDestroy(ev[i]);
@@ -223,7 +246,12 @@ struct HipBackend {
 
   size_t bytes_live = 0;      // device bytes currently allocated through THIS backend (a pipeline's workspace, a context's buffers)
   void* alloc(size_t bytes) { void* p = nullptr; PC_HIP_CHECK(dev_malloc(&p, bytes ? bytes : 4)); bytes_live += bytes ? bytes : 4; return p; }
-  void free(void* p) { if (p) bytes_live -= dev_free(p); }
+  void free(void* p) { if (p) { bytes_live -= dev_free(p); free_epoch++; } }
+  // bumped by every device free through this backend: a captured hipGraph (curve_ops_impl.hpp) holds the addresses of the grow-only
+  // scratch buffers (sort, scan, workspace) as they were at capture time; once ANY of them was given back the graph must not be
+  // replayed (round 6: a memory access fault in the second opening of a process, where the pipelines meet other call sizes in
+  // another order and the sort scratch of one grew after a smaller call had been captured on it)
+  uint64_t free_epoch = 0;
   // Grow-only scratch for the short kernels of one call (division scan levels): hipMalloc/hipFree per
   // call would synchronise the whole device and drain the MSM pipelines running on other streams.
   void* workspace(size_t bytes) {

@@ -484,6 +484,35 @@ def test_msm_repeated_call_through_captured_graph(monkeypatch):
     ctx.close()
 
 
+def test_msm_graph_replay_survives_a_growing_scratch_buffer():
+    """Calls of at most 2^18 pairs on device scalars replay a captured hipGraph from their third occurrence on (the library's default).
+    A captured graph holds the addresses of the pipeline's grow-only scratch as they were; a LARGER call on the same pipeline then
+    reallocates that scratch.  Round 6: the replay after it read freed memory (a GPU memory access fault in the second IPA opening of
+    a process).  Now every device free on the pipeline invalidates its graphs: small, small, small on each of the three pipelines,
+    then a large call on each, then the small ones again -- all results the oracle's."""
+    import torch
+    import poly_commit_amd as pc
+    ctx = pc.Context(0)
+    curve, n_small, n_big = "pallas", 3000, 1 << 16
+    bases = O.gen_bases(curve, n_big)
+    sc_small, sc_big = O.gen_scalars(curve, 0x6B0, n_small), O.gen_scalars(curve, 0x6B1, n_big)
+    want_small = O.msm_pippenger(curve, np.ascontiguousarray(bases[:n_small]), sc_small, 8, 1)
+    want_big = O.msm_pippenger(curve, bases, sc_big, 8, 1)
+    d_small = torch.from_numpy(sc_small.view(np.int64).copy()).cuda()
+    d_big = torch.from_numpy(sc_big.view(np.int64).copy()).cuda()
+    srs = ctx.upload_srs(curve, bases)
+    for rep in range(3):
+        for _ in range(9):                    # three pipelines in rotation: plain, captured, replayed on each
+            assert (srs.msm(d_small.data_ptr(), n=n_small)[0] == want_small).all()
+        for _ in range(3):                    # every pipeline's sort scratch grows
+            assert (srs.msm(d_big.data_ptr(), n=n_big)[0] == want_big).all()
+        for _ in range(7):                    # (7: the rotation shifts, so that across the repetitions every pipeline meets both sizes in both orders)
+            assert (srs.msm(d_small.data_ptr(), n=n_small)[0] == want_small).all()
+        ctx.trim()                            # idle pipelines give their scratch back: the graphs must go with it
+    srs.free()
+    ctx.close()
+
+
 def test_msm_randomised_differential():
     """tools/msm_fuzz.py for a few seconds: random sizes / chunk lengths / window widths / tables / scalar distributions on all three
     curves against the oracle (6000 cases in 150 s without a mismatch on the round-3 library; this keeps ~400 of them in the suite)."""

@@ -13,6 +13,8 @@ fkb = (1 << int(sys.argv[2])) if len(sys.argv) > 2 else None        # log2 of th
 curve = "pallas"
 n = 1 << log_n
 ctx = pc.Context(0)
+if os.environ.get("PC_IPA_C"):          # window width of the table-free MSMs (rounds 3+), experiment switch
+    ctx.set_msm_tuning(int(os.environ["PC_IPA_C"]), 0)
 key = O.gen_bases(curve, n + 1)
 coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xA11CE, n))
 point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B, 1))[0]
