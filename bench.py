@@ -1755,7 +1755,7 @@ def main():
                 elif name == "batch":
                     workloads[name] = batch_case(ctx, D, args, 14 if small else 20, 8 if small else args.polys, 3, 1)
                 elif name == "ipa":
-                    workloads[name] = ipa_case(ctx, 14 if small else 22, 2, with_cpu=not args.no_cpu_baseline)
+                    workloads[name] = ipa_case(ctx, 14 if small else 22, 2 if small else 5, with_cpu=not args.no_cpu_baseline)
                 elif name == "ligero":
                     workloads[name] = ligero_case(ctx, D, curve, 16 if small else 24, 5 if small else 20, 2, with_cpu=not args.no_cpu_baseline, with_trait=not args.no_trait)
                 else:

@@ -2,10 +2,11 @@
 # Copies the summaries of one tools/gpu_full_run.sh call (gpurun_out/d_*) into profiles/<round>_* (tracked).  usage: collect_profiles.sh r05
 set -e
 cd "$(dirname "$0")/.."
-P=${1:-r05}
+P=${1:-r06}
 G=gpurun_out
 cp $G/d_microbench.txt profiles/${P}_microbench.txt
 for f in bench_n1 bench_n1_inflight0 bench_n1_notable bench_n1_glv bench_ntt bench_rccl_1rank bench_2ranks_dev0 bench_8ranks_dev0 group_host group_device; do [ -f $G/d_$f.json ] && cp $G/d_$f.json profiles/${P}_$f.json; done
+[ -f $G/d_bench_n1_line.json ] && cp $G/d_bench_n1_line.json profiles/${P}_bench_n1_line.json      # the line the driver parses (<= 6 KB); ${P}_bench_n1.json is the full record it points at
 cp $G/d_bench_batch.json profiles/${P}_bench_batch_bn254.json
 cp $G/d_ipa_2p22.json profiles/${P}_ipa_pallas_2p22.json
 cp $G/d_lincomb.json profiles/${P}_lincomb_bn254.json
