@@ -513,6 +513,17 @@ def test_msm_graph_replay_survives_a_growing_scratch_buffer():
     ctx.close()
 
 
+def test_msm_graph_path_randomised_differential():
+    """tools/graph_fuzz.py for a few seconds: resident buffers and call shapes repeated in random order on one key (plain, captured,
+    replayed on every pipeline), with growing scratch, pc_hip_ctx_trim, table builds and in-place key folds in between (21 442 cases with
+    11 176 repeats in 150 s without a mismatch on the round-6 library)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_fuzz.py"), "12", "20260930"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
+
+
 def test_msm_randomised_differential():
     """tools/msm_fuzz.py for a few seconds: random sizes / chunk lengths / window widths / tables / scalar distributions on all three
     curves against the oracle (6000 cases in 150 s without a mismatch on the round-3 library; this keeps ~400 of them in the suite)."""
