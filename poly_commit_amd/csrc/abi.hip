@@ -1574,12 +1574,24 @@ int pc_hip_srs_precompute_fold_ex(pc_ctx* ctx, pc_srs* srs, unsigned levels, uns
     size_t free_b = 0, total_b = 0;
     PC_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     auto bytes_of = [&](unsigned L, unsigned w) { return ((size_t)ops.fold_rows << (w - 2)) * (srs->n - (srs->n >> L)) * pb; };
-    unsigned L = levels, w = naf_width;
-    if (!L) L = (srs->n >= ((size_t)1 << 16) && !(srs->n & 3)) ? 2u : 1u;
-    if (!w) { w = 4; while (w > 2 && (double)bytes_of(L, w) > frac * (double)free_b) w--; }
-    if (!levels && L == 2 && (double)bytes_of(L, w) > frac * (double)free_b) L = 1;
-    const size_t need = bytes_of(L, w);
-    if ((double)need > frac * (double)free_b) {
+    // the forms in the order of the opening times measured on a 2^22-point Pallas key (EXPERIMENTS 00): (2,4) 63.6 ms, (2,3) 66.8,
+    // (1,4) 69.6, (2,2) 70.9, (1,3), (1,2) 73.7; the first one the caller's choice allows and the memory share holds
+    static const unsigned order[6][2] = {{2, 4}, {2, 3}, {1, 4}, {2, 2}, {1, 3}, {1, 2}};
+    const bool two_ok = srs->n >= ((size_t)1 << 16) && !(srs->n & 3);      // (below 2^16 points the second fold is a latency-bound ladder either way)
+    unsigned L = 0, w = 0; size_t need = 0;
+    for (const auto& f : order) {
+      if (levels ? f[0] != levels : (f[0] == 2 && !two_ok)) continue;
+      if (naf_width && f[1] != naf_width) continue;
+      need = bytes_of(f[0], f[1]);
+      if ((double)need <= frac * (double)free_b) { L = f[0]; w = f[1]; break; }
+    }
+    if (!L && naf_width == 5)      // width 5 (43 additions per term, twice the rows of width 4) only on request
+      for (unsigned l : {2u, 1u}) {
+        if (levels ? l != levels : (l == 2 && !two_ok)) continue;
+        need = bytes_of(l, 5);
+        if ((double)need <= frac * (double)free_b) { L = l; w = 5; break; }
+      }
+    if (!L) {
       ctx->last_error = "fold table of " + std::to_string(need >> 20) + " MiB exceeds " + std::to_string(frac) + " of the free device memory (" + std::to_string(free_b >> 20) + " MiB)";
       return (int)PC_ERR_UNSUPPORTED;
     }

@@ -36,7 +36,8 @@ bool ec_fold_table_run(Backend& be, const uint32_t* key_lo, uint32_t* out, size_
         const uint32_t mag = (uint32_t)(dg[bit] < 0 ? -dg[bit] : dg[bit]);          // odd, < 2^(w-1)
         const uint32_t row = (mag >> 1) * FOLD_ROWS + (uint32_t)bit;
         const bool negate = (dg[bit] < 0) != (sgn != 0);
-        ops.push_back(Op{row, (uint16_t)(row | (t << 10) | (which ? 0x4000u : 0u) | (negate ? 0x8000u : 0u))});
+        if (row > 0x7ffu) return false;
+        ops.push_back(Op{row, (uint16_t)(row | (t << 11) | (which ? 0x4000u : 0u) | (negate ? 0x8000u : 0u))});
       }
     }
   }

@@ -228,7 +228,7 @@ struct AffineAddRowBody {
 
 // out_xyzz[i] = K[i] + sum of the listed table entries.  The table holds, for the `row_pts` key points it covers, FOLD_ROWS rows per
 // odd multiple d = 1, 3, .., 2^(w-1) - 1:  T[(d >> 1) * FOLD_ROWS + b][j] = d * 2^b * P_j.  An op names one entry for lane i:
-//   bits 0..9 row, bits 10..11 term (the entry is at point term * count + i of its row), bit 14: phi of the entry, bit 15: negate.
+//   bits 0..10 row (8 x 131 rows at width 5), bits 11..12 term (the entry is at point term * count + i of its row), bit 14: phi of the entry, bit 15: negate.
 // One level (the first fold of an opening, ipa_pc/mod.rs:699-701): one term, the upper half of the key, scalar u.  Two levels: the
 // key after TWO folds straight from the committer key,
 //   K''[i] = K[i] + u2 K[q + i] + u1 K[2q + i] + (u1 u2) K[3q + i],  q = n / 4,
@@ -250,7 +250,7 @@ struct EcFoldTableBody {
     XyzzD<C> acc = XyzzD<C>::from_affine(AffD<C>::load(key_lo + (size_t)i * AW));
     const Fq b = Fq::load(beta);
     for (uint32_t k = 0; k < n_ops; k++) {
-      const uint32_t op = ops[k], row = op & 0x3ffu, term = (op >> 10) & 3u;
+      const uint32_t op = ops[k], row = op & 0x7ffu, term = (op >> 11) & 3u;
       AffD<C> p = AffD<C>::load(table + ((size_t)row * row_pts + (size_t)term * count + i) * AW);
       if (p.is_inf()) continue;
       if (op & 0x4000u) p.x = p.x.mul(b);

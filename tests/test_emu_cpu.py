@@ -712,7 +712,7 @@ def test_wnaf_digits(w):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("levels,w", [(1, 2), (1, 4), (2, 2), (2, 3), (2, 4)])
+@pytest.mark.parametrize("levels,w", [(1, 2), (1, 4), (2, 2), (2, 3), (2, 4), (2, 5), (1, 5)])
 def test_fold_table_one_and_two_levels(curve, levels, w):
     """Table build (affine doublings, odd multiples by affine additions) + the fold out of it, stepped on the CPU, against Python big
     ints: one level = K[i] + u1 K[h + i]; two levels = the key after the folds by u1 and by u2 (ipa_pc/mod.rs:699-707 twice), i.e.

@@ -73,7 +73,7 @@ def test_ipa_open_rounds_on_a_resident_key(ctx, curve, n, fkb, tables):
 @pytest.mark.parametrize("curve,n,fkb,levels,w", [("pallas", 1 << 13, 64, 2, 2), ("pallas", 1 << 13, 64, 2, 3), ("pallas", 1 << 13, 64, 2, 4),
                                                   ("pallas", 1 << 12, 1 << 10, 2, 4), ("pallas", 1 << 12, 1 << 11, 2, 4), ("bn254", 1 << 11, 16, 2, 3),
                                                   ("bls12_381", 1 << 10, 16, 2, 4), ("bls12_381", 1 << 10, 16, 1, 4), ("pallas", 1 << 12, 0, 1, 3),
-                                                  ("pallas", 8, 0, 2, 4), ("pallas", 1 << 16, None, 0, 0)])
+                                                  ("pallas", 8, 0, 2, 4), ("pallas", 1 << 12, 64, 2, 5), ("bn254", 1 << 10, 16, 1, 5), ("pallas", 1 << 16, None, 0, 0)])
 def test_ipa_open_rounds_with_the_general_fold_table(ctx, curve, n, fkb, levels, w):
     """pc_hip_srs_precompute_fold_ex: the fold table in its general form.  Two levels: round 1 leaves the key alone, round 2's four MSMs run
     on the committer key (linearity), pc_hip_ec_fold2_from then gives the key after both folds out of the table (width-w NAF digits,
