@@ -385,6 +385,14 @@ int pc_hip_srs_fold_table_info(const pc_srs* srs, unsigned* out_levels, unsigned
  * so the once-folded key never exists.  With a two-level fold table on src: 3 x ~52 table additions per element (width 4); without
  * one the two folds run one after the other (table / ladder): same result, no gain. */
 int pc_hip_ec_fold2_from(pc_ctx* ctx, const pc_srs* src, size_t n_quarter, const void* u1_host, const void* u2_host, pc_srs** out);
+/* Round 2's two commitments of such an opening, computed on the committer key `srs` itself (ipa_pc/mod.rs:671-675 for the key after the
+ * first fold, K' = K_l + u1 K_r, which is never formed): with q = n_quarter and c = the coefficient vector after the first fold (2q
+ * Montgomery scalars on the device),
+ *   out_l = MSM(K'[0 .. q), c[q .. 2q)) = MSM(K[0 .. 3q), (c_r | 0 | u1 c_r)),   out_r = MSM(K'[q .. 2q), c[0 .. q)) = MSM(K[q .. 4q), (c_l | 0 | u1 c_l))
+ * -- two MSMs of 3q pairs (a third of them zero scalars: no bucket entries) against the key's window table, on two pipelines.  The caller
+ * adds h' * <c_r, z_l> and h' * <c_l, z_r> as in every round.  Blocking; affine results (x || y, Montgomery), infinity flags optional. */
+int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs, const void* coeffs_dev, size_t n_quarter, const void* u1_host,
+                           void* out_l_xy, int* out_l_is_infinity, void* out_r_xy, int* out_r_is_infinity);
 /* Late halving rounds without folding the key (same l_vec / r_vec / final_comm_key, bit for bit): once n has
  * shrunk to n0 the resident key K0 = key[0..n0) stays as it is and the per-base factors s_j that the remaining
  * folds `k_l += k_r * u` (ipa_pc/mod.rs:699-701) would have applied are kept as a device vector s (n0 Fr,

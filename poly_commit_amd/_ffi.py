@@ -104,6 +104,7 @@ def load_library():
     lib.pc_hip_srs_precompute_fold_ex.argtypes = [vp, vp, C.c_uint, C.c_uint]
     lib.pc_hip_srs_fold_table_info.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     lib.pc_hip_ec_fold2_from.argtypes = [vp, vp, sz, vp, vp, C.POINTER(vp)]
+    lib.pc_hip_ipa_round2_msms.argtypes = [vp, vp, vp, sz, vp, vp, C.POINTER(ip), vp, C.POINTER(ip)]
     lib.pc_hip_ipa_key_scalars.argtypes = [vp, ip, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
@@ -515,6 +516,16 @@ class Srs:
         a, b = C.c_uint(), C.c_uint()
         self.ctx.check(self.ctx.lib.pc_hip_srs_fold_table_info(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def ipa_round2_msms(self, coeffs_dev, n_quarter, u1):
+        """Round 2's two commitments of an opening on this (committer) key by linearity (pc_hip_ipa_round2_msms): (l, r) affine."""
+        u1 = np.ascontiguousarray(u1, dtype=np.uint64)
+        w = 2 * FQ_BYTES[self.curve] // 8
+        l, r = np.zeros(w, dtype=np.uint64), np.zeros(w, dtype=np.uint64)
+        p, _ = _ptr(coeffs_dev)
+        self.ctx.check(self.ctx.lib.pc_hip_ipa_round2_msms(self.ctx.h, self.h, p, n_quarter, C.c_void_p(u1.ctypes.data), C.c_void_p(l.ctypes.data), None,
+                                                           C.c_void_p(r.ctypes.data), None))
+        return l, r
 
     def fold2_from(self, n_quarter, u1, u2):
         """A new resident key of n_quarter points: the key after the first TWO folds (by u1, then u2), straight from this key

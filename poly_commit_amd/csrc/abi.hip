@@ -1696,6 +1696,39 @@ int pc_hip_ec_fold2_from(pc_ctx* ctx, const pc_srs* src, size_t n_quarter, const
   return PC_OK;
 }
 
+int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs_c, const void* coeffs_dev, size_t n_quarter, const void* u1_host,
+                           void* out_l_xy, int* out_l_is_infinity, void* out_r_xy, int* out_r_is_infinity) {
+  pc_srs* srs = const_cast<pc_srs*>(srs_c);
+  if (!ctx || !srs || srs->ctx != ctx || !coeffs_dev || !u1_host || !out_l_xy || !out_r_xy || !n_quarter || 4 * n_quarter > srs->n) return PC_ERR_INVALID_ARG;
+  if (3 * n_quarter >= (1ull << 31)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  return guarded(ctx, [&]() {
+    const size_t q = n_quarter, fw = 8;                                    // scalars: 8 words each
+    const size_t bytes = 2 * 3 * q * fw * 4;
+    // scalar vectors (c_r | 0 | u1 c_r) and (c_l | 0 | u1 c_l): the context's grow-only call buffer up to STAGE_KEEP, transient above it
+    const bool owned = bytes > pc::HipBackend::STAGE_KEEP;
+    uint32_t* buf = (uint32_t*)(owned ? ctx->be.alloc(bytes) : ctx->be.stage(0, bytes));
+    struct Release { pc::HipBackend& be; void* p; ~Release() { if (p) { (void)hipStreamSynchronize(be.stream); be.free(p); } } } release{ctx->be, owned ? buf : nullptr};
+    uint32_t* sl = buf; uint32_t* sr = buf + 3 * q * fw;
+    const uint32_t* c = (const uint32_t*)coeffs_dev;
+    ctx->be.memset(buf, 0, bytes);
+    ctx->be.copy_d2d(sl, c + q * fw, q * fw * 4);                          // c_r = coeffs[q .. 2q)
+    ctx->be.copy_d2d(sr, c, q * fw * 4);                                   // c_l = coeffs[0 .. q)
+    const pc::FieldOps& fo = pc::field_ops(srs->curve);
+    fo.fr_fold(ctx->be, sl + 2 * q * fw, c + q * fw, q, (const uint32_t*)u1_host);      // 0 + u1 c_r
+    fo.fr_fold(ctx->be, sr + 2 * q * fw, c, q, (const uint32_t*)u1_host);               // 0 + u1 c_l
+    ctx->be.sync();                                                        // the pipelines run on queues of their own
+    StackJob jl(ctx), jr(ctx);
+    int rc = enqueue_job(ctx, srs, 0, sl, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, 3 * q, out_l_xy, out_l_is_infinity, &jl.job, true);
+    if (rc != PC_OK) return rc;
+    rc = enqueue_job(ctx, srs, q, sr, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, 3 * q, out_r_xy, out_r_is_infinity, &jr.job, true);
+    if (rc != PC_OK) return rc;
+    if (!jl.job.done) complete_job(ctx, &jl.job);
+    if (!jr.job.done) complete_job(ctx, &jr.job);
+    return jl.job.status != PC_OK ? jl.job.status : jr.job.status;
+  });
+}
+
 int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy) {
   if ((int)curve < 0 || (int)curve > 2 || !point_xy || !scalar_mont || !out_xy) return PC_ERR_INVALID_ARG;
   pc::curve_ops(curve).point_mul((const uint32_t*)point_xy, (const uint32_t*)scalar_mont, (uint32_t*)out_xy);

@@ -89,7 +89,7 @@ struct InnerProductArgPC {
   // opening_challenges: what the caller's sponge squeezed, one per polynomial (:502, then :525/:556).
   static Error open(pc_ctx* ctx, const IpaCommitterKey<E>& ck, const std::vector<const DensePolynomial<E>*>& polynomials,
                     const std::vector<G1Affine<E>>& commitments, const Fr& point, const std::vector<Fr>& opening_challenges,
-                    IpaProof<E>& proof) {
+                    IpaProof<E>& proof, size_t fixed_key_below = (size_t)1 << 16, bool two_level_table = false) {
     const size_t d1 = ck.comm_key.size();
     if (polynomials.size() != commitments.size() || polynomials.size() != opening_challenges.size()) { Error e; e.kind = Error::Backend; e.msg = "ipa open: one commitment and one opening challenge per polynomial"; return e; }
     std::vector<Fr> combined(d1, Fr::zero());
@@ -111,7 +111,7 @@ struct InnerProductArgPC {
     const Fr round_challenge = t.challenge();
     const G1Affine<E> h_prime = ck.h.mul(round_challenge);
     IpaRandomOracle<E> ro(round_challenge);
-    return open_rounds(ctx, ck.comm_key, combined, point, h_prime, ro, proof);
+    return open_rounds(ctx, ck.comm_key, combined, point, h_prime, ro, proof, fixed_key_below, two_level_table);
   }
 
   // The halving loop of open(): n = comm_key.size() = coeffs.size() = 2^k.
@@ -119,7 +119,7 @@ struct InnerProductArgPC {
   // (pc_hip_ipa_key_scalars: the same points, without a latency-bound scalar-multiplication pass per round).
   static Error open_rounds(pc_ctx* ctx, const std::vector<G1Affine<E>>& comm_key, const std::vector<Fr>& coeffs, const Fr& point,
                            const G1Affine<E>& h_prime, IpaChallengeSource<E>& challenges, IpaProof<E>& proof,
-                           size_t fixed_key_below = (size_t)1 << 16) {
+                           size_t fixed_key_below = (size_t)1 << 16, bool two_level_table = false) {
     size_t n = coeffs.size();
     if (n == 0 || (n & (n - 1)) || comm_key.size() != n) { Error e; e.kind = Error::Backend; e.msg = "ipa: key / coefficient lengths must be one power of two"; return e; }
     proof = IpaProof<E>();
@@ -135,6 +135,17 @@ struct InnerProductArgPC {
     Fr dots[2];
     if (rc == PC_OK) rc = pc_hip_ipa_fold_dots(ctx, E::ID, cdev, zdev, n, nullptr, nullptr, dots);
     Fr u_prev = Fr::zero(); bool have_u_prev = false;
+    // two_level_table: what a prover holding a resident committer key does (the Rust shim's loop): the key's two-level fold table
+    // (pc_hip_srs_precompute_fold_ex, once per key -- here per call, the key being uploaded per call) serves rounds 1 and 2: round 1
+    // leaves the key alone, round 2's commitments run on the committer key by linearity (pc_hip_ipa_round2_msms), the key after both
+    // folds comes out of the table in one step (pc_hip_ec_fold2_from).
+    bool two_level = two_level_table && n >= 8 && n / 2 > fixed_key_below;
+    if (rc == PC_OK && two_level) {
+      rc = pc_hip_srs_precompute(ctx, srs, 0, 1);
+      if (rc == PC_OK) rc = pc_hip_srs_precompute_fold_ex(ctx, srs, 2, 0);
+      if (rc == PC_ERR_UNSUPPORTED) { two_level = false; rc = PC_OK; }                         // no memory for it: round by round
+    }
+    pc_srs* root = srs; Fr u_first = Fr::zero(); bool have_u_first = false;
     while (rc == PC_OK && n > 1) {
       const size_t h = n / 2;
       char* c = (char*)cdev; char* z = (char*)zdev;
@@ -155,6 +166,8 @@ struct InnerProductArgPC {
         rc = pc_hip_ipa_key_scalars(ctx, E::ID, c, n, sdev, n0, have_u_prev ? u_prev.l : nullptr, have_u_prev ? 2 * n : 0, alrdev, (char*)alrdev + 32 * n0);
         if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, 0, alrdev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, lrxy[0], &lrinf[0], &jl);
         if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, 0, (char*)alrdev + 32 * n0, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, lrxy[1], &lrinf[1], &jr);
+      } else if (have_u_first) {
+        rc = pc_hip_ipa_round2_msms(ctx, srs, c, h, u_first.l, lrxy[0], &lrinf[0], lrxy[1], &lrinf[1]);   // round 2 on the committer key
       } else {
         rc = pc_hip_msm_async(ctx, srs, 0, c + 32 * h, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, h, lrxy[0], &lrinf[0], &jl);
         if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, h, c, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, h, lrxy[1], &lrinf[1], &jr);
@@ -169,6 +182,13 @@ struct InnerProductArgPC {
       rc = pc_hip_ipa_fold_dots(ctx, E::ID, c, z, h, u.l, u_inv.l, dots);
       if (rc == PC_OK) {
         if (n0) { u_prev = u; have_u_prev = true; }                                            // applied to the factors at the top of the next round
+        else if (two_level && !have_u_first && srs == root) { u_first = u; have_u_first = true; }   // round 1: the key stays
+        else if (have_u_first) {                                                               // round 2: both folds out of the table
+          pc_srs* work = nullptr;
+          rc = pc_hip_ec_fold2_from(ctx, root, h, u_first.l, u.l, &work);
+          if (rc == PC_OK) srs = work;
+          have_u_first = false; two_level = false;
+        }
         else rc = pc_hip_ec_fold(ctx, srs, h, u.l);                                            // key_l += u key_r, normalised :699-707
       }
       n = h;
@@ -181,7 +201,8 @@ struct InnerProductArgPC {
       if (rc == PC_OK) { proof.final_comm_key = from_out(kxy); rc = pc_hip_memcpy_d2h(ctx, proof.c.l, cdev, 32); }
     }
     pc_hip_free(ctx, cdev); pc_hip_free(ctx, zdev); pc_hip_free(ctx, sdev); pc_hip_free(ctx, alrdev);
-    pc_hip_srs_free(srs);
+    if (srs != root) pc_hip_srs_free(srs);                                                     // the working key of the two-level path
+    pc_hip_srs_free(root);
     return rc == PC_OK ? Error() : backend_error(ctx, rc);
   }
 

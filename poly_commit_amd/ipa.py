@@ -163,22 +163,11 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
                     jl = srs.msm_async(alr.data_ptr(), n=n0, base_offset=0, montgomery=True)
                     jr = srs.msm_async(alr.data_ptr() + 32 * n0, n=n0, base_offset=0, montgomery=True)
             elif u_first is not None:
-                # round 2 on the committer key (its window table serves it): by linearity, with q = h,
-                #   l = MSM(K[0 .. q), c_r) + u1 MSM(K[2q .. 3q), c_r) = MSM(K[0 .. 3q), (c_r | 0 | u1 c_r))
-                #   r = MSM(K[q .. 2q), c_l) + u1 MSM(K[3q .. 4q), c_l) = MSM(K[q .. 4q), (c_l | 0 | u1 c_l))
-                # two MSMs of 3q pairs, a third of them zero scalars (no bucket entries), instead of four of q with two host point
-                # multiplications and a fourth job queued behind the first on the key's three pipelines (measured: 5 ms more)
-                q = h
-                sc2 = torch.zeros((2, 3 * q, 4), dtype=torch.int64, device=coeffs_dev.device)
-                cv = coeffs_dev.view(-1, 4)
-                sc2[0, :q] = cv[q:2 * q]
-                sc2[1, :q] = cv[:q]
-                torch.cuda.synchronize()
-                u1row = np.ascontiguousarray(u_first, dtype=np.uint64).reshape(1, 4)
-                ctx.fr_lincomb(curve, [cptr + 32 * q], u1row, n_out=q, out=sc2[0, 2 * q:].data_ptr(), lens=[q])
-                ctx.fr_lincomb(curve, [cptr], u1row, n_out=q, out=sc2[1, 2 * q:].data_ptr(), lens=[q])
-                jl = srs.msm_async(sc2[0].data_ptr(), n=3 * q, base_offset=0, montgomery=True)
-                jr = srs.msm_async(sc2[1].data_ptr(), n=3 * q, base_offset=q, montgomery=True)
+                # round 2 on the committer key (its window table serves it), by linearity: pc_hip_ipa_round2_msms -- two MSMs of 3q pairs,
+                #   l = MSM(K[0 .. 3q), (c_r | 0 | u1 c_r)),  r = MSM(K[q .. 4q), (c_l | 0 | u1 c_l)),  q = h
+                # (as four MSMs of q pairs + two host point multiplications the fourth job waits for the first of the key's three
+                # pipelines: measured 0.5 ms more)
+                ml, mr = srs.ipa_round2_msms(cptr, h, u_first)
             else:
                 jl = srs.msm_async(cptr + 32 * h, n=h, base_offset=0, montgomery=True)
                 jr = srs.msm_async(cptr, n=h, base_offset=h, montgomery=True)
@@ -189,7 +178,7 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
             if n0 and many:
                 pts, _ = srs.msm_many(alr.data_ptr(), m=n0, n_msms=2, base_offset=0, montgomery=True)
                 ml, mr = pts[0], pts[1]
-            else:
+            elif u_first is None or n0:
                 ml, mr = jl.wait()[0], jr.wait()[0]
             l = _ffi.points_sum(curve, np.stack([ml, hl]))
             r = _ffi.points_sum(curve, np.stack([mr, hr]))

@@ -11,7 +11,8 @@
 //!   h' * <..>     `pc_hip_point_mul` (one point, host -- as in the reference)
 //!   transcript    `serialize_uncompressed` + `compute_random_oracle_challenge`: the reference's own Rust, two points a round
 //!   folds         `pc_hip_ipa_fold_dots`: c_l += u^-1 c_r, z_l += u z_r + the next round's inner products, 64 bytes back `:691-697`
-//!   key fold      `pc_hip_ec_fold` (GLV ladder per element + batched normalisation) while n > 2^16; from there on the key
+//!   key fold      rounds 1 and 2 in one step from the committer key's two-level fold table (`pc_hip_ec_fold2_from`, round 2's commitments by
+//!                 `pc_hip_ipa_round2_msms`), then `pc_hip_ec_fold` (GLV ladder per element + batched normalisation) while n > 2^16; from there on the key
 //!                 stays FIXED and the folds act on per-base factors s_j (`pc_hip_ipa_key_scalars`): the round's MSMs run
 //!                 over the fixed key with scalars c * s, `final_comm_key = sum_j s_j K_j` is one last MSM -- the same
 //!                 points, bit for bit, without a latency-bound ladder pass per round                  `:699-707`
@@ -126,10 +127,9 @@ where
         }
         let mut guard = if off == 0 && resident.n == d1 {
             if d1 >= 2 && !resident.fold_table_built.swap(true, std::sync::atomic::Ordering::SeqCst) {
-                // ONE level (this loop folds round by round with pc_hip_ec_fold_from), digits as wide as the memory share allows (0):
-                // ~52 instead of ~86 table additions per element at width 4.  The two-level form (pc_hip_ec_fold2_from: rounds 1 and 2
-                // in one step, round 2's MSMs on the committer key -- poly_commit_amd/ipa.py) is the next step for this loop.
-                let _ = unsafe { ffi::pc_hip_srs_precompute_fold_ex(c.raw, resident.srs, 1, 0) };      // refused / OOM: the ladder fold stays in use
+                // the library's choice of form: two levels (rounds 1 and 2 in one step, below) with the widest digits that fit half of
+                // the free device memory; one level on small keys
+                let _ = unsafe { ffi::pc_hip_srs_precompute_fold(c.raw, resident.srs) };      // refused / OOM: the ladder fold stays in use
             }
             KeyGuard(resident.srs, false)
         } else {
@@ -149,6 +149,12 @@ where
         let fixed_below = std::env::var("PC_HIP_IPA_FIXED_KEY_BELOW").ok().and_then(|v| v.parse().ok()).unwrap_or(FIXED_KEY_BELOW);
         let mut fixed: Option<(usize, DevicePoly, DevicePoly)> = None;      // (n0, s, scalars of l | scalars of r)
         let w = 2 * G::FQ_LIMBS;
+        // A resident committer key with a TWO-level fold table: round 1 leaves the key alone, round 2's commitments run on the committer key
+        // by linearity (pc_hip_ipa_round2_msms) and the key after both folds then comes out of the table in one step (pc_hip_ec_fold2_from)
+        let (mut fold_levels, mut fold_width): (core::ffi::c_uint, core::ffi::c_uint) = (0, 0);
+        let two_level = !guard.1 && d1 >= 8 && d1 / 2 > fixed_below
+            && unsafe { ffi::pc_hip_srs_fold_table_info(key, &mut fold_levels, &mut fold_width) } == ffi::PC_OK && fold_levels == 2;
+        let mut u_first: Option<G::ScalarField> = None;
 
         // the inner products of the first round; every later round gets its pair from the pass that folds the vectors
         let mut dots = [[0u64; 4]; 2];
@@ -181,16 +187,22 @@ where
                                                         lp.as_mut_ptr() as *mut c_void, &mut lr_inf[0], &mut jl) })?;
                 unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, alr.at(*n0), ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, *n0,
                                                rp.as_mut_ptr() as *mut c_void, &mut lr_inf[1], &mut jr) }
+            } else if let Some(u1) = u_first.as_ref() {
+                // round 2 on the committer key: MSM(K'[a .. a + q), s) = MSM(K[a .. a + q), s) + u1 MSM(K[a + 2q .. a + 3q), s), blocking
+                unsafe { ffi::pc_hip_ipa_round2_msms(c.raw, key, coeffs.dev, h, limbs(u1).as_ptr() as *const c_void, lp.as_mut_ptr() as *mut c_void, &mut lr_inf[0],
+                                                     rp.as_mut_ptr() as *mut c_void, &mut lr_inf[1]) }
             } else {
                 check(c, unsafe { ffi::pc_hip_msm_async(c.raw, key, 0, coeffs.at(h), ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
                                                         lp.as_mut_ptr() as *mut c_void, &mut lr_inf[0], &mut jl) })?;
                 unsafe { ffi::pc_hip_msm_async(c.raw, key, h, coeffs.dev, ffi::PC_SCALARS_MONTGOMERY, ffi::PC_MEM_DEVICE, h,
                                                rp.as_mut_ptr() as *mut c_void, &mut lr_inf[1], &mut jr) }
             };
-            let w1 = unsafe { ffi::pc_hip_job_wait(c.raw, jl) };                          // always reap the queued job
+            let w1 = if jl.is_null() { ffi::PC_OK } else { unsafe { ffi::pc_hip_job_wait(c.raw, jl) } };      // always reap the queued job
             check(c, rc)?;
             check(c, w1)?;
-            check(c, unsafe { ffi::pc_hip_job_wait(c.raw, jr) })?;
+            if !jr.is_null() {
+                check(c, unsafe { ffi::pc_hip_job_wait(c.raw, jr) })?;
+            }
             let (mut hl, mut hr) = (vec![0u64; w], vec![0u64; w]);
             check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, dots[0].as_ptr() as *const c_void, hl.as_mut_ptr() as *mut c_void) })?;
             check(c, unsafe { ffi::pc_hip_point_mul(G::CURVE, h_xy.as_ptr() as *const c_void, dots[1].as_ptr() as *const c_void, hr.as_mut_ptr() as *mut c_void) })?;
@@ -212,6 +224,14 @@ where
                                                         limbs(&round_challenge_inv).as_ptr() as *const c_void, dots.as_mut_ptr() as *mut c_void) })?;
             if fixed.is_some() {                                                                                                                           // :699-707
                 u_prev = Some(round_challenge);             // applied to the factors at the top of the next round
+            } else if two_level && u_first.is_none() && n == d1 {
+                u_first = Some(round_challenge);            // round 1: the key stays; round 2 runs on it as well
+            } else if let Some(u1) = u_first.take() {
+                // round 2: the key after both folds, K'' = K_0 + u2 K_1 + u1 K_2 + u1 u2 K_3 over the quarters of the committer key
+                let mut work = core::ptr::null_mut();
+                check(c, unsafe { ffi::pc_hip_ec_fold2_from(c.raw, key, h, limbs(&u1).as_ptr() as *const c_void, limbs(&round_challenge).as_ptr() as *const c_void, &mut work) })?;
+                guard = KeyGuard(work, true);
+                key = work;
             } else if guard.1 {
                 check(c, unsafe { ffi::pc_hip_ec_fold(c.raw, key, h, limbs(&round_challenge).as_ptr() as *const c_void) })?;
             } else {

@@ -48,6 +48,16 @@ static int run(pc_ctx* ctx, FILE* in, uint32_t n, uint32_t k, const char* out_pa
     if (e.kind != Error::IncorrectInputLength) { printf("check: short proof not reported as IncorrectInputLength\n"); return 1; }
   }
   printf("ipa check OK\n");
+  // the same opening the way a prover with a resident committer key runs it (the Rust shim's loop): two-level fold table, round 2 on the
+  // committer key by linearity, both folds in one step; rounds on the fixed key from n = 4 so that small test keys take the path too
+  {
+    IpaProof<E> p2;
+    if (Error e = InnerProductArgPC<E>::open(ctx, ck, pp, comms, point, xi, p2, 4, true)) { printf("open (two-level table): %s\n", e.msg.c_str()); return 1; }
+    bool same = p2.l_vec.size() == proof.l_vec.size() && p2.c == proof.c && p2.final_comm_key == proof.final_comm_key;
+    for (size_t i = 0; same && i < proof.l_vec.size(); i++) same = p2.l_vec[i] == proof.l_vec[i] && p2.r_vec[i] == proof.r_vec[i];
+    if (!same) { printf("the two-level fold path gives another proof\n"); return 1; }
+    printf("ipa two-level OK\n");
+  }
   FILE* out = fopen(out_path, "wb");
   auto wr_pt = [&](const G1Affine<E>& p) { uint64_t xy[2 * E::NQ]; p.to_xy(xy); fwrite(xy, 1, sizeof xy, out); };
   for (auto& p : proof.l_vec) wr_pt(p);
