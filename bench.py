@@ -1350,10 +1350,22 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
         work = cdev.clone()                 # the folds act in place on the coefficient vector
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        proof = ipa.ipa_open_rounds(ctx, curve, srs, work, n, point, h_prime, lambda L, R_: ch[next(it)], timings=tm)
+        proof = ipa.ipa_open_rounds(ctx, curve, srs, work, n, point, h_prime, lambda L, R_: ch[next(it)], timings=tm)      # pc_hip_ipa_open_rounds
         dt = time.perf_counter() - t0
         if best is None or dt < best:
             best, tm_best = dt, tm
+    # the same opening driven round by round through the single entry points (what the line's open_breakdown_ms splits; not the timed figure)
+    it = iter(range(log_n))
+    tm_py = {}
+    work = cdev.clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    proof_py = ipa.ipa_open_rounds(ctx, curve, srs, work, n, point, h_prime, lambda L, R_: ch[next(it)], timings=tm_py, python_loop=True)
+    py_ms = (time.perf_counter() - t0) * 1e3
+    loops_agree = all(bool((np.asarray(a) == np.asarray(b)).all()) for a, b in zip(proof, proof_py))
+    for k in ("per_round_ms", "ec_fold_per_round_ms", "ec_fold_kind"):
+        tm_py.pop(k, None)
+    tm_best = dict(tm_best, **{k: v for k, v in tm_py.items() if k != "ec_fold"})
     ctx.set_timing(True)
     per_round = tm_best.pop("per_round_ms", [])
     fold_rounds = tm_best.pop("ec_fold_per_round_ms", [])
@@ -1380,7 +1392,9 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
     del cdev
     torch.cuda.empty_cache()
     return {"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: cm_commit MSM + open's {log_n} halving rounds (BASELINE configs[3])",
-            "commit_ms": t_commit * 1e3, "open_ms": best * 1e3, "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / best,
+            "commit_ms": t_commit * 1e3, "open_ms": best * 1e3, "open_ms_is": "one pc_hip_ipa_open_rounds call (the loop inside the library), best of the openings",
+            "open_round_by_round_ms": py_ms, "open_round_by_round_is": "the same opening driven through the single entry points from Python (one run; the breakdown's source)",
+            "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / best,
             "open_coeffs_per_s": n / best, "log_n": log_n,
             "open_breakdown_ms": {k: round(v, 2) for k, v in tm_best.items()}, "per_round_ms": [round(x, 2) for x in per_round],
             "roofline": msm_roofline(curve, n, shape_c["digits_per_scalar"], float(ph_c[3]), 1,
@@ -1392,7 +1406,7 @@ def ipa_case(ctx, log_n, reps, with_cpu=True):
             "roofline_open": roof_open, "cpu_baseline": cpu,
             "key_gen_ms": key_gen_ms, "key_tables_build_ms": key_tables_ms,
             "key_tables_note": "window table + fold table of the committer key (two levels: 131 x 2^(w-2) rows of the upper three quarters), built once per key outside the timing",
-            "parity": {"commit_ok": ok_commit, "final_comm_key_ok": ok_key,
+            "parity": {"commit_ok": ok_commit, "final_comm_key_ok": ok_key, "library_loop_equals_round_by_round_ok": loops_agree,
                        "method": "generators a^i g built on the device: commitment == p(a) g (oracle Horner + scalar multiplication); "
                                  "final_comm_key == prod_i (1 + u_i a^(2^(log n - 1 - i))) g for the supplied round challenges u_i "
                                  "(ipa_pc/mod.rs:699-701 folded in closed form); the whole Proof is compared with the oracle at this "

@@ -393,6 +393,22 @@ int pc_hip_ec_fold2_from(pc_ctx* ctx, const pc_srs* src, size_t n_quarter, const
  * adds h' * <c_r, z_l> and h' * <c_l, z_r> as in every round.  Blocking; affine results (x || y, Montgomery), infinity flags optional. */
 int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs, const void* coeffs_dev, size_t n_quarter, const void* u1_host,
                            void* out_l_xy, int* out_l_is_infinity, void* out_r_xy, int* out_r_is_infinity);
+/* The whole halving loop of InnerProductArgPC::open (ipa_pc/mod.rs:664-711) as ONE call, for a resident committer key:
+ *   per round k (size m -> m / 2):  l_k, r_k = the two commitments + h' * inner products (:666-677);  u_k = next_challenge(l_k, r_k)
+ *   (:681-689 -- the transcript is the caller's: Blake2s over ark-serialize bytes in the reference, host/transcript.hpp here);
+ *   coeffs_l += u_k^-1 coeffs_r, z_l += u_k z_r (:691-697);  key_l += u_k key_r (:699-707)
+ * with everything the round-by-round entry points above offer, chosen by the library: the committer key's fold table (two levels: rounds
+ * 1 and 2 in one step, round 2 on the committer key by linearity), GLV ladder folds, the fixed key with per-base factors from
+ * `fixed_key_below` points on (0: the library's default, 2^16; 1: never), captured launch graphs for its small MSMs.  The committer key
+ * is not modified (the working keys are cached with it); coeffs_dev (n Montgomery scalars, n a power of two <= the key's length) is
+ * consumed.  Outputs: l_vec / r_vec = log2(n) affine points each (x || y, Montgomery; all zero = infinity), final_comm_key, c -- the
+ * Proof of ipa_pc/data_structures.rs:175-195 without hiding.  out_round_ms / out_fold_ms: optional, log2(n) floats each (wall time of
+ * every round, and of its key fold).  Between the rounds there is no host language: the 16 latency-bound rounds on the fixed key cost
+ * ~0.65 instead of ~0.85 ms each against the same sequence driven through the entry points one by one. */
+typedef void (*pc_ipa_challenge_fn)(void* user, const void* l_xy, const void* r_xy, void* out_u_mont);
+int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev, size_t n, const void* point_host, const void* h_prime_xy_host,
+                           pc_ipa_challenge_fn next_challenge, void* user, size_t fixed_key_below,
+                           void* out_l_vec_xy, void* out_r_vec_xy, void* out_final_key_xy, void* out_c_host, float* out_round_ms, float* out_fold_ms);
 /* Late halving rounds without folding the key (same l_vec / r_vec / final_comm_key, bit for bit): once n has
  * shrunk to n0 the resident key K0 = key[0..n0) stays as it is and the per-base factors s_j that the remaining
  * folds `k_l += k_r * u` (ipa_pc/mod.rs:699-701) would have applied are kept as a device vector s (n0 Fr,

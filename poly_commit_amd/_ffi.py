@@ -105,6 +105,7 @@ def load_library():
     lib.pc_hip_srs_fold_table_info.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     lib.pc_hip_ec_fold2_from.argtypes = [vp, vp, sz, vp, vp, C.POINTER(vp)]
     lib.pc_hip_ipa_round2_msms.argtypes = [vp, vp, vp, sz, vp, vp, C.POINTER(ip), vp, C.POINTER(ip)]
+    lib.pc_hip_ipa_open_rounds.argtypes = [vp, vp, vp, sz, vp, vp, IPA_CHALLENGE_FN, vp, sz, vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pc_hip_ipa_key_scalars.argtypes = [vp, ip, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.pc_hip_srs_read.argtypes = [vp, vp, sz, sz, vp]
     lib.pc_hip_fixed_base_batch_mul.argtypes = [vp, ip, vp, vp, sz, vp]
@@ -132,6 +133,10 @@ def load_library():
     lib.pc_hip_group_job_wait.argtypes = [vp, vp]
     _lib = lib
     return lib
+
+
+# pc_ipa_challenge_fn: void (*)(void* user, const void* l_xy, const void* r_xy, void* out_u_mont)
+IPA_CHALLENGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 def _ptr(x):
@@ -516,6 +521,40 @@ class Srs:
         a, b = C.c_uint(), C.c_uint()
         self.ctx.check(self.ctx.lib.pc_hip_srs_fold_table_info(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def ipa_open_rounds(self, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, fixed_key_below=0, want_times=False):
+        """The whole halving loop of InnerProductArgPC::open on this resident committer key (pc_hip_ipa_open_rounds).
+        next_challenge(l_xy, r_xy) -> u as 4 Montgomery uint64 limbs.  Returns (l_vec, r_vec, final_key, c[, round_ms, fold_ms])."""
+        lg = n.bit_length() - 1
+        w = 2 * FQ_BYTES[self.curve] // 8
+        l = np.zeros((max(lg, 1), w), dtype=np.uint64)
+        r = np.zeros((max(lg, 1), w), dtype=np.uint64)
+        fk, c = np.zeros(w, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        err = []
+
+        def cb(_user, lp, rp, up):
+            try:
+                lxy = np.frombuffer((C.c_uint64 * w).from_address(lp), dtype=np.uint64).copy()
+                rxy = np.frombuffer((C.c_uint64 * w).from_address(rp), dtype=np.uint64).copy()
+                u = np.ascontiguousarray(next_challenge(lxy, rxy), dtype=np.uint64)
+                C.memmove(up, u.ctypes.data, 32)
+            except BaseException as e:      # an exception must not cross the C frames: finish the loop on a dummy challenge, raise afterwards
+                err.append(e)
+                C.memset(up, 0, 32); C.memset(up, 1, 1)
+        fn = IPA_CHALLENGE_FN(cb)
+        point = np.ascontiguousarray(point_mont, dtype=np.uint64)
+        hp = np.ascontiguousarray(h_prime_xy, dtype=np.uint64)
+        rms = (C.c_float * max(lg, 1))()
+        fms = (C.c_float * max(lg, 1))()
+        p, _ = _ptr(coeffs_dev)
+        rc = self.ctx.lib.pc_hip_ipa_open_rounds(self.ctx.h, self.h, p, n, C.c_void_p(point.ctypes.data), C.c_void_p(hp.ctypes.data), fn, None,
+                                                 fixed_key_below, C.c_void_p(l.ctypes.data), C.c_void_p(r.ctypes.data), C.c_void_p(fk.ctypes.data),
+                                                 C.c_void_p(c.ctypes.data), rms, fms)
+        if err:
+            raise err[0]
+        self.ctx.check(rc)
+        out = (l[:lg], r[:lg], fk, c)
+        return out + (list(rms)[:lg], list(fms)[:lg]) if want_times else out
 
     def ipa_round2_msms(self, coeffs_dev, n_quarter, u1):
         """Round 2's two commitments of an opening on this (committer) key by linearity (pc_hip_ipa_round2_msms): (l, r) affine."""

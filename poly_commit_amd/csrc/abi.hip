@@ -51,6 +51,8 @@ struct pc_ctx {
   // pc_hip_ligero_commit in row slabs: the slab buffers (grow-only up to LIGERO_KEEP, pc_hip_ctx_trim frees them) and the queue of the way out
   void* lig_arena = nullptr; size_t lig_bytes = 0; hipStream_t lig_out_q[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<struct pc_srs*> keys;   // every key object of this context that is alive (pc_hip_ctx_bytes_resident, pc_hip_ctx_trim)
+  // pc_hip_ipa_open_rounds: the powers of z, the per-base factors of the fixed key and the two scalar vectors of its rounds (grow-only, pc_hip_ctx_trim frees them)
+  void* ipa_buf[3] = {nullptr, nullptr, nullptr}; size_t ipa_bytes[3] = {0, 0, 0};
 };
 
 // Independent pipelines per SRS (stream + workspace each), used round-robin; a pipeline that still
@@ -237,6 +239,7 @@ void pc_hip_shutdown(pc_ctx* ctx) {
   if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
   for (hipStream_t q : ctx->lig_out_q) if (q) (void)hipStreamDestroy(q);
   ctx->be.free(ctx->lig_arena);
+  for (int i = 0; i < 3; i++) ctx->be.free(ctx->ipa_buf[i]);
   ctx->be.destroy();
   delete ctx;
 }
@@ -882,6 +885,7 @@ int pc_hip_ctx_trim(pc_ctx* ctx) {
     ctx->be.trim();
     ctx->ntt_plans.clear();
     ctx->be.free(ctx->lig_arena); ctx->lig_arena = nullptr; ctx->lig_bytes = 0;      // pc_hip_ligero_commit's slab buffers
+    for (int i = 0; i < 3; i++) { ctx->be.free(ctx->ipa_buf[i]); ctx->ipa_buf[i] = nullptr; ctx->ipa_bytes[i] = 0; }      // pc_hip_ipa_open_rounds' vectors
     // working keys that an opening handed back (pc_hip_ec_fold_from keeps one per committer key, with its three pipelines)
     std::vector<pc_srs*> cached;
     for (pc_srs* s : ctx->keys) if (s->work_cache) { cached.push_back(s->work_cache); s->work_cache = nullptr; }
@@ -1727,6 +1731,112 @@ int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs_c, const void* coeffs_
     if (!jr.job.done) complete_job(ctx, &jr.job);
     return jl.job.status != PC_OK ? jl.job.status : jr.job.status;
   });
+}
+
+// The halving loop of InnerProductArgPC::open (ipa_pc/mod.rs:664-711) as ONE call: everything the round-by-round entry points above do,
+// in the order poly_commit_amd/ipa.py and host/ipa_pc.hpp drive them, without a host language between the rounds (the 16 rounds on the
+// fixed key are a latency chain: ~190 us of every ~850 us round were the harness).  The transcript stays the caller's: `next_challenge`
+// gets the round's l and r (affine, Montgomery x || y; all zeros = infinity) and returns the challenge u (Montgomery Fr).
+static void* ipa_buffer(pc_ctx* ctx, int i, size_t bytes) {
+  if (bytes > ctx->ipa_bytes[i]) {
+    if (ctx->ipa_buf[i]) { ctx->be.sync(); ctx->be.free(ctx->ipa_buf[i]); ctx->ipa_buf[i] = nullptr; ctx->ipa_bytes[i] = 0; }
+    ctx->ipa_buf[i] = ctx->be.alloc(bytes); ctx->ipa_bytes[i] = bytes;
+  }
+  return ctx->ipa_buf[i];
+}
+int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev, size_t n, const void* point_host, const void* h_prime_xy_host,
+                           pc_ipa_challenge_fn next_challenge, void* user, size_t fixed_key_below,
+                           void* out_l_vec_xy, void* out_r_vec_xy, void* out_final_key_xy, void* out_c_host, float* out_round_ms, float* out_fold_ms) {
+  pc_srs* root = const_cast<pc_srs*>(comm_key);
+  if (!ctx || !root || root->ctx != ctx || !coeffs_dev || !n || (n & (n - 1)) || n > root->n || !point_host || !h_prime_xy_host || !next_challenge ||
+      !out_final_key_xy || !out_c_host || (n > 1 && (!out_l_vec_xy || !out_r_vec_xy))) return PC_ERR_INVALID_ARG;
+  if (n >= (1ull << 31)) return PC_ERR_TOO_LARGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  const pc_curve curve = root->curve;
+  const pc::CurveOps& ops = pc::curve_ops(curve);
+  const size_t pb = (size_t)root->aw * 4;                       // bytes of an affine point
+  if (!fixed_key_below) fixed_key_below = (size_t)1 << 16;      // (2^16: EXPERIMENTS 00; (size_t)-1 >> 1 or any value below 2: never / always fold the key)
+  pc_srs* srs = root; bool owned = false;
+  struct KeyGuard { pc_srs*& k; bool& owned; ~KeyGuard() { if (owned && k) pc_hip_srs_free(k); } } key_guard{srs, owned};
+  void* z = nullptr; void* s_dev = nullptr; char* alr = nullptr;
+  int rc = guarded(ctx, [&]() { z = ipa_buffer(ctx, 0, n * 32); return (int)PC_OK; });
+  if (rc != PC_OK) return rc;
+  char* c = (char*)coeffs_dev;
+  rc = pc_hip_fr_powers(ctx, curve, point_host, n, z);                                          // z = (1, point, point^2, ..)   :641-649
+  uint32_t dots[2][8];
+  if (rc == PC_OK) rc = pc_hip_ipa_fold_dots(ctx, curve, c, z, n, nullptr, nullptr, dots);      // the inner products of the first round
+  size_t n0 = 0;
+  uint32_t u_prev[8], u_first[8], u[8], ui[8], one[8];
+  bool have_u_prev = false, have_u_first = false;
+  ops.fr_one(one);
+  // a committer key with a two-level fold table (pc_hip_srs_precompute_fold_ex): round 1 leaves the key alone, round 2 runs on it by
+  // linearity (pc_hip_ipa_round2_msms), the key after both folds comes out of the table in one step (pc_hip_ec_fold2_from)
+  bool two_level = n == root->n && n >= 8 && n / 2 > fixed_key_below && root->fold_tbl && root->fold_levels == 2;
+  std::vector<uint32_t> pts(4 * (size_t)root->aw);               // ml | hl | mr | hr
+  size_t round = 0;
+  using clk = std::chrono::steady_clock;
+  for (size_t m = n; rc == PC_OK && m > 1; m /= 2, round++) {
+    const auto t_round = clk::now();
+    const size_t h = m / 2;
+    if (!n0 && m <= fixed_key_below) {                                                          // from here on key[0 .. n0) stays fixed
+      n0 = m;
+      rc = guarded(ctx, [&]() { s_dev = ipa_buffer(ctx, 1, n0 * 32); alr = (char*)ipa_buffer(ctx, 2, 2 * n0 * 32); return (int)PC_OK; });
+      if (rc == PC_OK) rc = pc_hip_fr_powers(ctx, curve, one, n0, s_dev);                        // s = (1, 1, ..)
+      if (rc != PC_OK) break;
+      have_u_prev = false;                                                                      // the key itself carries every fold so far
+    }
+    uint32_t* ml = pts.data(); uint32_t* hl = ml + root->aw; uint32_t* mr = hl + root->aw; uint32_t* hr = mr + root->aw;
+    pc_job* jl = nullptr; pc_job* jr = nullptr;
+    // l = cm_commit(key_l, coeffs_r) + h' <coeffs_r, z_l>;  r = cm_commit(key_r, coeffs_l) + h' <coeffs_l, z_r>          :666-675
+    if (n0) {
+      rc = pc_hip_ipa_key_scalars(ctx, curve, c, m, s_dev, n0, have_u_prev ? u_prev : nullptr, have_u_prev ? 2 * m : 0, alr, alr + 32 * n0);
+      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, 0, alr, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, ml, nullptr, &jl);
+      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, 0, alr + 32 * n0, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, mr, nullptr, &jr);
+    } else if (have_u_first) {
+      rc = pc_hip_ipa_round2_msms(ctx, srs, c, h, u_first, ml, nullptr, mr, nullptr);
+    } else {
+      rc = pc_hip_msm_async(ctx, srs, 0, c + 32 * h, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, h, ml, nullptr, &jl);
+      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, h, c, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, h, mr, nullptr, &jr);
+    }
+    if (rc == PC_OK) {                                                                          // beside the MSMs: h' * <.., ..>, one point each
+      ops.point_mul((const uint32_t*)h_prime_xy_host, dots[0], hl);
+      ops.point_mul((const uint32_t*)h_prime_xy_host, dots[1], hr);
+    }
+    const int w1 = jl ? pc_hip_job_wait(ctx, jl) : PC_OK, w2 = jr ? pc_hip_job_wait(ctx, jr) : PC_OK;      // always reap queued jobs
+    if (rc == PC_OK) rc = w1 != PC_OK ? w1 : w2;
+    if (rc != PC_OK) break;
+    uint32_t* l = (uint32_t*)((char*)out_l_vec_xy + round * pb); uint32_t* r = (uint32_t*)((char*)out_r_vec_xy + round * pb);
+    ops.points_sum(ml, 2, l);
+    ops.points_sum(mr, 2, r);
+    next_challenge(user, l, r, u);                                                              // :681-689, the caller's transcript
+    ops.fr_inv(u, ui);
+    rc = pc_hip_ipa_fold_dots(ctx, curve, c, z, h, u, ui, dots);                                // :691-697 + the next round's inner products
+    if (rc != PC_OK) break;
+    const auto t_fold = clk::now();
+    bool folded = false;
+    if (n0) { memcpy(u_prev, u, 32); have_u_prev = true; }                                      // applied to the factors at the top of the next round
+    else if (two_level && !have_u_first && srs == root) { memcpy(u_first, u, 32); have_u_first = true; }
+    else if (have_u_first) {
+      pc_srs* work = nullptr;
+      rc = pc_hip_ec_fold2_from(ctx, root, h, u_first, u, &work);
+      if (rc == PC_OK) { srs = work; owned = true; }
+      have_u_first = false; two_level = false; folded = true;
+    } else if (owned) { rc = pc_hip_ec_fold(ctx, srs, h, u); folded = true; }                   // key_l += u key_r, normalised          :699-707
+    else {
+      pc_srs* work = nullptr;
+      rc = pc_hip_ec_fold_from(ctx, srs, h, u, &work);                                          // the same fold, out of place: the committer key stays
+      if (rc == PC_OK) { srs = work; owned = true; }
+      folded = true;
+    }
+    const auto t_end = clk::now();
+    if (out_fold_ms) out_fold_ms[round] = folded ? std::chrono::duration<float, std::milli>(t_end - t_fold).count() : 0.0f;
+    if (out_round_ms) out_round_ms[round] = std::chrono::duration<float, std::milli>(t_end - t_round).count();
+  }
+  if (rc == PC_OK && n0 && have_u_prev) rc = pc_hip_ipa_key_scalars(ctx, curve, nullptr, 0, s_dev, n0, u_prev, 2, nullptr, nullptr);      // the last fold (size 2)
+  if (rc == PC_OK) rc = n0 ? pc_hip_msm(ctx, srs, 0, s_dev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, out_final_key_xy, nullptr)           // sum_j s_j K0_j
+                           : pc_hip_srs_read(ctx, srs, 0, 1, out_final_key_xy);
+  if (rc == PC_OK) rc = pc_hip_memcpy_d2h(ctx, out_c_host, coeffs_dev, 32);
+  return rc;
 }
 
 int pc_hip_point_mul(pc_curve curve, const void* point_xy, const void* scalar_mont, void* out_xy) {

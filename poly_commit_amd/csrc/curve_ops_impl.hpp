@@ -225,6 +225,8 @@ struct CurveOpsImpl {
     typedef Fd<typename C::FrP> Fr;
     Fr::load(a).mul(Fr::load(b)).store(out);
   }
+  static void fr_inv(const uint32_t* a, uint32_t* out) { Fd<typename C::FrP>::load(a).inv().store(out); }
+  static void fr_one(uint32_t* out) { Fd<typename C::FrP>::one().store(out); }
   static void fold_table_build(HipBackend& be, const uint32_t* pts, size_t count, uint32_t w, uint32_t* table) { fold_table_build_run<C>(be, pts, count, w, table); }
   static void fixed_base(HipBackend& be, const uint32_t* g, const uint32_t* scalars, size_t n, uint32_t* out) {
     if (n < 4096) {          // a handful of scalars: the per-lane ladder, no table
@@ -296,7 +298,7 @@ struct CurveOpsImpl {
     acc.store_affine(out);
   }
   static CurveOps table() {
-    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &ec_fold_to, &ec_fold_table, &fold_table_build, (uint32_t)FOLD_ROWS, &fixed_base, &srs_decode, &srs_encode, &points_sum, &point_mul, &fr_mul};
+    return CurveOps{AW, (uint32_t)C::FrP::BITS, &make_runner, &window_table, &ec_fold, &ec_fold_to, &ec_fold_table, &fold_table_build, (uint32_t)FOLD_ROWS, &fixed_base, &srs_decode, &srs_encode, &points_sum, &point_mul, &fr_mul, &fr_inv, &fr_one};
   }
 };
 

@@ -59,6 +59,8 @@ struct CurveOps {
   void (*points_sum)(const uint32_t* pts, size_t count, uint32_t* out);
   void (*point_mul)(const uint32_t* pt, const uint32_t* k_mont, uint32_t* out);
   void (*fr_mul)(const uint32_t* a_mont, const uint32_t* b_mont, uint32_t* out_mont);      // one scalar-field product on the host
+  void (*fr_inv)(const uint32_t* a_mont, uint32_t* out_mont);                             // a^-1 (0 -> 0), host
+  void (*fr_one)(uint32_t* out_mont);
 };
 
 struct FieldOps {

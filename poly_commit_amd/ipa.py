@@ -95,14 +95,44 @@ FIXED_KEY_BELOW = 1 << 16
 
 
 def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, timings=None,
-                    fixed_key_below=None):
+                    fixed_key_below=None, python_loop=None):
     """comm_key: n x (x||y) host array, or a resident Srs (it is cloned on the device, not consumed); coeffs_dev: torch cuda int64 tensor (n,4), Montgomery,
-    CONSUMED (folded in place).  Returns (l_vec, r_vec, final_comm_key, c) as numpy arrays."""
+    CONSUMED (folded in place).  Returns (l_vec, r_vec, final_comm_key, c) as numpy arrays.
+    python_loop: False (default; PC_IPA_PY_LOOP=1 flips it) = the library's own loop, pc_hip_ipa_open_rounds; True = the same sequence driven
+    from here through the round-by-round entry points (the per-phase `timings` of bench.py's breakdown come from this form)."""
+    if python_loop is None:
+        python_loop = os.environ.get("PC_IPA_PY_LOOP", "0") == "1"
     if fixed_key_below is None:
         fixed_key_below = FIXED_KEY_BELOW
     import time
     import torch
     assert n & (n - 1) == 0
+    if not python_loop:
+        # the loop inside the library (pc_hip_ipa_open_rounds): the same calls in the same order, no host language between the rounds
+        resident = isinstance(comm_key, _ffi.Srs)
+        srs = comm_key if resident else ctx.upload_srs(curve, np.ascontiguousarray(comm_key))
+        try:
+            out = srs.ipa_open_rounds(coeffs_dev.data_ptr(), n, point_mont, np.ascontiguousarray(h_prime_xy), next_challenge,
+                                      fixed_key_below if fixed_key_below >= 2 else 1, want_times=timings is not None)
+        finally:
+            if not resident:
+                srs.free()
+        if timings is not None:
+            l, r, fk, c, rms, fms = out
+            levels = srs.fold_table_info()[0] if resident else 0
+            two = resident and n == srs.n and n >= 8 and n // 2 > fixed_key_below and levels == 2
+            timings["per_round_ms"] = [round(x, 3) for x in rms]
+            kinds, folds, m = [], [], n
+            for k, ms in enumerate(fms):
+                h = m // 2
+                if m > fixed_key_below:
+                    kind = ("deferred" if k == 0 else "table2") if (two and k < 2) else ("table1" if (k == 0 and resident and levels == 1 and srs.n == n) else "ladder")
+                    kinds.append(kind); folds.append((h, round(ms, 3)))
+                m = h
+            timings["ec_fold_per_round_ms"], timings["ec_fold_kind"] = folds, kinds
+            timings["ec_fold"] = sum(fms)
+            return l, r, fk, c
+        return out
 
     class _T:
         def __init__(self, name):

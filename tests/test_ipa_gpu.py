@@ -32,11 +32,13 @@ def test_ipa_open_rounds(ctx, curve, n, fkb):
     ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A1, lg))
     want_l, want_r, want_key, want_c = O.ipa_rounds(curve, np.ascontiguousarray(comm_key), coeffs, point,
                                                     np.ascontiguousarray(h_prime), ch)
-    it = iter(range(lg))
-    cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
-    l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, comm_key, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb)
-    assert (l == want_l).all() and (r == want_r).all()
-    assert (fk == want_key).all() and (c == want_c).all()
+    for python_loop in (False, True):      # the library's own loop (pc_hip_ipa_open_rounds) and the same sequence driven round by round from Python
+        it = iter(range(lg))
+        cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+        l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, comm_key, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb,
+                                          python_loop=python_loop)
+        assert (l == want_l).all() and (r == want_r).all(), python_loop
+        assert (fk == want_key).all() and (c == want_c).all(), python_loop
 
 
 @pytest.mark.parametrize("curve,n,fkb,tables", [("pallas", 1 << 13, 64, True), ("pallas", 1 << 13, 64, False), ("bn254", 1 << 12, 0, True),
@@ -103,7 +105,8 @@ def test_ipa_open_rounds_with_the_general_fold_table(ctx, curve, n, fkb, levels,
         it = iter(range(lg))
         cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
         tm = {}
-        l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, timings=tm)
+        l, r, fk, c = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, timings=tm,
+                                          python_loop=(rep == 1))      # the library's loop, then the round-by-round one
         assert (l == want_l).all() and (r == want_r).all() and (fk == want_key).all() and (c == want_c).all()
         kinds = tm.get("ec_fold_kind", [])
         limit = ipa.FIXED_KEY_BELOW if fkb is None else fkb
@@ -123,6 +126,41 @@ def test_ipa_rounds_randomised_differential():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ipa_fuzz.py"), "15", "20260930"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_ipa_open_rounds_one_call_edge_cases(ctx):
+    """pc_hip_ipa_open_rounds: n = 1 (no round: final key = key[0], c = the coefficient), a prefix of a longer resident key, an exception
+    in the caller's challenge function (reported after the loop, nothing left in flight), invalid arguments."""
+    import torch
+    import poly_commit_amd as pc
+    curve = "pallas"
+    key = O.gen_bases(curve, 65)
+    srs = ctx.upload_srs(curve, np.ascontiguousarray(key[:64]))
+    point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 3, 1))[0]
+    co = O.f_to_mont(curve, 1, O.gen_scalars(curve, 4, 64))
+    cdev = torch.from_numpy(co[:1].view(np.int64).copy()).cuda()
+    l, r, fk, c = srs.ipa_open_rounds(cdev.data_ptr(), 1, point, key[64], lambda L, R_: None)
+    assert len(l) == 0 and (fk == key[0]).all() and (c == co[0]).all()
+    for n in (16, 64):                                   # a prefix of the resident key, and all of it
+        ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 5, 6))
+        want = O.ipa_rounds(curve, np.ascontiguousarray(key[:n]), np.ascontiguousarray(co[:n]), point, np.ascontiguousarray(key[64]), ch[:n.bit_length() - 1])
+        it = iter(range(6))
+        cdev = torch.from_numpy(co[:n].view(np.int64).copy()).cuda()
+        got = srs.ipa_open_rounds(cdev.data_ptr(), n, point, key[64], lambda L, R_: ch[next(it)], fixed_key_below=4)
+        assert all((a == b).all() for a, b in zip(got, want)), n
+    cdev = torch.from_numpy(co.view(np.int64).copy()).cuda()
+    with pytest.raises(ZeroDivisionError):
+        srs.ipa_open_rounds(cdev.data_ptr(), 64, point, key[64], lambda L, R_: 1 // 0)
+    it = iter(range(6))
+    cdev = torch.from_numpy(co.view(np.int64).copy()).cuda()
+    got = srs.ipa_open_rounds(cdev.data_ptr(), 64, point, key[64], lambda L, R_: ch[next(it)])      # the context is as usable as before
+    want = O.ipa_rounds(curve, np.ascontiguousarray(key[:64]), co, point, np.ascontiguousarray(key[64]), ch)
+    assert all((a == b).all() for a, b in zip(got, want))
+    with pytest.raises(pc.PcHipError):
+        srs.ipa_open_rounds(cdev.data_ptr(), 48, point, key[64], lambda L, R_: ch[0])             # not a power of two
+    with pytest.raises(pc.PcHipError):
+        srs.ipa_open_rounds(cdev.data_ptr(), 128, point, key[64], lambda L, R_: ch[0])            # longer than the key
+    srs.free()
 
 
 def test_fold2_from_without_a_two_level_table_is_the_two_folds(ctx):

@@ -18,6 +18,7 @@ FFI_RS = os.path.join(ROOT, "rust", "poly-commit-hip", "src", "ffi.rs")
 
 OPAQUE = ("pc_ctx", "pc_srs", "pc_job", "pc_group", "pc_group_srs", "pc_group_job")
 ENUMS = ("pc_curve", "pc_scalar_form", "pc_mem", "pc_hash", "pc_status")
+CALLBACKS = ("pc_ipa_challenge_fn",)          # function-pointer typedefs of the header, declared as `pub type` aliases in ffi.rs
 
 
 def strip_comments(src):
@@ -47,6 +48,8 @@ def c_type_to_rust(t):
         r = base
     elif base in ENUMS:
         r = "c_int"
+    elif base in CALLBACKS:
+        r = base
     else:
         raise ValueError("unknown C base type: " + base)
     levels = re.findall(r"\*( ?const)?", ptrs)
@@ -64,6 +67,7 @@ def parse_header(path=HEADER):
     src = strip_comments(open(path).read())
     src = re.sub(r"#[^\n]*", " ", src)
     body = src[src.index('extern "C" {') + len('extern "C" {'):]
+    body = re.sub(r"typedef\s+[A-Za-z_][A-Za-z_0-9 \*]*\(\s*\*\s*[a-z_]+\s*\)\s*\([^;]*\)\s*;", " ", body)      # function-pointer typedefs
     funcs = {}
     for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(pc_hip_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", body, flags=re.S):
         ret, name, params = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())

@@ -45,7 +45,8 @@ while time.time() - t0 < budget:
         it = iter(range(lg))
         cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
         tm = {}
-        got = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, timings=tm)
+        got = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, timings=tm,
+                                  python_loop=rng.random() < 0.3)
         cases += 1
         for k in tm.get("ec_fold_kind", []):
             kinds_seen[k] = kinds_seen.get(k, 0) + 1
