@@ -1734,8 +1734,9 @@ int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs_c, const void* coeffs_
 }
 
 // The halving loop of InnerProductArgPC::open (ipa_pc/mod.rs:664-711) as ONE call: everything the round-by-round entry points above do,
-// in the order poly_commit_amd/ipa.py and host/ipa_pc.hpp drive them, without a host language between the rounds (the 16 rounds on the
-// fixed key are a latency chain: ~190 us of every ~850 us round were the harness).  The transcript stays the caller's: `next_challenge`
+// in the order poly_commit_amd/ipa.py and host/ipa_pc.hpp drive them, without a host language between the rounds (measured: 61.1-61.9 ms
+// against 62.2 ms driven from Python at 2^22 -- the rounds are bound by the device's dependency chain; what the call buys a binding is
+// one entry point instead of ~150 calls).  The transcript stays the caller's: `next_challenge`
 // gets the round's l and r (affine, Montgomery x || y; all zeros = infinity) and returns the challenge u (Montgomery Fr).
 static void* ipa_buffer(pc_ctx* ctx, int i, size_t bytes) {
   if (bytes > ctx->ipa_bytes[i]) {
