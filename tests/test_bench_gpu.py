@@ -42,6 +42,7 @@ def run_bench(argv, env_extra=None, timeout=900):
     import tempfile
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.pop("PC_BENCH_FULL_LINE", None)          # (tools/gpu_full_run.sh exports it for its own records: the tests check the driver's line)
     env.update(env_extra or {})
     with tempfile.TemporaryDirectory() as td:
         env["PC_BENCH_DETAIL"] = os.path.join(td, "detail.json")
@@ -123,7 +124,7 @@ def test_two_ranks_started_by_torchrun_as_the_driver_does(tmp_path):
     the command line of the driver's scaling runs (the ranks come from the environment, nothing is self-launched): one JSON line
     from rank 0, weak scaling, both ranks' chunks in the parity check."""
     env = dict(os.environ, PC_BENCH_DEVICES="0,0", PC_BENCH_DETAIL=str(tmp_path / "detail.json"))
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PC_BENCH_FULL_LINE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-degree", "14", "--steps", "3", "--warmup", "1",
@@ -147,7 +148,7 @@ def test_eight_ranks_started_by_torchrun_as_the_driver_does(tmp_path):
     device): ONE polynomial of 8 x 2^13 coefficients over eight real chunks of one true SRS, every commitment / proof of the timed
     region against the closed form of the WHOLE polynomial; the line carries what the N = 1 line carries."""
     env = dict(os.environ, PC_BENCH_DETAIL=str(tmp_path / "detail.json"), **EIGHT)
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PC_BENCH_FULL_LINE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", "29793", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--log-degree", "13", "--steps", "3", "--warmup", "1"]

@@ -7,7 +7,7 @@ export PC_BENCH_FULL_LINE=1          # the runs below record bench.py's FULL rec
 make -s -C oracle
 nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null
 timeout -k 10 240 tools/microbench > gpurun_out/d_microbench.txt 2>&1
-if [ -z "$SKIP_TESTS" ]; then timeout -k 10 1800 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/d_pytest.log 2>&1; tail -8 gpurun_out/d_pytest.log; fi
+if [ -z "$SKIP_TESTS" ]; then PC_BENCH_FULL_LINE= timeout -k 10 1800 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/d_pytest.log 2>&1; tail -8 gpurun_out/d_pytest.log; fi
 timeout -k 10 200 python __graft_entry__.py smoke 2>&1 | tail -1
 PC_BENCH_FULL_LINE= PC_BENCH_DETAIL=$R/gpurun_out/d_bench_n1.json timeout -k 10 900 python bench.py > gpurun_out/d_bench_n1_line.json 2> gpurun_out/d_bench.err; tail -2 gpurun_out/d_bench.err; wc -c gpurun_out/d_bench_n1_line.json
 timeout -k 10 600 python bench.py --inflight 0 --no-cpu-baseline --workloads none > gpurun_out/d_bench_n1_inflight0.json 2>/dev/null
