@@ -145,3 +145,32 @@ def test_emit_writes_the_detail_file_and_one_short_line(tmp_path, monkeypatch):
     assert out.count("\n") == 1 and len(out) <= 6145
     assert json.loads(out)["detail"] == str(tmp_path / "detail.json")
     assert json.load(open(tmp_path / "detail.json")) == d
+
+
+# ---- the counter summaries behind roofline.traffic ----------------------------------------------------------------------------------
+def test_pmc_summary_takes_the_launches_of_the_largest_geometry(tmp_path):
+    """tools/pmc_summary.py: a kernel's traffic per launch is averaged over the launches of its LARGEST grid only (round 5 averaged the
+    320 slab launches of the host-to-host Ligero leg into the whole-batch NTT launch: 0.21 GB instead of 7.2 GB)."""
+    import csv
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary as P
+    f = tmp_path / "c.csv"
+    rows = [("1", "16777216", "512", "void pc::k_ntt_pass_a<F>(a, b)", "FETCH_SIZE", "1000"), ("1", "16777216", "512", "void pc::k_ntt_pass_a<F>(a, b)", "FETCH_SIZE", "500"),
+            ("2", "16777216", "512", "void pc::k_ntt_pass_a<F>(a, b)", "FETCH_SIZE", "1700")] + \
+           [(str(10 + i), "262144", "512", "void pc::k_ntt_pass_a<F>(a, b)", "FETCH_SIZE", "20") for i in range(50)] + \
+           [("3", "16777216", "512", "void pc::k_ntt_pass_a<F>(a, b)", "WRITE_SIZE", "9")]
+    with open(f, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Dispatch_Id", "Grid_Size", "Workgroup_Size", "Kernel_Name", "Counter_Name", "Counter_Value"])
+        w.writerows(rows)
+    got = P.per_kernel(str(f), "FETCH_SIZE")["void pc::k_ntt_pass_a<F>"]
+    assert got["launches"] == 2 and got["avg_per_launch_KiB"] == 1600.0 and got["grid_size"] == 16777216 and got["launches_all_geometries"] == 52
+
+
+def test_bench_refuses_a_counter_traffic_below_the_algorithmic_bytes(capsys):
+    import bench
+    assert bench.checked_traffic(7.2e9, 2.684e9) == 7.2e9
+    assert bench.checked_traffic(2.08e8, 2.684e9) is None          # round 5's figure
+    assert bench.checked_traffic(None, 2.684e9) is None and bench.checked_traffic(5.0, None) == 5.0
+    # and the committed summary holds the NTT batch's traffic above its algorithmic bytes
+    assert bench.pmc_traffic("ntt:bls12_381:2^24", "ntt_hbm_bytes_per_batch") > 2684354560
