@@ -1604,6 +1604,23 @@ int pc_hip_srs_precompute_fold_ex(pc_ctx* ctx, pc_srs* srs, unsigned levels, uns
     try { ops.fold_table_build(ctx->be, srs->bases + q * (size_t)srs->aw, pts, w, t); }
     catch (...) { ctx->be.free(t); throw; }
     srs->fold_tbl = t; srs->fold_half = q; srs->fold_pts = pts; srs->fold_levels = L; srs->fold_w = w;
+    // The working key the first opening on this key will fold into (q points and three pipelines: ~10 ms of allocations) is made now,
+    // with the table, instead of inside that opening; it waits in the key's cache like one an opening handed back (pc_hip_ctx_trim
+    // releases it, pc_hip_ec_fold[2]_from re-creates it on demand).
+    if (!srs->work_cache && !srs->parent && q >= 2) {
+      pc_srs* wk = new (std::nothrow) pc_srs();
+      if (wk) {
+        wk->ctx = ctx; wk->curve = srs->curve; wk->n = q; wk->aw = srs->aw; wk->cfg = ctx->msm_cfg;
+        ctx->keys.push_back(wk);
+        try {
+          wk->bases = (uint32_t*)ctx->be.alloc(q * pb);
+          ctx->be.memset(wk->bases, 0, q * pb);                  // points at infinity until an opening folds into it
+          for (int i = 0; i < PC_MSM_LANES; i++) srs_lane(wk, i);
+          ctx->be.sync();
+          wk->parent = srs; srs->work_cache = wk;
+        } catch (...) { wk->parent = nullptr; srs_free_locked(wk); (void)hipGetLastError(); }      // no memory for it now: the opening will try again
+      }
+    }
     return (int)PC_OK;
   });
 }
