@@ -1020,6 +1020,7 @@ def latency_sweep(ctx, curve, logs, cpu_max_log):
     cores = effective_cores()
     rows = {}
     crossover = None
+    ctx.set_timing(False)      # (blocking calls as a caller makes them: no per-phase event marks, which also keep small calls off their launch graphs)
     for lg in logs:
         n = (1 << lg) + 1
         srs = ctx.upload_srs(curve, pts.data_ptr(), n=n)         # the key trimmed to this degree (MarlinKZG10::trim)
@@ -1070,6 +1071,7 @@ def latency_sweep(ctx, curve, logs, cpu_max_log):
         del co
     del pts
     torch.cuda.empty_cache()
+    ctx.set_timing(True)
     return {"curve": curve, "rows": rows,
             "cpu_faster_up_to_log_degree": crossover,
             "note": "blocking trait-shaped commit+open (host coefficients, key trimmed to the degree, window table built at trim) "

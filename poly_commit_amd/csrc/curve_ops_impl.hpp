@@ -96,7 +96,7 @@ struct MsmRunnerT : MsmRunner {
       be.copy_h2d(plan.scalar_staging(), scalars, n * (size_t)C::FrP::N * 4);
       sdev = plan.scalar_staging();
     }
-    if (graphs_on && !be.timing && where == PC_MEM_DEVICE && n >= 32 && n <= graph_max_n) {
+    if (graphs_on && !be.timing && where == PC_MEM_DEVICE && n >= 32 && n <= graph_max_n) {      // (host scalars through the staging buffer as well: measured, 1.12 vs 1.15 ms for a blocking commit+open at 2^10 -- a blocking call's launches are queued beside its own kernels -- not taken)
       GraphSlot* s = slot_for(CallKey{bases, base_off, sdev, n, from_mont});
       s->stamp = ++clock;
       if (s->seen >= 1 && !s->exec && s->plain_epoch == be.free_epoch && !capture(*s, bases, base_off, sdev, n, from_mont)) graphs_on = false;   // this runner stays on plain launches
