@@ -16,7 +16,7 @@
 //! | `p / (x - z)` (`kzg10/mod.rs:217-240`) | `pc_hip_witness_poly`, the quotient never leaves HBM |
 //! | `p += (challenge_j, polynomial)` (`marlin_pc/mod.rs:281-287`) | `pc_hip_fr_lincomb` over the device copies of the polynomials |
 //! | `ck.powers` / `ck.comm_key` | resident in HBM, uploaded the first time a key is seen ([`device::resident`]) |
-//! | IPA halving loop (`ipa_pc/mod.rs:664-711`) | `pc_hip_msm_async` x2, `pc_hip_fr_dot`, `pc_hip_fr_fold`, `pc_hip_ec_fold` / `pc_hip_ipa_key_scalars` |
+//! | IPA halving loop (`ipa_pc/mod.rs:664-711`) | `pc_hip_msm_async` x2, `pc_hip_ipa_fold_dots`, `pc_hip_ipa_round2_msms` + `pc_hip_ec_fold2_from` (rounds 1-2), `pc_hip_ec_fold` / `pc_hip_ipa_key_scalars` |
 //! | `reed_solomon` (`linear_codes/utils.rs:112-127`) | [`ligero::HipUnivariateLigero`] -> `pc_hip_ntt_batch` |
 //!
 //! Below [`device::min_pairs`] pairs the shim keeps `ark-ec`'s CPU `msm_bigint` (a launch sequence costs ~1 ms; see
