@@ -72,6 +72,7 @@ struct pc_srs {
   // hands it back to the committer key it was folded from (a fresh key cost ~4 ms of pipeline workspace allocation per opening)
   pc_srs* parent = nullptr;      // the key this one was folded from (while that key is alive)
   pc_srs* work_cache = nullptr;  // a returned working key, ready for reuse
+  pc_srs* fixed_cache = nullptr; // pc_hip_ipa_open_rounds: the key object of the late rounds' FIXED key (n0 points, its window table, its pipelines), refilled by every opening
   pc_srs* work_out = nullptr;    // the working key currently handed out
   int aw = 0;                    // words per affine point
   pc::MsmConfig cfg;
@@ -230,6 +231,7 @@ void pc_hip_shutdown(pc_ctx* ctx) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     std::vector<pc_srs*> alive = ctx->keys, cached;
     for (pc_srs* s : alive) if (s->work_cache) { cached.push_back(s->work_cache); s->work_cache = nullptr; }
+    for (pc_srs* s : alive) if (s->fixed_cache) { cached.push_back(s->fixed_cache); s->fixed_cache = nullptr; }
     for (pc_srs* s : alive) { s->parent = nullptr; s->work_out = nullptr; }
     for (pc_srs* s : alive) { srs_release_device(s); s->ctx = nullptr; }
     for (pc_srs* s : cached) delete s;
@@ -422,6 +424,7 @@ static void srs_free_locked(pc_srs* srs) {
     srs->parent = nullptr;                             // the cache is taken: a real free
   }
   if (srs->work_cache) { srs->work_cache->parent = nullptr; srs_free_locked(srs->work_cache); srs->work_cache = nullptr; }
+  if (srs->fixed_cache) { pc_srs* f = srs->fixed_cache; srs->fixed_cache = nullptr; f->parent = nullptr; srs_free_locked(f); }
   if (srs->work_out) { srs->work_out->parent = nullptr; srs->work_out = nullptr; }      // still held by the caller: it frees it
   srs_release_device(srs);
   delete srs;
@@ -889,6 +892,7 @@ int pc_hip_ctx_trim(pc_ctx* ctx) {
     // working keys that an opening handed back (pc_hip_ec_fold_from keeps one per committer key, with its three pipelines)
     std::vector<pc_srs*> cached;
     for (pc_srs* s : ctx->keys) if (s->work_cache) { cached.push_back(s->work_cache); s->work_cache = nullptr; }
+    for (pc_srs* s : ctx->keys) if (s->fixed_cache) { cached.push_back(s->fixed_cache); s->fixed_cache = nullptr; }
     for (pc_srs* w : cached) { w->parent = nullptr; pc_hip_srs_free(w); }
     // idle pipelines give their sort / scan scratch back (the plan's own workspace stays: it is what makes the next call cheap)
     for (pc_srs* s : ctx->keys)
@@ -1755,6 +1759,10 @@ int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs_c, const void* coeffs_
 // against 62.2 ms driven from Python at 2^22 -- the rounds are bound by the device's dependency chain; what the call buys a binding is
 // one entry point instead of ~150 calls).  The transcript stays the caller's: `next_challenge`
 // gets the round's l and r (affine, Montgomery x || y; all zeros = infinity) and returns the challenge u (Montgomery Fr).
+static bool ipa_fixed_table() {      // PC_HIP_IPA_FIXED_TABLE=0: the late rounds run table-free on the working key (round 5's form)
+  static const bool on = []() { const char* e = getenv("PC_HIP_IPA_FIXED_TABLE"); return !(e && !strcmp(e, "0")); }();
+  return on;
+}
 static void* ipa_buffer(pc_ctx* ctx, int i, size_t bytes) {
   if (bytes > ctx->ipa_bytes[i]) {
     if (ctx->ipa_buf[i]) { ctx->be.sync(); ctx->be.free(ctx->ipa_buf[i]); ctx->ipa_buf[i] = nullptr; ctx->ipa_bytes[i] = 0; }
@@ -1775,6 +1783,7 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
   const size_t pb = (size_t)root->aw * 4;                       // bytes of an affine point
   if (!fixed_key_below) fixed_key_below = (size_t)1 << 16;      // (2^16: EXPERIMENTS 00; (size_t)-1 >> 1 or any value below 2: never / always fold the key)
   pc_srs* srs = root; bool owned = false;
+  pc_srs* fixed = nullptr;                                      // the fixed key's own object (window table), or null: the working key serves the late rounds
   struct KeyGuard { pc_srs*& k; bool& owned; ~KeyGuard() { if (owned && k) pc_hip_srs_free(k); } } key_guard{srs, owned};
   void* z = nullptr; void* s_dev = nullptr; char* alr = nullptr;
   int rc = guarded(ctx, [&]() { z = ipa_buffer(ctx, 0, n * 32); return (int)PC_OK; });
@@ -1802,14 +1811,39 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
       if (rc == PC_OK) rc = pc_hip_fr_powers(ctx, curve, one, n0, s_dev);                        // s = (1, 1, ..)
       if (rc != PC_OK) break;
       have_u_prev = false;                                                                      // the key itself carries every fold so far
+      // The fixed key serves 2 log2(n0) + 1 MSMs of n0 pairs: with a window table (one shared bucket set, fewer digits) each costs
+      // ~0.15 ms less.  The table lives in a key object that belongs to the committer key and is REFILLED by every opening (points
+      // copied on the device, table rebuilt in place: no allocation, the pipelines and their captured launch graphs stay): building a
+      // new key with its table per opening cost 7-8 ms (EXPERIMENTS 00), refilling one costs what its kernels take.
+      if (ipa_fixed_table() && n0 >= ((size_t)1 << 12) && n0 <= ((size_t)1 << 18)) {
+        const int frc = guarded(ctx, [&]() {
+          pc_srs* fk = root->fixed_cache;
+          if (fk && fk->n != n0) { root->fixed_cache = nullptr; srs_free_locked(fk); fk = nullptr; }
+          if (!fk) {
+            fk = new pc_srs();
+            fk->ctx = ctx; fk->curve = curve; fk->n = n0; fk->aw = root->aw; fk->cfg = ctx->msm_cfg;
+            ctx->keys.push_back(fk);
+            root->fixed_cache = fk;
+            fk->bases = (uint32_t*)ctx->be.alloc(n0 * pb);
+          }
+          ctx->be.copy_d2d(fk->bases, srs->bases, n0 * pb);
+          if (!fk->table) return pc_hip_srs_precompute_ex(ctx, fk, 0, 1, 0);                    // first opening: table, pipelines (full form: the key is small)
+          for (int i = 0; i < PC_MSM_LANES; i++)
+            if (fk->lanes[i] && fk->lanes[i]->inflight) complete_job(ctx, fk->lanes[i]->inflight);
+          ops.window_table(ctx->be, fk->bases, (uint32_t)n0, fk->cfg.tbl_c, table_windows(fk, fk->cfg.tbl_c, false), fk->table, fk->cfg.tbl_pt_stride);
+          return (int)PC_OK;
+        });
+        if (frc == PC_OK) fixed = root->fixed_cache;                                            // (on any failure the rounds run table-free on the working key, as before)
+        else (void)hipGetLastError();
+      }
     }
     uint32_t* ml = pts.data(); uint32_t* hl = ml + root->aw; uint32_t* mr = hl + root->aw; uint32_t* hr = mr + root->aw;
     pc_job* jl = nullptr; pc_job* jr = nullptr;
     // l = cm_commit(key_l, coeffs_r) + h' <coeffs_r, z_l>;  r = cm_commit(key_r, coeffs_l) + h' <coeffs_l, z_r>          :666-675
     if (n0) {
       rc = pc_hip_ipa_key_scalars(ctx, curve, c, m, s_dev, n0, have_u_prev ? u_prev : nullptr, have_u_prev ? 2 * m : 0, alr, alr + 32 * n0);
-      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, 0, alr, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, ml, nullptr, &jl);
-      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, srs, 0, alr + 32 * n0, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, mr, nullptr, &jr);
+      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, fixed ? fixed : srs, 0, alr, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, ml, nullptr, &jl);
+      if (rc == PC_OK) rc = pc_hip_msm_async(ctx, fixed ? fixed : srs, 0, alr + 32 * n0, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, mr, nullptr, &jr);
     } else if (have_u_first) {
       rc = pc_hip_ipa_round2_msms(ctx, srs, c, h, u_first, ml, nullptr, mr, nullptr);
     } else {
@@ -1851,7 +1885,7 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
     if (out_round_ms) out_round_ms[round] = std::chrono::duration<float, std::milli>(t_end - t_round).count();
   }
   if (rc == PC_OK && n0 && have_u_prev) rc = pc_hip_ipa_key_scalars(ctx, curve, nullptr, 0, s_dev, n0, u_prev, 2, nullptr, nullptr);      // the last fold (size 2)
-  if (rc == PC_OK) rc = n0 ? pc_hip_msm(ctx, srs, 0, s_dev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, out_final_key_xy, nullptr)           // sum_j s_j K0_j
+  if (rc == PC_OK) rc = n0 ? pc_hip_msm(ctx, fixed ? fixed : srs, 0, s_dev, PC_SCALARS_MONTGOMERY, PC_MEM_DEVICE, n0, out_final_key_xy, nullptr)           // sum_j s_j K0_j
                            : pc_hip_srs_read(ctx, srs, 0, 1, out_final_key_xy);
   if (rc == PC_OK) rc = pc_hip_memcpy_d2h(ctx, out_c_host, coeffs_dev, 32);
   return rc;

@@ -147,6 +147,7 @@ void build_window_table(HipBackend& be, const uint32_t* bases, uint32_t n, uint3
   // PC_HIP_TABLE_BUILD=serial: one lane per base walking its chain and inverting at every window (the round-1 build)
   static const bool serial = []() { const char* e = getenv("PC_HIP_TABLE_BUILD"); return e && !strcmp(e, "serial"); }();
   if (serial) { WindowTableBody<C> b{bases, n, c, Wd, table, stride}; be.launch(b, n, 64); be.sync(); }
+  else if ((size_t)(Wd > 1 ? Wd - 1 : 0) * n <= TABLE_ONESHOT_MAX_POINTS) build_window_table_oneshot<C>(be, bases, n, c, Wd, table, stride);
   else build_window_table_batched<C>(be, bases, n, c, Wd, table, stride);
 }
 

@@ -615,6 +615,47 @@ void build_window_table_batched(Backend& be, const uint32_t* bases, uint32_t n, 
   be.free(state);
 }
 
+// The same table for SMALL keys in one normalisation: the Jacobian states of all windows are kept (window w from window w - 1 by c
+// doublings, a launch each) and ONE JacBatchAffineBody pass normalises the (Wd - 1) n points together -- one inversion chain in the
+// whole build instead of one per window, and the backend's grow-only workspace instead of an allocation.  What the window-by-window
+// build costs a small key is latency: 15 x (16 doublings + an inversion chain) and a hipMalloc / hipFree pair, ~5 ms for the 2^16
+// points of an IPA opening's fixed key, against ~1 ms here.  Affine coordinates are canonical: the table is the same, bit for bit.
+template <class C>
+struct TableDoubleToBody {      // out[i] = 2^c * in[i]
+  typedef Fd<typename C::FqP> Fq;
+  static constexpr int FN = Fq::N;
+  const uint32_t* in; uint32_t* out; uint32_t c;
+  PC_HD void operator()(uint32_t i) const {
+    const uint32_t* s = in + (size_t)i * 3 * FN;
+    uint32_t* o = out + (size_t)i * 3 * FN;
+    JacD<C> a; a.X = Fq::load(s); a.Y = Fq::load(s + FN); a.Z = Fq::load(s + 2 * FN);
+    for (uint32_t k = 0; k < c; k++) a = a.dbl();
+    if (a.is_inf()) { Fq::zero().store(o); Fq::zero().store(o + FN); Fq::zero().store(o + 2 * FN); }
+    else { a.X.store(o); a.Y.store(o + FN); a.Z.store(o + 2 * FN); }
+  }
+};
+static constexpr size_t TABLE_ONESHOT_MAX_POINTS = (size_t)1 << 21;      // (Wd - 1) n up to here: 268 MB of workspace for the 8-limb curves
+template <class C, class Backend>
+void build_window_table_oneshot(Backend& be, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t Wd, uint32_t* table, uint32_t stride,
+                                uint32_t K = 16) {
+  constexpr int FN = Fd<typename C::FqP>::N;
+  if (!n) return;
+  const size_t pts = (size_t)(Wd > 1 ? Wd - 1 : 0) * n;
+  uint32_t* st0 = (uint32_t*)be.workspace(((size_t)n * 3 * FN + pts * 4 * FN) * 4);      // state of window 0 | states of windows 1 .. | prefix products
+  uint32_t* sts = st0 + (size_t)n * 3 * FN;
+  uint32_t* scratch = sts + pts * 3 * FN;
+  { TableInitBody<C> b{bases, table, stride, st0}; be.launch(b, n); }
+  for (uint32_t w = 1; w < Wd; w++) {
+    TableDoubleToBody<C> b{w == 1 ? st0 : sts + (size_t)(w - 2) * n * 3 * FN, sts + (size_t)(w - 1) * n * 3 * FN, c};
+    be.launch(b, n);
+  }
+  if (pts) {
+    JacBatchAffineBody<C> nb{sts, scratch, table + (size_t)n * stride, (uint32_t)pts, K, stride};
+    be.launch(nb, (pts + K - 1) / K);
+  }
+  be.sync();
+}
+
 // window width for the table mode: n * (bits/c + 1) mixed adds against ~3 * 2^(c-1) reduction adds
 inline uint32_t msm_choose_table_c(size_t n, uint32_t scalar_bits = 255, uint32_t min_top_bits = 5, bool glv = false) {
   uint32_t best = 8; double best_cost = 1e300;

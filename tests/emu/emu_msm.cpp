@@ -425,7 +425,9 @@ static int table_builds_agree(const uint32_t* bases, uint32_t n, uint32_t c, uin
   CpuStepBackend be;
   { pc::WindowTableBody<C> body{bases, n, c, Wd, a.data(), stride}; be.launch(body, n); }
   pc::build_window_table_batched<C>(be, bases, n, c, Wd, b.data(), stride, K);
-  return a == b;
+  std::vector<uint32_t> d((size_t)Wd * n * stride, 0xabababab);      // and the one-normalisation build of small keys
+  pc::build_window_table_oneshot<C>(be, bases, n, c, Wd, d.data(), stride, K);
+  return a == b && a == d;
 }
 extern "C" int emu_table_builds_agree(int curve, const uint32_t* bases, uint32_t n, uint32_t c, uint32_t stride, uint32_t K) {
   switch (curve) {
