@@ -1834,7 +1834,10 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
           return (int)PC_OK;
         });
         if (frc == PC_OK) fixed = root->fixed_cache;                                            // (on any failure the rounds run table-free on the working key, as before)
-        else (void)hipGetLastError();
+        else {                                                                                  // a half-made object is not kept: the next opening starts over
+          (void)hipGetLastError();
+          if (pc_srs* fk = root->fixed_cache) { root->fixed_cache = nullptr; (void)guarded(ctx, [&]() { srs_free_locked(fk); return (int)PC_OK; }); }
+        }
       }
     }
     uint32_t* ml = pts.data(); uint32_t* hl = ml + root->aw; uint32_t* mr = hl + root->aw; uint32_t* hr = mr + root->aw;

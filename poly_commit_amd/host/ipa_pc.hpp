@@ -89,7 +89,7 @@ struct InnerProductArgPC {
   // opening_challenges: what the caller's sponge squeezed, one per polynomial (:502, then :525/:556).
   static Error open(pc_ctx* ctx, const IpaCommitterKey<E>& ck, const std::vector<const DensePolynomial<E>*>& polynomials,
                     const std::vector<G1Affine<E>>& commitments, const Fr& point, const std::vector<Fr>& opening_challenges,
-                    IpaProof<E>& proof, size_t fixed_key_below = (size_t)1 << 16, bool two_level_table = false) {
+                    IpaProof<E>& proof, size_t fixed_key_below = (size_t)1 << 16, bool two_level_table = false, bool one_call = false) {
     const size_t d1 = ck.comm_key.size();
     if (polynomials.size() != commitments.size() || polynomials.size() != opening_challenges.size()) { Error e; e.kind = Error::Backend; e.msg = "ipa open: one commitment and one opening challenge per polynomial"; return e; }
     std::vector<Fr> combined(d1, Fr::zero());
@@ -111,7 +111,46 @@ struct InnerProductArgPC {
     const Fr round_challenge = t.challenge();
     const G1Affine<E> h_prime = ck.h.mul(round_challenge);
     IpaRandomOracle<E> ro(round_challenge);
+    if (one_call) return open_rounds_one_call(ctx, ck.comm_key, combined, point, h_prime, ro, proof, fixed_key_below);
     return open_rounds(ctx, ck.comm_key, combined, point, h_prime, ro, proof, fixed_key_below, two_level_table);
+  }
+
+  // The halving loop as ONE library call (pc_hip_ipa_open_rounds; what the Rust shim's open does): the transcript goes in as a callback,
+  // the library picks fold table / ladder / fixed key -- and keeps the fixed key as a key object with its own window table, which the
+  // loop over the single entry points below cannot express.  Same proof, bit for bit.
+  static void challenge_trampoline(void* user, const void* l_xy, const void* r_xy, void* out_u_mont) {
+    IpaChallengeSource<E>* src = (IpaChallengeSource<E>*)user;
+    const Fr u = src->next(from_out((const uint64_t*)l_xy), from_out((const uint64_t*)r_xy));
+    memcpy(out_u_mont, u.l, 32);
+  }
+  static Error open_rounds_one_call(pc_ctx* ctx, const std::vector<G1Affine<E>>& comm_key, const std::vector<Fr>& coeffs, const Fr& point,
+                                    const G1Affine<E>& h_prime, IpaChallengeSource<E>& challenges, IpaProof<E>& proof,
+                                    size_t fixed_key_below = (size_t)1 << 16) {
+    const size_t n = coeffs.size();
+    if (n == 0 || (n & (n - 1)) || comm_key.size() != n) { Error e; e.kind = Error::Backend; e.msg = "ipa: key / coefficient lengths must be one power of two"; return e; }
+    proof = IpaProof<E>();
+    size_t rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
+    pc_srs* srs = nullptr; void* cdev = nullptr;
+    int rc = pc_hip_srs_upload(ctx, E::ID, comm_key.data(), n, sizeof(G1Affine<E>), PC_MEM_HOST, &srs);
+    if (rc == PC_OK) rc = pc_hip_srs_precompute(ctx, srs, 0, 1);                               // per call here (the key is uploaded per call); once per key for a prover
+    if (rc == PC_OK && n >= 2) { rc = pc_hip_srs_precompute_fold(ctx, srs); if (rc == PC_ERR_UNSUPPORTED) rc = PC_OK; }
+    if (rc == PC_OK) rc = pc_hip_malloc(ctx, n * 32, &cdev);
+    if (rc == PC_OK) rc = pc_hip_memcpy_h2d(ctx, cdev, coeffs.data(), n * 32);
+    uint64_t hp[2 * E::NQ]; h_prime.to_xy(hp);
+    std::vector<uint64_t> lxy((rounds ? rounds : 1) * 2 * E::NQ), rxy((rounds ? rounds : 1) * 2 * E::NQ);
+    uint64_t kxy[2 * E::NQ];
+    if (rc == PC_OK) rc = pc_hip_ipa_open_rounds(ctx, srs, cdev, n, point.l, hp, &challenge_trampoline, &challenges, fixed_key_below,
+                                                 lxy.data(), rxy.data(), kxy, proof.c.l, nullptr, nullptr);
+    if (rc == PC_OK) {
+      for (size_t k = 0; k < rounds; k++) {
+        proof.l_vec.push_back(from_out(lxy.data() + k * 2 * E::NQ));
+        proof.r_vec.push_back(from_out(rxy.data() + k * 2 * E::NQ));
+      }
+      proof.final_comm_key = from_out(kxy);
+    }
+    pc_hip_free(ctx, cdev);
+    pc_hip_srs_free(srs);
+    return rc == PC_OK ? Error() : backend_error(ctx, rc);
   }
 
   // The halving loop of open(): n = comm_key.size() = coeffs.size() = 2^k.

@@ -16,6 +16,10 @@
 //!                 stays FIXED and the folds act on per-base factors s_j (`pc_hip_ipa_key_scalars`): the round's MSMs run
 //!                 over the fixed key with scalars c * s, `final_comm_key = sum_j s_j K_j` is one last MSM -- the same
 //!                 points, bit for bit, without a latency-bound ladder pass per round                  `:699-707`
+//! The loop itself is ONE library call (`pc_hip_ipa_open_rounds`, the transcript handed in as a callback: `next_round_challenge` below):
+//! the library then also keeps the fixed key as a key object with its own window table, refilled per opening, which the entry points
+//! above cannot express (57-58 ms against 62-63 ms at 2^22 over Pallas).  The same loop spelled out over the single entry points is
+//! `open_rounds_by_entry_points` (`PC_HIP_IPA_EXPLICIT_LOOP=1` selects it: same proof, bit for bit).
 //! `compute_random_oracle_challenge`, `check_degrees_and_bounds`, `shift_polynomial` are private in the reference
 //! (`:74-87`, `:205-239`) and restated verbatim.
 use ark_crypto_primitives::sponge::CryptographicSponge;
@@ -39,6 +43,17 @@ use crate::kzg10_hip::{msm, Scalars};
 
 /// Rounds with n at most this keep the key fixed (see the module doc); `PC_HIP_IPA_FIXED_KEY_BELOW` overrides.
 const FIXED_KEY_BELOW: usize = 1 << 16;
+
+/// A key handle of an opening and whether this opening owns it (a working key or a copy: freed on drop, which hands a working key back
+/// to its committer key's cache; the resident committer key itself is not ours to free).
+struct KeyGuard(*mut ffi::pc_srs, bool);
+impl Drop for KeyGuard {
+    fn drop(&mut self) {
+        if self.1 {
+            unsafe { ffi::pc_hip_srs_free(self.0) }
+        }
+    }
+}
 
 pub struct HipIpaPC<G: AffineRepr, D: Digest, P: DenseUVPolynomial<G::ScalarField>> {
     _projective: PhantomData<G>,
@@ -103,41 +118,84 @@ where
         }
     }
 
-    /// The halving loop (`ipa_pc/mod.rs:641-711`) on device-resident vectors.  `coeffs`: the d + 1 padded coefficients of
-    /// the combined polynomial (consumed); returns `(l_vec, r_vec, final_comm_key, c)`.
-    fn open_rounds(ck: &CommitterKey<G>, coeffs: DevicePoly, point: G::ScalarField, h_prime: G, mut round_challenge: G::ScalarField)
+    /// The committer key of an opening as a resident handle.  It stays resident and untouched across openings: round 1's MSMs run on
+    /// it (with its window table), its folds go OUT OF PLACE into working keys (from the key's fold table, built once per key).  A key
+    /// that is a sub-slice of a larger resident allocation is copied instead.
+    fn opening_key(ck: &CommitterKey<G>) -> Result<KeyGuard, Error> {
+        let c = ctx()?;
+        let d1 = ck.comm_key.len();
+        let (resident, off) = device::resident(&ck.comm_key[..])?;
+        if off == 0 && resident.n == d1 {
+            if d1 >= 2 && !resident.fold_table_built.swap(true, std::sync::atomic::Ordering::SeqCst) {
+                // the library's choice of form: two levels (rounds 1 and 2 in one step) with the widest digits that fit half of the
+                // free device memory; one level on small keys
+                let _ = unsafe { ffi::pc_hip_srs_precompute_fold(c.raw, resident.srs) };      // refused / OOM: the ladder fold stays in use
+            }
+            Ok(KeyGuard(resident.srs, false))
+        } else {
+            let mut copy = core::ptr::null_mut();
+            let key_src = (unsafe { ffi::pc_hip_srs_device_ptr(resident.srs) } as usize + off * 16 * G::FQ_LIMBS) as *const c_void;
+            check(c, unsafe { ffi::pc_hip_srs_upload(c.raw, G::CURVE, key_src, d1, 0, ffi::PC_MEM_DEVICE, &mut copy) })?;
+            Ok(KeyGuard(copy, true))
+        }
+    }
+
+    /// `pc_ipa_challenge_fn` of `pc_hip_ipa_open_rounds`: the reference's transcript step (`ipa_pc/mod.rs:681-689`) on the round's
+    /// `(l, r)`.  `user`: the running `round_challenge` (read, replaced); the new one goes back as Montgomery limbs.
+    unsafe extern "C" fn next_round_challenge(user: *mut c_void, l_xy: *const c_void, r_xy: *const c_void, out_u_mont: *mut c_void) {
+        let w = 2 * G::FQ_LIMBS;
+        let round_challenge = &mut *(user as *mut G::ScalarField);
+        let l = G::read_xy(core::slice::from_raw_parts(l_xy as *const u64, w));
+        let r = G::read_xy(core::slice::from_raw_parts(r_xy as *const u64, w));
+        let mut byte_vec = Vec::new();
+        round_challenge.serialize_uncompressed(&mut byte_vec).unwrap();
+        l.serialize_uncompressed(&mut byte_vec).unwrap();
+        r.serialize_uncompressed(&mut byte_vec).unwrap();
+        *round_challenge = Self::compute_random_oracle_challenge(byte_vec.as_slice());
+        let u = round_challenge.to_mont_limbs();
+        core::ptr::copy_nonoverlapping(u.as_ptr(), out_u_mont as *mut u64, 4);
+    }
+
+    /// The halving loop (`ipa_pc/mod.rs:641-711`) on device-resident vectors, one library call.  `coeffs`: the d + 1 padded
+    /// coefficients of the combined polynomial (consumed); returns `(l_vec, r_vec, final_comm_key, c)`.
+    fn open_rounds(ck: &CommitterKey<G>, coeffs: DevicePoly, point: G::ScalarField, h_prime: G, round_challenge: G::ScalarField)
+        -> Result<(Vec<G>, Vec<G>, G, G::ScalarField), Error> {
+        if std::env::var_os("PC_HIP_IPA_EXPLICIT_LOOP").is_some() {
+            return Self::open_rounds_by_entry_points(ck, coeffs, point, h_prime, round_challenge);
+        }
+        let c = ctx()?;
+        let d1 = ck.comm_key.len();
+        let log_d = ark_std::log2(d1) as usize;
+        let w = 2 * G::FQ_LIMBS;
+        let guard = Self::opening_key(ck)?;
+        let mut h_xy = vec![0u64; w];
+        h_prime.write_xy(&mut h_xy);
+        let fixed_below = std::env::var("PC_HIP_IPA_FIXED_KEY_BELOW").ok().and_then(|v| v.parse().ok()).unwrap_or(FIXED_KEY_BELOW);
+        let mut running = round_challenge;                       // the callback's state (:615-625 produced the first value)
+        let mut l_xy = vec![0u64; log_d.max(1) * w];
+        let mut r_xy = vec![0u64; log_d.max(1) * w];
+        let mut fk = vec![0u64; w];
+        let mut c0 = [0u64; 4];
+        check(c, unsafe { ffi::pc_hip_ipa_open_rounds(c.raw, guard.0, coeffs.dev, d1, point.to_mont_limbs().as_ptr() as *const c_void,
+                                                      h_xy.as_ptr() as *const c_void, Some(Self::next_round_challenge),
+                                                      &mut running as *mut G::ScalarField as *mut c_void, fixed_below,
+                                                      l_xy.as_mut_ptr() as *mut c_void, r_xy.as_mut_ptr() as *mut c_void,
+                                                      fk.as_mut_ptr() as *mut c_void, c0.as_mut_ptr() as *mut c_void,
+                                                      core::ptr::null_mut(), core::ptr::null_mut()) })?;
+        let l_vec = (0..log_d).map(|k| G::read_xy(&l_xy[k * w..(k + 1) * w])).collect();
+        let r_vec = (0..log_d).map(|k| G::read_xy(&r_xy[k * w..(k + 1) * w])).collect();
+        Ok((l_vec, r_vec, G::read_xy(&fk), <G::ScalarField as HipField>::from_mont_limbs(c0)))
+    }
+
+    /// The same loop over the single entry points (what `pc_hip_ipa_open_rounds` does inside, minus the fixed key's own table).
+    fn open_rounds_by_entry_points(ck: &CommitterKey<G>, coeffs: DevicePoly, point: G::ScalarField, h_prime: G, mut round_challenge: G::ScalarField)
         -> Result<(Vec<G>, Vec<G>, G, G::ScalarField), Error> {
         let c = ctx()?;
         let fid = <G::ScalarField as HipField>::FIELD_OF;
         let d1 = ck.comm_key.len();
         let log_d = ark_std::log2(d1) as usize;
         let limbs = |x: &G::ScalarField| x.to_mont_limbs();
-
-        // The committer key stays resident and untouched across openings: round 1's MSMs run on it (with its window table), its first
-        // fold goes OUT OF PLACE into a half-size working key (pc_hip_ec_fold_from; from the key's fold table, built once per key),
-        // later folds act on that key in place.  (A key that is a sub-slice of a larger resident allocation is copied instead.)
-        let (resident, off) = device::resident(&ck.comm_key[..])?;
-        struct KeyGuard(*mut ffi::pc_srs, bool);
-        impl Drop for KeyGuard {
-            fn drop(&mut self) {
-                if self.1 {
-                    unsafe { ffi::pc_hip_srs_free(self.0) }      // a working key goes back to its committer key's cache
-                }
-            }
-        }
-        let mut guard = if off == 0 && resident.n == d1 {
-            if d1 >= 2 && !resident.fold_table_built.swap(true, std::sync::atomic::Ordering::SeqCst) {
-                // the library's choice of form: two levels (rounds 1 and 2 in one step, below) with the widest digits that fit half of
-                // the free device memory; one level on small keys
-                let _ = unsafe { ffi::pc_hip_srs_precompute_fold(c.raw, resident.srs) };      // refused / OOM: the ladder fold stays in use
-            }
-            KeyGuard(resident.srs, false)
-        } else {
-            let mut copy = core::ptr::null_mut();
-            let key_src = (unsafe { ffi::pc_hip_srs_device_ptr(resident.srs) } as usize + off * 16 * G::FQ_LIMBS) as *const c_void;
-            check(c, unsafe { ffi::pc_hip_srs_upload(c.raw, G::CURVE, key_src, d1, 0, ffi::PC_MEM_DEVICE, &mut copy) })?;
-            KeyGuard(copy, true)
-        };
+        let mut guard = Self::opening_key(ck)?;
         let mut key = guard.0;
 
         // powers of z (:641-649)

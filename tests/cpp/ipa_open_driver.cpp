@@ -58,6 +58,15 @@ static int run(pc_ctx* ctx, FILE* in, uint32_t n, uint32_t k, const char* out_pa
     if (!same) { printf("the two-level fold path gives another proof\n"); return 1; }
     printf("ipa two-level OK\n");
   }
+  // and as ONE library call (pc_hip_ipa_open_rounds, the transcript as a callback): what the Rust shim's open does
+  for (size_t fkb : {(size_t)4, (size_t)1 << 16}) {
+    IpaProof<E> p3;
+    if (Error e = InnerProductArgPC<E>::open(ctx, ck, pp, comms, point, xi, p3, fkb, false, true)) { printf("open (one call): %s\n", e.msg.c_str()); return 1; }
+    bool same = p3.l_vec.size() == proof.l_vec.size() && p3.c == proof.c && p3.final_comm_key == proof.final_comm_key;
+    for (size_t i = 0; same && i < proof.l_vec.size(); i++) same = p3.l_vec[i] == proof.l_vec[i] && p3.r_vec[i] == proof.r_vec[i];
+    if (!same) { printf("the one-call loop gives another proof\n"); return 1; }
+  }
+  printf("ipa one-call OK\n");
   FILE* out = fopen(out_path, "wb");
   auto wr_pt = [&](const G1Affine<E>& p) { uint64_t xy[2 * E::NQ]; p.to_xy(xy); fwrite(xy, 1, sizeof xy, out); };
   for (auto& p : proof.l_vec) wr_pt(p);

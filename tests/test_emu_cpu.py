@@ -22,11 +22,16 @@ _emu = None
 def emu():
     global _emu
     if _emu is None:
-        so = os.path.join(HERE, "emu", "libemu.so")
+        # PC_EMU_SANITIZE=1 (tools/emu_sanitize.sh): the same bodies under AddressSanitizer + UBSan -- the sanitizer run the GPU pool cannot do
+        san = os.environ.get("PC_EMU_SANITIZE") == "1"
+        so = os.path.join(HERE, "emu", "libemu_san.so" if san else "libemu.so")
         srcs = [os.path.join(HERE, "emu", "emu_msm.cpp")] + [
             os.path.join(HERE, "..", "poly_commit_amd", "csrc", f) for f in ("msm.hpp", "poly.hpp", "ec.hpp", "fp32.hpp", "ipa.hpp", "glv.hpp", "serialize.hpp", "fold_table.hpp")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
+            flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if san else ["-O2"]
+            tmp = "%s.%d.tmp" % (so, os.getpid())                      # (xdist workers may build at once: each its own file, renamed into place)
+            subprocess.check_call(["g++", *flags, "-std=c++17", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+            os.replace(tmp, so)
         _emu = C.CDLL(so)
     return _emu
 

@@ -72,6 +72,37 @@ def test_ipa_open_rounds_on_a_resident_key(ctx, curve, n, fkb, tables):
     srs.free()
 
 
+@pytest.mark.parametrize("curve,n,fkbs", [("pallas", 1 << 14, (1 << 12, 1 << 12, 1 << 13)), ("pallas", 1 << 13, (1 << 13, 1 << 13)),
+                                          ("bn254", 1 << 13, (1 << 12, 1 << 12))])
+def test_ipa_late_rounds_on_the_cached_fixed_key(ctx, curve, n, fkbs):
+    """From 2^12 points up the fixed key of the late rounds is a key object of its own that belongs to the committer key
+    (pc_hip_ipa_open_rounds): the working key's points are copied into it and its window table is refilled by every opening.  First
+    opening (object + table built), a second with the same switch (refilled in place), a third with another switch (object replaced;
+    n0 = n: no fold before the switch) -- each bit for bit the oracle's; the object is the committer key's and goes with it."""
+    import torch
+    from poly_commit_amd import ipa
+    lg = n.bit_length() - 1
+    key = O.gen_bases(curve, n + 1)
+    key[3] = 0
+    comm_key, h_prime = np.ascontiguousarray(key[:n]), key[n]
+    keys_before = ctx.bytes_resident()["n_keys"]
+    srs = ctx.upload_srs(curve, comm_key)
+    srs.precompute(min_pairs=1)
+    srs.precompute_fold()
+    for rep, fkb in enumerate(fkbs):
+        coeffs = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xF1CED + rep, n))
+        point = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xB0B0 + rep, 1))[0]
+        ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, 0xC4A2 + rep, lg))
+        want = O.ipa_rounds(curve, comm_key, coeffs, point, np.ascontiguousarray(h_prime), ch)
+        it = iter(range(lg))
+        cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+        got = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, python_loop=False)
+        assert all((a == b).all() for a, b in zip(got, want)), (rep, fkb)
+    assert ctx.bytes_resident()["n_keys"] > keys_before + 1               # the committer key, its working key and / or its fixed key
+    srs.free()
+    assert ctx.bytes_resident()["n_keys"] == keys_before
+
+
 @pytest.mark.parametrize("curve,n,fkb,levels,w", [("pallas", 1 << 13, 64, 2, 2), ("pallas", 1 << 13, 64, 2, 3), ("pallas", 1 << 13, 64, 2, 4),
                                                   ("pallas", 1 << 12, 1 << 10, 2, 4), ("pallas", 1 << 12, 1 << 11, 2, 4), ("bn254", 1 << 11, 16, 2, 3),
                                                   ("bls12_381", 1 << 10, 16, 2, 4), ("bls12_381", 1 << 10, 16, 1, 4), ("pallas", 1 << 12, 0, 1, 3),
@@ -321,6 +352,7 @@ def test_ipa_open_whole_proof_cpp_host_mirror(curve, n, tmp_path):
         f.write(point.tobytes()); f.write(xi.tobytes())
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "ipa two-level OK" in r.stdout and "ipa one-call OK" in r.stdout, r.stdout      # the explicit loop, its two-level form and pc_hip_ipa_open_rounds agree
     lg, nq = n.bit_length() - 1, 2 * O.fq_limbs(curve)
     got = np.fromfile(fout, dtype=np.uint64)
     assert got.size == (2 * lg + 1) * nq + 4

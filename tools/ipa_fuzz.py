@@ -18,6 +18,9 @@ t0, cases, bad, kinds_seen = time.time(), 0, 0, {}
 while time.time() - t0 < budget:
     curve = rng.choice(["pallas", "pallas", "bn254", "bls12_381"])
     lg = rng.randint(1, 11 if curve == "pallas" else 9)
+    big = curve != "bls12_381" and rng.random() < 0.06                 # now and then a size where the late rounds get the cached fixed key (n0 >= 2^12)
+    if big:
+        lg = rng.randint(12, 13)
     n = 1 << lg
     key = O.gen_bases(curve, n + 1)
     for _ in range(rng.choice([0, 0, 1, 3])):
@@ -28,7 +31,7 @@ while time.time() - t0 < budget:
         coeffs[rng.randrange(n):] = 0
     point = O.f_to_mont(curve, 1, O.gen_scalars(curve, rng.getrandbits(30), 1))[0]
     ch = O.f_to_mont(curve, 1, O.gen_scalars(curve, rng.getrandbits(30), lg))
-    fkb = rng.choice([0, 0, 2, 8, 64, 1 << 9, None])
+    fkb = rng.choice([1 << 12, 1 << 13]) if big else rng.choice([0, 0, 2, 8, 64, 1 << 9, None])
     resident = rng.random() < 0.8
     form = None
     want = O.ipa_rounds(curve, comm_key, coeffs, point, np.ascontiguousarray(h_prime), ch)
