@@ -471,7 +471,7 @@ int pc_hip_srs_precompute_ex(pc_ctx* ctx, pc_srs* srs, unsigned window_bits, siz
     bool glv = (flags & PC_HIP_TABLE_GLV) != 0;
     auto geometry = [&](bool g, uint32_t& c, uint32_t& Wt, size_t& bytes) {
       c = window_bits ? window_bits : pc::msm_choose_table_c(srs->n, bits, 5, g);
-      if (const char* e = getenv("PC_HIP_TBL_C")) { if (!window_bits && atoi(e) >= 4 && atoi(e) <= 23) c = (uint32_t)atoi(e); }      // measurements only
+      if (const char* e = getenv("PC_HIP_TBL_C")) { if (!window_bits && atoi(e) >= 4 && atoi(e) <= 24) c = (uint32_t)atoi(e); }      // measurements only
       Wt = table_windows(srs, c, g);
       bytes = (size_t)Wt * srs->n * pt_stride * 4;
     };
