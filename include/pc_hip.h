@@ -399,7 +399,7 @@ int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs, const void* coeffs_de
  *   coeffs_l += u_k^-1 coeffs_r, z_l += u_k z_r (:691-697);  key_l += u_k key_r (:699-707)
  * with everything the round-by-round entry points above offer, chosen by the library: the committer key's fold table (two levels: rounds
  * 1 and 2 in one step, round 2 on the committer key by linearity), GLV ladder folds, the fixed key with per-base factors from
- * `fixed_key_below` points on (0: the library's default, 2^16; 1: never), captured launch graphs for its small MSMs.  The committer key
+ * `fixed_key_below` points on (0: the library's default, 2^17; 1: never), captured launch graphs for its small MSMs.  The committer key
  * is not modified (the working keys are cached with it); coeffs_dev (n Montgomery scalars, n a power of two <= the key's length) is
  * consumed.  Outputs: l_vec / r_vec = log2(n) affine points each (x || y, Montgomery; all zero = infinity), final_comm_key, c -- the
  * Proof of ipa_pc/data_structures.rs:175-195 without hiding.  out_round_ms / out_fold_ms: optional, log2(n) floats each (wall time of

@@ -1782,7 +1782,9 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
   const pc_curve curve = root->curve;
   const pc::CurveOps& ops = pc::curve_ops(curve);
   const size_t pb = (size_t)root->aw * 4;                       // bytes of an affine point
-  if (!fixed_key_below) fixed_key_below = (size_t)1 << 16;      // (2^16: EXPERIMENTS 00; (size_t)-1 >> 1 or any value below 2: never / always fold the key)
+  // the default: 2^17 when the fixed key gets its window table (56.6 ms at 2^22 against 57.5 with 2^16 and 62.2 with 2^18), 2^16 without
+  // one (EXPERIMENTS 00); any value below 2: the key is folded in every round
+  if (!fixed_key_below) fixed_key_below = (size_t)1 << (ipa_fixed_table() ? 17 : 16);
   pc_srs* srs = root; bool owned = false;
   pc_srs* fixed = nullptr;                                      // the fixed key's own object (window table), or null: the working key serves the late rounds
   struct KeyGuard { pc_srs*& k; bool& owned; ~KeyGuard() { if (owned && k) pc_hip_srs_free(k); } } key_guard{srs, owned};

@@ -125,7 +125,7 @@ struct InnerProductArgPC {
   }
   static Error open_rounds_one_call(pc_ctx* ctx, const std::vector<G1Affine<E>>& comm_key, const std::vector<Fr>& coeffs, const Fr& point,
                                     const G1Affine<E>& h_prime, IpaChallengeSource<E>& challenges, IpaProof<E>& proof,
-                                    size_t fixed_key_below = (size_t)1 << 16) {
+                                    size_t fixed_key_below = 0 /* the library's default: 2^17 */) {
     const size_t n = coeffs.size();
     if (n == 0 || (n & (n - 1)) || comm_key.size() != n) { Error e; e.kind = Error::Backend; e.msg = "ipa: key / coefficient lengths must be one power of two"; return e; }
     proof = IpaProof<E>();

@@ -94,6 +94,13 @@ def ipa_open(ctx, curve, comm_key, h_xy, polys_dev, lens, comms, point_mont, ope
 FIXED_KEY_BELOW = 1 << 16
 
 
+def library_fixed_key_below():
+    """The default of pc_hip_ipa_open_rounds itself: inside the library the fixed key is a key object with its own window table, refilled
+    per opening (rounds of 0.57 ms on 2^17 points, 0.53 on 2^16), and the switch pays one size earlier: 2^17 -- 56.6 ms per opening at
+    2^22 against 57.5 (2^16) and 62.2 (2^18).  PC_HIP_IPA_FIXED_TABLE=0 (no such table): 2^16, as in the loop below."""
+    return 1 << (16 if os.environ.get("PC_HIP_IPA_FIXED_TABLE") == "0" else 17)
+
+
 def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy, next_challenge, timings=None,
                     fixed_key_below=None, python_loop=None):
     """comm_key: n x (x||y) host array, or a resident Srs (it is cloned on the device, not consumed); coeffs_dev: torch cuda int64 tensor (n,4), Montgomery,
@@ -103,7 +110,7 @@ def ipa_open_rounds(ctx, curve, comm_key, coeffs_dev, n, point_mont, h_prime_xy,
     if python_loop is None:
         python_loop = os.environ.get("PC_IPA_PY_LOOP", "0") == "1"
     if fixed_key_below is None:
-        fixed_key_below = FIXED_KEY_BELOW
+        fixed_key_below = FIXED_KEY_BELOW if python_loop else library_fixed_key_below()
     import time
     import torch
     assert n & (n - 1) == 0

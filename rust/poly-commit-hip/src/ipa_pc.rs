@@ -41,7 +41,8 @@ use crate::device::{self, check, ctx, DevicePoly};
 use crate::ffi;
 use crate::kzg10_hip::{msm, Scalars};
 
-/// Rounds with n at most this keep the key fixed (see the module doc); `PC_HIP_IPA_FIXED_KEY_BELOW` overrides.
+/// Rounds with n at most this keep the key fixed in the loop over the single entry points (see the module doc);
+/// `PC_HIP_IPA_FIXED_KEY_BELOW` overrides.  (`pc_hip_ipa_open_rounds` has its own default, 2^17: there the fixed key has a window table.)
 const FIXED_KEY_BELOW: usize = 1 << 16;
 
 /// A key handle of an opening and whether this opening owns it (a working key or a copy: freed on drop, which hands a working key back
@@ -170,7 +171,7 @@ where
         let guard = Self::opening_key(ck)?;
         let mut h_xy = vec![0u64; w];
         h_prime.write_xy(&mut h_xy);
-        let fixed_below = std::env::var("PC_HIP_IPA_FIXED_KEY_BELOW").ok().and_then(|v| v.parse().ok()).unwrap_or(FIXED_KEY_BELOW);
+        let fixed_below: usize = std::env::var("PC_HIP_IPA_FIXED_KEY_BELOW").ok().and_then(|v| v.parse().ok()).unwrap_or(0);      // 0: the library's default
         let mut running = round_challenge;                       // the callback's state (:615-625 produced the first value)
         let mut l_xy = vec![0u64; log_d.max(1) * w];
         let mut r_xy = vec![0u64; log_d.max(1) * w];

@@ -59,7 +59,7 @@ static int run(pc_ctx* ctx, FILE* in, uint32_t n, uint32_t k, const char* out_pa
     printf("ipa two-level OK\n");
   }
   // and as ONE library call (pc_hip_ipa_open_rounds, the transcript as a callback): what the Rust shim's open does
-  for (size_t fkb : {(size_t)4, (size_t)1 << 16}) {
+  for (size_t fkb : {(size_t)4, (size_t)0}) {                    // 0: the library's default switch to the fixed key
     IpaProof<E> p3;
     if (Error e = InnerProductArgPC<E>::open(ctx, ck, pp, comms, point, xi, p3, fkb, false, true)) { printf("open (one call): %s\n", e.msg.c_str()); return 1; }
     bool same = p3.l_vec.size() == proof.l_vec.size() && p3.c == proof.c && p3.final_comm_key == proof.final_comm_key;

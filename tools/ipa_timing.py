@@ -48,7 +48,7 @@ first = runs[0][0]
 t_open, tm, per_round = min(runs, key=lambda r: r[0])
 print(json.dumps({"workload": f"InnerProductArgPC over Pallas, n = 2^{log_n}: commit MSM + {log_n} halving rounds (challenges supplied)",
                   "commit_ms": t_commit * 1e3, "open_rounds_ms": t_open * 1e3, "first_open_rounds_ms": first * 1e3, "openings": len(runs),
-                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open, "fixed_key_below": fkb or ipa.FIXED_KEY_BELOW,
+                  "commit_pairs_per_s": n / t_commit, "open_msm_pairs_per_s": 2 * n / t_open, "fixed_key_below": fkb or (ipa.FIXED_KEY_BELOW if os.environ.get("PC_IPA_PY_LOOP") == "1" else ipa.library_fixed_key_below()),
                   "key_tables": os.environ.get("PC_IPA_TABLES", "1") != "0", "fold_table": list(srs.fold_table_info()) + [srs.bytes_resident()["fold_table"]],
                   "key_tables_build_ms": t_tables * 1e3,
                   "open_breakdown_ms": {k: round(v, 1) for k, v in tm.items()}, "per_round_ms": per_round}))
