@@ -1830,7 +1830,8 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
             fk->bases = (uint32_t*)ctx->be.alloc(n0 * pb);
           }
           ctx->be.copy_d2d(fk->bases, srs->bases, n0 * pb);
-          if (!fk->table) return pc_hip_srs_precompute_ex(ctx, fk, 0, 1, 0);                    // first opening: table, pipelines (full form: the key is small)
+          static const unsigned fixed_c = []() { const char* e = getenv("PC_HIP_IPA_FIXED_C"); int v = e ? atoi(e) : 0; return (unsigned)(v >= 4 && v <= 22 ? v : 0); }();      // measurements: the table's window width
+          if (!fk->table) return pc_hip_srs_precompute_ex(ctx, fk, fixed_c, 1, 0);                    // first opening: table, pipelines (full form: the key is small)
           for (int i = 0; i < PC_MSM_LANES; i++)
             if (fk->lanes[i] && fk->lanes[i]->inflight) complete_job(ctx, fk->lanes[i]->inflight);
           ops.window_table(ctx->be, fk->bases, (uint32_t)n0, fk->cfg.tbl_c, table_windows(fk, fk->cfg.tbl_c, false), fk->table, fk->cfg.tbl_pt_stride);
