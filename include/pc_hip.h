@@ -405,8 +405,8 @@ int pc_hip_ipa_round2_msms(pc_ctx* ctx, const pc_srs* srs, const void* coeffs_de
  * Proof of ipa_pc/data_structures.rs:175-195 without hiding.  out_round_ms / out_fold_ms: optional, log2(n) floats each (wall time of
  * every round, and of its key fold).  What it buys: one call instead of ~150 for a binding (the Rust shim, a C++ prover), and the
  * fixed key as a key object of its own (cached with the committer key, its points copied and its window table refilled on the device
- * by every opening, its captured launch graphs kept) -- the late rounds' MSMs then run against a table: 0.53 instead of 0.85 ms per
- * round.  Measured at 2^22 over Pallas: 57.4-58.1 ms against 62.2-63.3 ms for the same sequence driven through the single entry points
+ * by every opening, its captured launch graphs kept) -- the late rounds' MSMs then run against a table: 0.57 ms on 2^17 points instead of 0.85 ms on 2^16 per
+ * round.  Measured at 2^22 over Pallas: 55.5-56.6 ms against 61.9-63.3 ms for the same sequence driven through the single entry points
  * (PC_HIP_IPA_FIXED_TABLE=0: 62.6 ms here as well -- the host between the rounds is not what the difference is). */
 typedef void (*pc_ipa_challenge_fn)(void* user, const void* l_xy, const void* r_xy, void* out_u_mont);
 int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev, size_t n, const void* point_host, const void* h_prime_xy_host,
