@@ -1818,7 +1818,9 @@ int pc_hip_ipa_open_rounds(pc_ctx* ctx, const pc_srs* comm_key, void* coeffs_dev
       // ~0.15 ms less.  The table lives in a key object that belongs to the committer key and is REFILLED by every opening (points
       // copied on the device, table rebuilt in place: no allocation, the pipelines and their captured launch graphs stay): building a
       // new key with its table per opening cost 7-8 ms (EXPERIMENTS 00), refilling one costs what its kernels take.
-      if (ipa_fixed_table() && n0 >= ((size_t)1 << 12) && n0 <= ((size_t)1 << 18)) {
+      if (ipa_fixed_table() && srs == root && root->table && n0 >= root->cfg.tbl_min_n) {
+        fixed = root;                                                                           // no fold yet and the committer key has its window table: it IS the fixed key, nothing to copy or refill
+      } else if (ipa_fixed_table() && n0 >= ((size_t)1 << 12) && n0 <= ((size_t)1 << 18)) {
         const int frc = guarded(ctx, [&]() {
           pc_srs* fk = root->fixed_cache;
           if (fk && fk->n != n0) { root->fixed_cache = nullptr; srs_free_locked(fk); fk = nullptr; }

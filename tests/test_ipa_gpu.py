@@ -100,7 +100,9 @@ def test_ipa_late_rounds_on_the_cached_fixed_key(ctx, curve, n, fkbs):
         cdev = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
         got = ipa.ipa_open_rounds(ctx, curve, srs, cdev, n, point, h_prime, lambda L, R_: ch[next(it)], fixed_key_below=fkb, python_loop=False)
         assert all((a == b).all() for a, b in zip(got, want)), (rep, fkb)
-    assert ctx.bytes_resident()["n_keys"] > keys_before + 1               # the committer key, its working key and / or its fixed key
+    # the committer key, its working key and its fixed key -- or the committer key alone when it is itself the fixed key (no fold before
+    # the switch and a window table of its own: nothing is copied)
+    assert ctx.bytes_resident()["n_keys"] >= keys_before + (2 if fkbs[-1] < n else 1)
     srs.free()
     assert ctx.bytes_resident()["n_keys"] == keys_before
 
