@@ -1256,18 +1256,30 @@ static size_t ligero_slab_rows(size_t rows, size_t N) {
 }
 
 namespace {
-// Page-aligned, disjoint registrations covering [lo, hi) piece by piece; every copy is cut at the pieces' edges.
+// Page-aligned, disjoint registrations of the WHOLE pages inside [lo, hi), piece by piece; every copy is cut at the pieces' edges.  A page
+// the buffer shares with a neighbour (its first and last bytes, unless it is page-aligned) is NOT registered: the runtime resolves a host
+// pointer to the registration it lies in, and a copy to or from the neighbour that starts inside such a page and runs past the
+// registration's end fails with "invalid argument" (seen as a one-in-three failure of the encoded matrix's copy out when a small
+// coefficient matrix and the output array shared a heap page).
 struct HostPins {
   char* lo = nullptr; char* hi = nullptr; char* done_to = nullptr; size_t piece = (size_t)64 << 20; bool ok = true;
   std::vector<char*> regs;
   size_t freed = 0;                          // pieces [0, freed) are unregistered again
   static uintptr_t page() { static const uintptr_t p = (uintptr_t)sysconf(_SC_PAGESIZE); return p; }
+  char* first() const { return (char*)(((uintptr_t)lo + page() - 1) & ~(page() - 1)); }      // the whole pages inside: [first(), last())
+  char* last() const { char* l = (char*)((uintptr_t)hi & ~(page() - 1)); return l > first() ? l : first(); }
   char* cut(size_t k) const {                // piece k covers [cut(k), cut(k + 1))
+    if (k == 0) return first();
     char* c = lo + k * piece;
-    if (c >= hi) return (char*)(((uintptr_t)hi + page() - 1) & ~(page() - 1));
-    return (char*)((uintptr_t)c & ~(page() - 1));
+    if (c >= last()) return last();
+    c = (char*)((uintptr_t)c & ~(page() - 1));
+    return c < first() ? first() : c;
   }
-  char* piece_end(char* a) const { const size_t k = (size_t)(a - lo) / piece; char* e = cut(k + 1); return e > a ? e : cut(k + 2); }
+  char* piece_end(char* a) const {           // where a copy that starts at a has to stop
+    if (a < first()) return first();                                                          // the unregistered head
+    if (a >= last()) return hi;                                                               // the unregistered tail
+    const size_t k = (size_t)(a - lo) / piece; char* e = cut(k + 1); return e > a ? e : cut(k + 2);
+  }
   void cover(char* upto) {
     while (ok && done_to < upto) {
       const size_t k = regs.size();
