@@ -1237,11 +1237,12 @@ int pc_hip_ipa_key_scalars(pc_ctx* ctx, pc_curve field_of, const void* coeffs_de
 // DMA runs (after a key was freed: 82 / 53 / 43-46 / 52 ms with 1 / 2 / 3 / 4 helpers; quiet: 40-42 ms with any).  The way IN stays with
 // the runtime too: with one helper it was the slow side after a key was freed (a bounce-buffer memcpy at 11 GB/s of the calling
 // thread), with three it hides under the way out, and registering the coefficient matrix's pages from the calling thread instead
-// (PC_HIP_LIGERO_PIN=1: page-aligned pieces just ahead of the copies, released behind them) measured 2-3 ms slower in both states
-// (42.3 vs 40.0 ms quiet, 46.0 vs 42.8 ms after a key was freed: releasing a registration waits for the device).
+// (page-aligned pieces just ahead of the copies, released behind them: built in round 5 as PC_HIP_LIGERO_PIN=1) measured 2-3 ms slower in
+// both states (42.3 vs 40.0 ms quiet, 46.0 vs 42.8 ms after a key was freed: releasing a registration waits for the device) and was
+// REMOVED in round 6: the library maps no caller memory into the device's address space (EXPERIMENTS 00).
 // The whole-matrix path of the same call: 58-60 ms in either state.
 // PC_HIP_LIGERO_SLAB_MB: encoded bytes per slab (default 32; 0 = the whole-matrix path), PC_HIP_LIGERO_HELPERS (default 3, at most 4),
-// PC_HIP_LIGERO_PIN=1: register the coefficient matrix's pages, PC_HIP_LIGERO_TRACE=1: where the threads spent the call, on stderr;
+// PC_HIP_LIGERO_TRACE=1: where the threads spent the call, on stderr;
 // all read per call.  tools/ligero_stream_probe.py sweeps them in both states of the process.
 static constexpr int LIG_MAX_HELPERS = 4;
 static int lig_helpers() { const char* e = getenv("PC_HIP_LIGERO_HELPERS"); const int h = e ? atoi(e) : 3; return h < 1 ? 1 : h > LIG_MAX_HELPERS ? LIG_MAX_HELPERS : h; }
@@ -1254,47 +1255,6 @@ static size_t ligero_slab_rows(size_t rows, size_t N) {
   if (s < 2) s = 2;
   return s * 2 <= rows ? s : 0;                        // fewer than two slabs: nothing to overlap
 }
-
-namespace {
-// Page-aligned, disjoint registrations of the WHOLE pages inside [lo, hi), piece by piece; every copy is cut at the pieces' edges.  A page
-// the buffer shares with a neighbour (its first and last bytes, unless it is page-aligned) is NOT registered: the runtime resolves a host
-// pointer to the registration it lies in, and a copy to or from the neighbour that starts inside such a page and runs past the
-// registration's end fails with "invalid argument" (seen as a one-in-three failure of the encoded matrix's copy out when a small
-// coefficient matrix and the output array shared a heap page).
-struct HostPins {
-  char* lo = nullptr; char* hi = nullptr; char* done_to = nullptr; size_t piece = (size_t)64 << 20; bool ok = true;
-  std::vector<char*> regs;
-  size_t freed = 0;                          // pieces [0, freed) are unregistered again
-  static uintptr_t page() { static const uintptr_t p = (uintptr_t)sysconf(_SC_PAGESIZE); return p; }
-  char* first() const { return (char*)(((uintptr_t)lo + page() - 1) & ~(page() - 1)); }      // the whole pages inside: [first(), last())
-  char* last() const { char* l = (char*)((uintptr_t)hi & ~(page() - 1)); return l > first() ? l : first(); }
-  char* cut(size_t k) const {                // piece k covers [cut(k), cut(k + 1))
-    if (k == 0) return first();
-    char* c = lo + k * piece;
-    if (c >= last()) return last();
-    c = (char*)((uintptr_t)c & ~(page() - 1));
-    return c < first() ? first() : c;
-  }
-  char* piece_end(char* a) const {           // where a copy that starts at a has to stop
-    if (a < first()) return first();                                                          // the unregistered head
-    if (a >= last()) return hi;                                                               // the unregistered tail
-    const size_t k = (size_t)(a - lo) / piece; char* e = cut(k + 1); return e > a ? e : cut(k + 2);
-  }
-  void cover(char* upto) {
-    while (ok && done_to < upto) {
-      const size_t k = regs.size();
-      char* b = cut(k); char* e = cut(k + 1);
-      if (e <= b) { done_to = hi; break; }
-      if (hipHostRegister(b, (size_t)(e - b), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
-      regs.push_back(b); done_to = e;
-    }
-  }
-  void release_below(char* a) {             // every piece that ends at or below a (its copies have completed)
-    while (freed < regs.size() && cut(freed + 1) <= a) { (void)hipHostUnregister(regs[freed]); freed++; }
-  }
-  void release() { for (; freed < regs.size(); freed++) (void)hipHostUnregister(regs[freed]); }
-};
-}  // namespace
 
 static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* mat, size_t rows, size_t in_cols, unsigned log_n, size_t S,
                                   pc_hash col_hash, pc_hash tree_hash, int len_prefix, char* ext_out, void* leaves_out_host, void* nodes_out_host) {
@@ -1313,10 +1273,6 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
   std::mutex mu; std::condition_variable cv;
   size_t queued = 0; std::vector<char> arrived(n_slabs, 0); bool stop = false; int helper_rc = PC_OK; std::string helper_err;
   std::thread helpers[LIG_MAX_HELPERS];
-  HostPins pins_in;
-  pins_in.lo = pins_in.done_to = const_cast<char*>(mat); pins_in.hi = pins_in.lo + rows * in_row;
-  pins_in.ok = false;
-  if (const char* e = getenv("PC_HIP_LIGERO_PIN")) pins_in.ok = e[0] == '1';
   double tr_out[LIG_MAX_HELPERS] = {}, tr_in[3] = {0, 0, 0};      // PC_HIP_LIGERO_TRACE: helpers [copies out], caller [input buffer free, pin + copy in, slab buffer free]
   auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int rc = guarded(ctx, [&]() {
@@ -1372,14 +1328,7 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
       if (s >= (size_t)LIG_BUFS) PC_HIP_CHECK(hipEventSynchronize(done[s - LIG_BUFS]));        // in_dev[b] has been read
       const double t_b = now_ms();
       {
-        char* const h0 = pins_in.lo + r0 * in_row; char* const h1 = h0 + nr * in_row;
-        pins_in.cover(h1);
-        if (s >= (size_t)LIG_BUFS) pins_in.release_below(pins_in.lo + (s - LIG_BUFS + 1) * S * in_row);      // slab s - LIG_BUFS has been read
-        for (char* a = h0; a < h1;) {                     // no copy straddles two registrations
-          char* e = pins_in.ok ? std::min(h1, pins_in.piece_end(a)) : h1;
-          ctx->be.copy_h2d((char*)in_dev[b] + (a - h0), a, (size_t)(e - a));
-          a = e;
-        }
+        ctx->be.copy_h2d(in_dev[b], mat + r0 * in_row, nr * in_row);
       }
       const double t_c = now_ms();
       if (s >= (size_t)LIG_BUFS) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return arrived[s - LIG_BUFS] != 0; }); }   // ext_dev[b] is on the host
@@ -1411,14 +1360,13 @@ static int ligero_commit_streamed(pc_ctx* ctx, pc_curve field_of, const char* ma
   (void)guarded(ctx, [&]() {
     (void)hipStreamSynchronize(ctx->be.stream);
     for (int h = 0; h < LIG_HELPERS; h++) if (ctx->lig_out_q[h]) (void)hipStreamSynchronize(ctx->lig_out_q[h]);
-    pins_in.release();
     ctx->be.free(transient);
     for (auto e : done) if (e) (void)hipEventDestroy(e);
     return (int)PC_OK;
   });
   if (getenv("PC_HIP_LIGERO_TRACE"))
-    fprintf(stderr, "[pc_hip] ligero slabs %zu x %zu rows: helpers' copies out %.1f / %.1f ms | caller in-buffer %.1f pin + copy in %.1f out-buffer %.1f ms (input pinned: %d)\n",
-            n_slabs, S, tr_out[0], tr_out[LIG_HELPERS - 1], tr_in[0], tr_in[1], tr_in[2], (int)pins_in.ok);
+    fprintf(stderr, "[pc_hip] ligero slabs %zu x %zu rows: helpers' copies out %.1f / %.1f ms | caller in-buffer %.1f copy in %.1f out-buffer %.1f ms\n",
+            n_slabs, S, tr_out[0], tr_out[LIG_HELPERS - 1], tr_in[0], tr_in[1], tr_in[2]);
   const float ph[4] = {0, 0, 0, with_digests ? ctx->ntt_phases[0] : 0.f};      // the slabs' kernels overlap the copies: only the tree has a bracket of its own
   memcpy(ctx->ligero_phases, ph, sizeof ph);
   return rc;

@@ -127,10 +127,9 @@ def test_host_to_host_commit_in_row_slabs(ctx, curve, rows, in_cols, log_n, monk
     nodes_d, leaves_d = ctx.ligero_commit(curve, dev, log_n, rows=rows, in_cols=in_cols, ext_out=ext_dev)
     assert (nodes_d == nodes0).all() and (leaves_d == leaves0).all() and (ext_dev.cpu().numpy().view(np.uint64) == ext0).all()
     row_mb = n * 32 / 1048576.0
-    for slab_rows, helpers, pin in ((2, "3", "1"), (4, "1", "1"), (10, "4", "0"), (2, "2", "0"), (rows, "3", "1")):
+    for slab_rows, helpers in ((2, "3"), (4, "1"), (10, "4"), (2, "2"), (rows, "3")):
         monkeypatch.setenv("PC_HIP_LIGERO_SLAB_MB", repr(slab_rows * row_mb * 1.01))
         monkeypatch.setenv("PC_HIP_LIGERO_HELPERS", helpers)      # threads copying slabs out (slab buffers: helpers + 1)
-        monkeypatch.setenv("PC_HIP_LIGERO_PIN", pin)              # the coefficient matrix's pages registered by the call (1) / left to the runtime (0, the default)
         ext = np.full((rows, n, 4), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
         nodes, leaves = ctx.ligero_commit(curve, mat, log_n, ext_out=ext)
         assert (ext == ext0).all(), (curve, slab_rows)
